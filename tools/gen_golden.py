@@ -1,0 +1,124 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only; needs /root/reference).
+
+Each fixture stores: the case description (so inputs/weights/noise are re-derived from seeds with
+oracle.caddy_oracle.make_params / torch generators -- no reference source or weights are stored), the 20 outputs of
+reference Model.forward, the loss terms of the reference loss classes (training/losses.py, VGG term excluded),
+per-parameter gradient summaries, BN buffers / centroids / MI-EMA after the step, and eval-mode roll-out frames
+from Model.generate_next.    Usage:  python tools/gen_golden.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_harness as rh  # noqa: E402
+from oracle import caddy_oracle as O  # noqa: E402
+
+CASES = {
+    # name: variant, K, Da, Ch, S, B, T, H, W, gt, tau, hard, pretraining
+    "full_reduced_s1": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False),
+    "full_main_s1": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=5, H=32, W=32, gt=3, tau=0.4, hard=False, pre=False),
+    "full_main_s4_hard": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=6, H=32, W=48, gt=2, tau=0.9, hard=True, pre=False),
+    "pre_main_s4": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=4, H=32, W=32, gt=0, tau=1.0, hard=False, pre=True),
+}
+LOSS_W = dict(O.DEFAULT_LOSS_WEIGHTS, state_kl=1e-5, entropy=0.01)
+PARAM_SEED, OBS_SEED, NOISE_SEED = 7, 1, 5
+
+
+def case_inputs(c):
+    cfg = rh.make_config(variant=c["variant"], actions=c["K"], action_dim=c["Da"], hidden=c["Ch"], stacking=c["S"],
+                         state_res=(c["H"] // 8, c["W"] // 8), hard_gumbel=c["hard"])
+    d = O.Dims.from_config(cfg)
+    P = O.make_params(d, seed=PARAM_SEED)
+    obs = torch.rand(c["B"], c["T"], 3 * c["S"], c["H"], c["W"], generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
+    return cfg, d, P, obs
+
+
+def flat_outputs(out):
+    res = {}
+    for i, o in enumerate(out):
+        if isinstance(o, (list, tuple)):
+            for j, x in enumerate(o):
+                res[f"out{i}_{j}"] = x.detach().numpy()
+        else:
+            res[f"out{i}"] = o.detach().numpy()
+    return res
+
+
+def main():
+    rh.install()
+    import training.losses as RL
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, c in CASES.items():
+        cfg, d, P, obs = case_inputs(c)
+        ref = rh.build_reference_model(cfg, P)
+        ref.train()
+        acts = torch.zeros(c["B"], c["T"], dtype=torch.int32)
+        torch.manual_seed(NOISE_SEED)
+        random.seed(NOISE_SEED)
+        out = ref((obs, acts, None, None), c["gt"], pretraining=c["pre"], gumbel_temperature=c["tau"])
+        data = flat_outputs(out)
+        data["case"] = np.array(repr(c))
+        if not c["pre"]:
+            smi = RL.SmoothMutualInformationLoss(cfg)
+            rec = [RL.ObservationsLoss()(obs, m) for m in out[1]]
+            comp = {
+                "rec": (sum(r.double() for r in rec) / 3),
+                "states": RL.StatesLoss()(out[3].detach(), out[2]),
+                "entropy": RL.EntropyLogitLoss()(out[6]),
+                "dir_kl": RL.KLGaussianDivergenceLoss()(out[10]),
+                "mi": smi(torch.softmax(out[6], -1), torch.softmax(out[15], -1), lamb=LOSS_W["mi_entropy"]),
+                "state_kl": RL.KLGeneralGaussianDivergenceLoss()(out[18], out[12].detach()),
+            }
+            total = sum(LOSS_W[k] * v for k, v in comp.items())
+            total.backward()
+            data["loss_total"] = np.array(total.item())
+            for k, v in comp.items():
+                data["loss_" + k] = np.array(v.item())
+            data["mi_ema"] = smi.matrix_estimator.estimated_matrix.detach().numpy()
+            names, gsum, gabs, gfirst = [], [], [], []
+            for n, p in ref.named_parameters():
+                if p.grad is None:
+                    continue
+                names.append(n)
+                gsum.append(p.grad.double().sum().item())
+                gabs.append(p.grad.double().abs().sum().item())
+                gfirst.append(p.grad.flatten()[:4].tolist() + [0.0] * max(0, 4 - p.grad.numel()))
+            data["grad_names"] = np.array(names)
+            data["grad_sum"], data["grad_abs"], data["grad_first4"] = np.array(gsum), np.array(gabs), np.array(gfirst, dtype=np.float32)
+        sd = ref.state_dict()
+        for k, v in sd.items():
+            if O.is_buffer(k) and not k.endswith("num_batches_tracked"):
+                data["buf:" + k] = v.numpy()
+        data["centroids"] = sd["centroid_estimator.estimated_centroids"].numpy()
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **data)
+        print(name, "written", sum(v.nbytes for v in data.values()) // 1024, "KiB raw")
+
+    # eval-mode roll-out (play.py path): start_inference + N x generate_next, zero variation
+    for name, c in {"rollout_main_s4": dict(variant="main", K=7, Da=5, Ch=128, S=4, H=32, W=32, steps=4),
+                    "rollout_reduced_s1": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, H=32, W=48, steps=4)}.items():
+        cc = dict(c, B=1, T=1, hard=False)
+        cfg, d, P, obs = case_inputs(cc)
+        ref = rh.build_reference_model(cfg, P)
+        ref.eval()
+        o = obs[0, 0]
+        frames = []
+        torch.manual_seed(NOISE_SEED)
+        with torch.no_grad():
+            ref.start_inference()
+            for i in range(c["steps"]):
+                f, o = ref.generate_next(o, i % c["K"])
+                frames.append(f.numpy())
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), case=np.array(repr(cc | {"steps": c["steps"]})),
+                            frames=np.stack(frames), last_obs=o.numpy())
+        print(name, "written")
+
+
+if __name__ == "__main__":
+    main()
