@@ -1,0 +1,60 @@
+"""ctypes binding of the C-ABI of libcaddy_hip.so (include/caddy_hip.h).
+
+The product path has NO CPU fallback: `load()` raises if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `python -m playablevideogeneration_amd.csrc.build`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libcaddy_hip.so")
+CONV_MAX_SRC = 3
+CONV_BK = 16
+
+
+class TV(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("sn", C.c_long), ("ld", C.c_int)]
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sn", C.c_long), ("ld", C.c_int), ("C", C.c_int), ("Cpad", C.c_int), ("bcast", C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
+                ("wp", C.c_void_p), ("Ktot", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("bias", C.c_void_p), ("act", C.c_int),
+                ("out", C.c_void_p), ("out_sn", C.c_long), ("out_ld", C.c_int), ("accumulate", C.c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
+                ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
+                ("dwp", C.c_void_p), ("slabs", C.c_int)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p * 4), ("gw", C.c_void_p * 4), ("nw", C.c_int), ("Co_each", C.c_int), ("Cin", C.c_int), ("KS", C.c_int),
+                ("nseg", C.c_int), ("seg_off", C.c_int * CONV_MAX_SRC), ("seg_C", C.c_int * CONV_MAX_SRC), ("seg_Cpad", C.c_int * CONV_MAX_SRC),
+                ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int)]
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load the HIP shared library (cached).  Raises RuntimeError when it is missing -- there is no fallback."""
+    global _lib
+    if path is None and _lib is not None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                           "playablevideogeneration_amd has no CPU fallback")
+    lib = C.CDLL(p)
+    if path is None:
+        _lib = lib
+    return lib

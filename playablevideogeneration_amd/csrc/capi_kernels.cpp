@@ -1,0 +1,53 @@
+// C-ABI entry points of the individual kernels (unit-parity tests call these through ctypes; SURVEY.md section 8b
+// "plus per-kernel entry points").  Declared in include/caddy_hip.h.
+#include "common.h"
+#include "pointwise.h"
+#include "pack.h"
+
+#define ST(s) ((hipStream_t)(s))
+extern "C" {
+int caddy_k_conv_fwd(const ConvArgs* a, void* s) { return conv_fwd_launch(*a, ST(s)); }
+int caddy_k_conv_wgrad(const WgradArgs* a, void* s) { return conv_wgrad_launch(*a, ST(s)); }
+int caddy_k_conv_pick_bn(int cout) { return conv_pick_bn(cout); }
+int caddy_k_pack_fwd(const PackDesc* d, float* wp, void* s) { return pack_fwd(*d, wp, ST(s)); }
+int caddy_k_pack_dgrad(const PackDesc* d, int seg, float* wpd, int Cd_pad, int Kd, void* s) { return pack_dgrad(*d, seg, wpd, Cd_pad, Kd, ST(s)); }
+int caddy_k_unpack_wgrad(const PackDesc* d, const float* dwp, void* s) { return unpack_wgrad(*d, dwp, ST(s)); }
+int caddy_k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale, void* s) {
+    return adam_launch(p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, ST(s));
+}
+int caddy_k_copy(const TV* a, const TV* b, int acc, void* s) { return pw_copy(*a, *b, acc, ST(s)); }
+int caddy_k_pool2(const TV* in, const TV* out, void* s) { return pw_pool2(*in, *out, ST(s)); }
+int caddy_k_pool2_bwd(const TV* dout, const TV* din, void* s) { return pw_pool2_bwd(*dout, *din, ST(s)); }
+int caddy_k_up2(const TV* in, const TV* out, void* s) { return pw_up2(*in, *out, ST(s)); }
+int caddy_k_up2_bwd(const TV* dout, const TV* din, void* s) { return pw_up2_bwd(*dout, *din, ST(s)); }
+int caddy_k_stats(const TV* x, double* sums, void* s) { return pw_stats(*x, sums, ST(s)); }
+int caddy_k_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
+                        float* mean, float* invstd, float* scale, float* shift, void* s) {
+    return pw_bn_finalize(sums, count, gamma, beta, rmean, rvar, C, training, mean, invstd, scale, shift, ST(s));
+}
+int caddy_k_bn_apply(const TV* x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV* out, void* s) {
+    return pw_bn_apply(*x, scale, shift, x2, scale2, shift2, act, *out, ST(s));
+}
+int caddy_k_bn_bwd_reduce(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, double* sums, void* s) {
+    return pw_bn_bwd_reduce(*dout, outm, *x, mean, invstd, sums, ST(s));
+}
+int caddy_k_bn_bwd_apply(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                         const TV* dx, float* dgamma, float* dbeta, void* s) {
+    return pw_bn_bwd_apply(*dout, outm, *x, mean, invstd, gamma, sums, *dx, dgamma, dbeta, ST(s));
+}
+int caddy_k_act_bwd_add(const TV* dout, const TV* outm, const TV* dres, void* s) { return pw_act_bwd_add(*dout, *outm, *dres, ST(s)); }
+int caddy_k_lstm_fwd(const TV* gates, const TV* cprev, const TV* h, const TV* cn, void* s) { return pw_lstm_fwd(*gates, *cprev, *h, *cn, ST(s)); }
+int caddy_k_lstm_bwd(const TV* gates, const TV* cprev, const TV* cn, const TV* dh, const TV* dc, const TV* dgates, const TV* dcprev, void* s) {
+    return pw_lstm_bwd(*gates, *cprev, *cn, *dh, *dc, *dgates, *dcprev, ST(s));
+}
+int caddy_k_tanh_bwd(const TV* dy, const TV* y, const TV* dz, void* s) { return pw_tanh_bwd(*dy, *y, *dz, ST(s)); }
+int caddy_k_attn_mul(const TV* x, const TV* out, const TV* att, void* s) { return pw_attn_mul(*x, *out, *att, ST(s)); }
+int caddy_k_attn_mul_bwd(const TV* x, const TV* dout, const TV* datt, const TV* dx, void* s) { return pw_attn_mul_bwd(*x, *dout, *datt, *dx, ST(s)); }
+int caddy_k_gap(const TV* x, float* out, void* s) { return pw_gap(*x, out, ST(s)); }
+int caddy_k_gap_bwd(const float* dout, const TV* dx, void* s) { return pw_gap_bwd(dout, *dx, ST(s)); }
+int caddy_k_colsum(const TV* x, float* out, void* s) { return pw_colsum(*x, out, ST(s)); }
+int caddy_k_spatial_sum(const TV* x, float* out, long out_sn, void* s) { return pw_spatial_sum(*x, out, out_sn, ST(s)); }
+int caddy_k_nchw_to_nhwc(const float* src, long src_sn, const TV* d, void* s) { return pw_nchw_to_nhwc(src, src_sn, *d, ST(s)); }
+int caddy_k_nhwc_to_nchw(const TV* src, float* dst, long dst_sn, int acc, void* s) { return pw_nhwc_to_nchw(*src, dst, dst_sn, acc, ST(s)); }
+int caddy_k_batch_sum(const float* src, long sn, long n_el, int N, float* dst, void* s) { return pw_batch_sum(src, sn, n_el, N, dst, ST(s)); }
+}

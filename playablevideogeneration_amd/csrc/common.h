@@ -1,0 +1,72 @@
+// Shared definitions for the CADDY hot-path HIP kernels (gfx950 / CDNA4).
+//
+// Data layout in HBM: every activation is NHWC fp32, addressed through a `TV` view
+//   addr(n,y,x,c) = p + n*sn + (y*W + x)*ld + c          (ld = pixel stride, sn = sample stride, both in floats)
+// so that channel-concatenation (reference: torch.cat along dim 1), time-slicing of (B,T,...) buffers
+// (reference: tensor[:, t]) and channel-slicing (state = x[:, :-1]) are free views instead of copies.
+// ld is always a multiple of 4 floats and base pointers are 16-byte aligned so float4 accesses are legal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TV {
+    float* p;
+    int N, H, W, C;
+    long sn;
+    int ld;
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// One input segment of a convolution.  A conv reads the channel-concatenation of up to CONV_MAX_SRC segments
+// (reference: ConvLSTMCell.channelwise_concat, convolutional_lstm_cell.py:47-86).  bcast=1: the segment is a
+// per-sample vector (N, C) broadcast over space (the action one-hot / variation inputs of R).
+#define CONV_MAX_SRC 3
+#define CONV_BK 16   // K-chunk: every segment is padded to a multiple of 16 channels in the packed weights
+struct ConvSrc {
+    const float* p;
+    long sn;
+    int ld;
+    int C;      // logical channels
+    int Cpad;   // round_up(C, CONV_BK)
+    int bcast;
+};
+
+struct ConvArgs {
+    ConvSrc src[CONV_MAX_SRC];
+    int nsrc;
+    int N, H, W;        // output spatial size == (virtual) input spatial size (stride 1, pad KS/2)
+    int KS;             // 1, 3 or 7
+    const float* wp;    // packed weights [KS*KS][Cout_pad][Ktot]  (k contiguous)
+    int Ktot;           // sum of Cpad
+    int Cout, Cout_pad; // Cout_pad multiple of the N tile
+    const float* bias;  // nullable, [Cout]
+    int act;            // 0 none, 1 tanh
+    float* out;
+    long out_sn;
+    int out_ld;
+    int accumulate;     // out += result
+};
+
+// wgrad: dwp[tap][o][k] += sum_p dY[p][o] * A[p+tap][k]   (A = concatenation of the forward sources)
+struct WgradArgs {
+    ConvSrc src[CONV_MAX_SRC];
+    int nsrc;
+    int N, H, W;
+    int KS;
+    const float* dy;    // (N,H,W,Cout) view
+    long dy_sn;
+    int dy_ld;
+    int Cout, Cout_pad;
+    int Ktot;
+    float* dwp;         // packed gradient, same layout as wp
+    int slabs;          // split of the pixel reduction across blocks (atomicAdd when > 1)
+};
+
+int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
+int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
+int conv_pick_bn(int cout);   // N-tile (32/64/128) the launcher will use for this Cout

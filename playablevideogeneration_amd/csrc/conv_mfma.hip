@@ -1,0 +1,351 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every nn.Conv2d on the CADDY hot path: 3x3 / 1x1 / 7x7, stride 1,
+// "same" zero padding, NHWC activations, the input being the channel-concatenation of up to three segments
+// (ConvLSTM: [x, (a|v) broadcast, h_prev] -- convolutional_lstm_cell.py:88-95 -- without materialising the cat).
+//   forward / dgrad :  out[p,o]  = sum_{tap,k} A[p+tap,k] * Wp[tap][o][k]          (k_conv_fwd; dgrad = same kernel on
+//                                                                                    flipped/transposed packed weights)
+//   wgrad           :  dWp[tap][o][k] += sum_p dY[p,o] * A[p+tap,k]                 (k_conv_wgrad)
+//
+// Tiling (wave64, 4 waves / workgroup): GEMM-M = output pixels, GEMM-N = output channels, GEMM-K = taps x channels in
+// chunks of 16.  A (pixels x 16ch) and B (couts x 16ch) tiles are staged through LDS with a 20-float row pitch, which
+// makes the ds_read_b128 fragment reads conflict-free (16 rows x 4 banks cover all 64 banks exactly once).
+// Next tile's global loads are issued into registers before the MFMA block of the current tile (register double buffer).
+// fp32 MFMA keeps the result bitwise a k-ordered fmaf chain, which is what holds the 1e-5 frame-MSE parity bound over
+// 15 recurrent steps (hard part 1); roofline for this kernel = 157.3 TFLOP/s fp32 matrix peak.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = CONV_BK;
+constexpr int LDSK = BK + 4;
+
+struct SegRef { const float* p; long sn; int ld; int C; int bcast; int c0; };
+
+// locate channel `k` (index into the padded concatenation) -> segment + channel inside it
+__device__ __forceinline__ SegRef find_seg(const ConvSrc* src, int nsrc, int k) {
+    int s = 0;
+    while (s + 1 < nsrc && k >= src[s].Cpad) { k -= src[s].Cpad; s++; }
+    SegRef r; r.p = src[s].p; r.sn = src[s].sn; r.ld = src[s].ld; r.C = src[s].C; r.bcast = src[s].bcast; r.c0 = k;
+    return r;
+}
+
+__device__ __forceinline__ float4 load4_masked(const float* q, int c, int C) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 4 <= C) v = *reinterpret_cast<const float4*>(q);
+    else {
+        if (c < C) v.x = q[0];
+        if (c + 1 < C) v.y = q[1];
+        if (c + 2 < C) v.z = q[2];
+    }
+    return v;
+}
+
+// value of the (virtual, zero-padded) concatenated input at pixel (n,yy,xx), channels seg.c0+kq*4 .. +3
+__device__ __forceinline__ float4 load_src4(const SegRef& sg, int kq, bool valid, int n, int yy, int xx, int W) {
+    int c = sg.c0 + kq * 4;
+    if (!valid || c >= sg.C) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* q = sg.p + (long)n * sg.sn + (sg.bcast ? 0L : (long)(yy * W + xx) * sg.ld) + c;
+    return load4_masked(q, c, sg.C);
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A_PER = BM * 4 / 256;
+    constexpr int B_PER = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ float As[BM * LDSK];
+    __shared__ float Bs[BN * LDSK];
+    __shared__ long rowoff[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int HW = a.H * a.W;
+    const long P = (long)a.N * HW;
+    const long p0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int R = a.KS >> 1;
+    const int kq = tid & 3;
+
+    int pn[A_PER], py[A_PER], px[A_PER];
+    bool pv[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; i++) {
+        long p = p0 + (tid >> 2) + 64 * i;
+        pv[i] = p < P;
+        long pp = pv[i] ? p : 0;
+        pn[i] = (int)(pp / HW);
+        int rem = (int)(pp - (long)pn[i] * HW);
+        py[i] = rem / a.W;
+        px[i] = rem - py[i] * a.W;
+    }
+    if (tid < BM) {
+        long p = p0 + tid;
+        long off = -1;
+        if (p < P) { long n = p / HW; off = n * a.out_sn + (p - n * HW) * a.out_ld; }
+        rowoff[tid] = off;
+    }
+
+    const int nchunks = a.Ktot / BK;
+    const int niter = a.KS * a.KS * nchunks;
+    float4 ra[A_PER], rb[B_PER];
+
+    auto gload = [&](int it) {
+        int tap = it / nchunks, ch = it - tap * nchunks;
+        int dy = tap / a.KS - R, dx = tap % a.KS - R;
+        SegRef sg = find_seg(a.src, a.nsrc, ch * BK);
+#pragma unroll
+        for (int i = 0; i < A_PER; i++) {
+            int yy = py[i] + dy, xx = px[i] + dx;
+            bool ok = pv[i] && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            ra[i] = load_src4(sg, kq, ok, pn[i], yy, xx, a.W);
+        }
+        const float* wt = a.wp + ((long)tap * a.Cout_pad + n0) * a.Ktot + ch * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < B_PER; i++) {
+            int r = (tid >> 2) + 64 * i;
+            if (r < BN) rb[i] = *reinterpret_cast<const float4*>(wt + (long)r * a.Ktot);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    gload(0);
+    for (int it = 0; it < niter; it++) {
+#pragma unroll
+        for (int i = 0; i < A_PER; i++) *reinterpret_cast<float4*>(&As[((tid >> 2) + 64 * i) * LDSK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; i++) {
+            int r = (tid >> 2) + 64 * i;
+            if (r < BN) *reinterpret_cast<float4*>(&Bs[r * LDSK + kq * 4]) = rb[i];
+        }
+        __syncthreads();
+        if (it + 1 < niter) gload(it + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+                fa[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D fragment map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+        if (col >= a.Cout) continue;
+        float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                long off = rowoff[row];
+                if (off < 0) continue;
+                float v = acc[i][j][r] + bv;
+                if (a.act == 1) v = tanhf(v);
+                float* o = a.out + off + col;
+                if (a.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad.  GEMM-M = output channels o, GEMM-N = concatenated input channels k (one tap per workgroup), reduction over
+// pixels in steps of 16; LDS tiles are [pixel][channel] so global->LDS is a straight float4 copy and the MFMA operand
+// reads are stride-1 ds_read_b32 (conflict-free).  grid.z = taps x slabs (split of the pixel reduction).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BP = 16;
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
+    constexpr int BMo = 32 * TM * WM, BNk = 32 * TN * WN;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BNk == 128, "loader assumes a 128-wide k tile");
+    constexpr int Y_PER = (BP * BMo / 4 + 255) / 256;
+    __shared__ float Ys[BP * BMo];
+    __shared__ float Xs[BP * BNk];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int HW = a.H * a.W;
+    const long P = (long)a.N * HW;
+    const int k0 = blockIdx.x * BNk, o0 = blockIdx.y * BMo;
+    const int tap = blockIdx.z / a.slabs, slab = blockIdx.z - tap * a.slabs;
+    const int R = a.KS >> 1;
+    const int dy = tap / a.KS - R, dx = tap % a.KS - R;
+    const long per = ((P + a.slabs - 1) / a.slabs + BP - 1) / BP * BP;
+    const long ps = per * slab, pe = (ps + per < P) ? ps + per : P;
+
+    // X loader: chunk (16 channels) is wave-uniform: chunks {wave, wave+4}; within: pixel = (lane>>2), q = lane&3
+    SegRef sg[2];
+    bool sgok[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int k = k0 + (wave + 4 * i) * BK;
+        sgok[i] = k < a.Ktot;
+        sg[i] = find_seg(a.src, a.nsrc, sgok[i] ? k : 0);
+    }
+    const int xp = lane >> 2, xq = lane & 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    float4 rx[2], ry[Y_PER];
+    auto gload = [&](long pbase) {
+        // X tile
+        long p = pbase + xp;
+        bool pvld = p < pe;
+        long pp = pvld ? p : 0;
+        int n = (int)(pp / HW);
+        int rem = (int)(pp - (long)n * HW);
+        int y = rem / a.W, x = rem - y * a.W;
+        int yy = y + dy, xx = x + dx;
+        bool ok = pvld && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+#pragma unroll
+        for (int i = 0; i < 2; i++) rx[i] = load_src4(sg[i], xq, ok && sgok[i], n, yy, xx, a.W);
+        // dY tile: BP pixels x BMo channels
+#pragma unroll
+        for (int i = 0; i < Y_PER; i++) {
+            int idx = tid + 256 * i;
+            int pr = idx / (BMo / 4), q = idx - pr * (BMo / 4);
+            ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < BP) {
+                long p2 = pbase + pr;
+                int c = o0 + q * 4;
+                if (p2 < pe && c < a.Cout) {
+                    long n2 = p2 / HW;
+                    const float* qy = a.dy + n2 * a.dy_sn + (p2 - n2 * HW) * a.dy_ld + c;
+                    ry[i] = load4_masked(qy, c, a.Cout);
+                }
+            }
+        }
+    };
+
+    if (ps < pe) gload(ps);
+    for (long pb = ps; pb < pe; pb += BP) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) *reinterpret_cast<float4*>(&Xs[xp * BNk + (wave + 4 * i) * BK + xq * 4]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < Y_PER; i++) {
+            int idx = tid + 256 * i;
+            int pr = idx / (BMo / 4), q = idx - pr * (BMo / 4);
+            if (pr < BP) *reinterpret_cast<float4*>(&Ys[pr * BMo + q * 4]) = ry[i];
+        }
+        __syncthreads();
+        if (pb + BP < pe) gload(pb + BP);
+#pragma unroll
+        for (int s = 0; s < BP / 2; s++) {
+            float fa[TM], fb[TN];
+            int prow = 2 * s + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = Ys[prow * BMo + wm * 32 * TM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = Xs[prow * BNk + wn * 32 * TN + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        int k = k0 + wn * 32 * TN + j * 32 + (lane & 31);
+        if (k >= a.Ktot) continue;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int o = o0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (o >= a.Cout) continue;
+                float* d = a.dwp + ((long)tap * a.Cout_pad + o) * a.Ktot + k;
+                if (a.slabs > 1) atomicAdd(d, acc[i][j][r]);
+                else *d += acc[i][j][r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int conv_pick_bn(int cout) {
+    int best = 128, bestpad = round_up(cout, 128);
+    for (int bn : {64, 32}) {
+        int pad = round_up(cout, bn);
+        if (pad < bestpad) { best = bn; bestpad = pad; }
+    }
+    return best;
+}
+
+int conv_fwd_launch(const ConvArgs& a, hipStream_t st) {
+    if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC || (a.KS != 1 && a.KS != 3 && a.KS != 7)) return -1;
+    int kt = 0;
+    for (int s = 0; s < a.nsrc; s++) {
+        if (a.src[s].Cpad != round_up(a.src[s].C, BK) || (a.src[s].ld & 3) || (a.src[s].sn & 3)) return -1;
+        kt += a.src[s].Cpad;
+    }
+    if (kt != a.Ktot || (a.out_ld < a.Cout)) return -1;
+    int bn = conv_pick_bn(a.Cout);
+    if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
+    long P = (long)a.N * a.H * a.W;
+    dim3 grid(cdiv(P, 128), a.Cout_pad / bn);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_fwd<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_fwd<2, 1, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1>), grid, dim3(256), 0, st, a);
+    return 0;
+}
+
+int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
+    WgradArgs a = a0;
+    if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC) return -1;
+    int bn = conv_pick_bn(a.Cout);
+    if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
+    long P = (long)a.N * a.H * a.W;
+    int taps = a.KS * a.KS;
+    int ktiles = cdiv(a.Ktot, 128);
+    int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
+    if (a.Cout_pad % bmo) bmo = 32;
+    int otiles = a.Cout_pad / bmo;
+    long blocks = (long)ktiles * otiles * taps;
+    if (a.slabs <= 0) {
+        long want = (1024 + blocks - 1) / blocks;
+        long maxs = P / 512 > 0 ? P / 512 : 1;
+        a.slabs = (int)(want < maxs ? want : maxs);
+        if (a.slabs < 1) a.slabs = 1;
+    }
+    dim3 grid(ktiles, otiles, taps * a.slabs);
+    if (bmo == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (bmo == 64) hipLaunchKernelGGL((k_conv_wgrad<1, 2, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_wgrad<1, 1, 1, 4>), grid, dim3(256), 0, st, a);
+    return 0;
+}

@@ -1,0 +1,75 @@
+// Weight re-layout between the boundary format (reference state_dict: OIHW fp32, training/trainer.py:100) and the
+// internal packed format of conv_mfma.hip ([tap][Cout_pad][Ktot], k contiguous, segments padded to 16 channels).
+// Runs once per optimiser step (weights change every step); ~2 x 39 MB of traffic for BAIR-main: HBM-bound, negligible.
+#include "common.h"
+#include "pack.h"
+
+namespace {
+__device__ __forceinline__ bool k_to_cin(const PackDesc& d, int k, int* cin) {
+    int base = 0;
+    for (int s = 0; s < d.nseg; s++) {
+        if (k < base + d.seg_Cpad[s]) { int c = k - base; if (c >= d.seg_C[s]) return false; *cin = d.seg_off[s] + c; return true; }
+        base += d.seg_Cpad[s];
+    }
+    return false;
+}
+__global__ void k_pack_fwd(PackDesc d, float* wp) {
+    long total = (long)d.KS * d.KS * d.Cout_pad * d.Ktot;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % d.Ktot); long r = i / d.Ktot; int o = (int)(r % d.Cout_pad); int tap = (int)(r / d.Cout_pad);
+        float v = 0.f; int cin;
+        if (o < d.Cout && k_to_cin(d, k, &cin)) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * d.KS * d.KS + tap];
+        wp[i] = v;
+    }
+}
+// dgrad weights of segment `seg`: wpd[tap'][c][o] = W[o][seg_off+c][KS*KS-1-tap']   (flip both spatial axes)
+__global__ void k_pack_dgrad(PackDesc d, int seg, float* wpd, int Cd_pad, int Kd) {
+    long total = (long)d.KS * d.KS * Cd_pad * Kd;
+    int taps = d.KS * d.KS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int o = (int)(i % Kd); long r = i / Kd; int c = (int)(r % Cd_pad); int tap = (int)(r / Cd_pad);
+        float v = 0.f;
+        if (o < d.Cout && c < d.seg_C[seg]) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + d.seg_off[seg] + c) * taps + (taps - 1 - tap)];
+        wpd[i] = v;
+    }
+}
+__global__ void k_unpack_wgrad(PackDesc d, const float* dwp) {
+    int taps = d.KS * d.KS;
+    long total = (long)taps * d.Cout_pad * d.Ktot;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % d.Ktot); long r = i / d.Ktot; int o = (int)(r % d.Cout_pad); int tap = (int)(r / d.Cout_pad);
+        int cin;
+        if (o < d.Cout && k_to_cin(d, k, &cin)) d.gw[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * taps + tap] = dwp[i];
+    }
+}
+// fused Adam (torch.optim.Adam semantics, L2 weight decay folded into the gradient; training/trainer.py:36,584-587)
+__global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale + wd * p[i];
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+}  // namespace
+
+static inline unsigned grid_for(long total) { long b = (total + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+int pack_fwd(const PackDesc& d, float* wp, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_fwd, dim3(grid_for((long)d.KS * d.KS * d.Cout_pad * d.Ktot)), dim3(256), 0, st, d, wp);
+    return 0;
+}
+int pack_dgrad(const PackDesc& d, int seg, float* wpd, int Cd_pad, int Kd, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_dgrad, dim3(grid_for((long)d.KS * d.KS * Cd_pad * Kd)), dim3(256), 0, st, d, seg, wpd, Cd_pad, Kd);
+    return 0;
+}
+int unpack_wgrad(const PackDesc& d, const float* dwp, hipStream_t st) {
+    hipLaunchKernelGGL(k_unpack_wgrad, dim3(grid_for((long)d.KS * d.KS * d.Cout_pad * d.Ktot)), dim3(256), 0, st, d, dwp);
+    return 0;
+}
+int adam_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale, hipStream_t st) {
+    float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+    return 0;
+}

@@ -1,0 +1,30 @@
+// Host launchers of the element-wise / reduction kernels (pointwise.hip) and of the packing / head kernels.
+#pragma once
+#include "common.h"
+
+int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st);
+int pw_fill(const TV& d, float v, hipStream_t st);
+int pw_pool2(const TV& in, const TV& out, hipStream_t st);
+int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st);
+int pw_up2(const TV& in, const TV& out, hipStream_t st);
+int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st);
+int pw_stats(const TV& x, double* sums, hipStream_t st);
+int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
+                   float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st);
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, hipStream_t st);
+int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                    const TV& dx, float* dgamma, float* dbeta, hipStream_t st);
+int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st);
+int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st);
+int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st);
+int pw_tanh_bwd(const TV& dy, const TV& y, const TV& dz, hipStream_t st);
+int pw_attn_mul(const TV& x, const TV& out, const TV& att, hipStream_t st);
+int pw_attn_mul_bwd(const TV& x, const TV& dout, const TV& datt, const TV& dx, hipStream_t st);
+int pw_gap(const TV& x, float* out, hipStream_t st);
+int pw_gap_bwd(const float* dout, const TV& dx, hipStream_t st);
+int pw_colsum(const TV& x, float* out, hipStream_t st);
+int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st);
+int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st);
+int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st);
+int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st);

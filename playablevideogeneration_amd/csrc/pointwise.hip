@@ -1,0 +1,419 @@
+// HBM-bound element-wise / reduction kernels of the CADDY hot path, NHWC fp32 views.
+// One work item = (pixel, group of 4 channels): float4 accesses, lanes run along the channel axis first so that a
+// wave touches contiguous memory.  Per-channel reductions (BatchNorm statistics and their backward sums) are done in
+// fp64 per thread -> LDS -> one fp64 atomicAdd per (block, channel), which keeps E[x^2]-E[x]^2 free of cancellation.
+// Roofline for everything in this file: HBM (8 TB/s).
+#include "common.h"
+#include "pointwise.h"
+
+namespace {
+
+__device__ __forceinline__ long tv_off(const TV& t, int HW, long q) {
+    long n = q / HW;
+    return n * t.sn + (q - n * HW) * (long)t.ld;
+}
+__device__ __forceinline__ float4 ld4(const float* p, int c, int C) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 4 <= C) v = *reinterpret_cast<const float4*>(p);
+    else { if (c < C) v.x = p[0]; if (c + 1 < C) v.y = p[1]; if (c + 2 < C) v.z = p[2]; }
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, int c, int C, float4 v) {
+    if (c + 4 <= C) *reinterpret_cast<float4*>(p) = v;
+    else { if (c < C) p[0] = v.x; if (c + 1 < C) p[1] = v.y; if (c + 2 < C) p[2] = v.z; }
+}
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float lrelu1(float v) { return v > 0.f ? v : 0.2f * v; }
+__device__ __forceinline__ float4 lrelu4(float4 v) { return make_float4(lrelu1(v.x), lrelu1(v.y), lrelu1(v.z), lrelu1(v.w)); }
+__device__ __forceinline__ float4 lmask4(float4 o) { return make_float4(o.x > 0.f ? 1.f : 0.2f, o.y > 0.f ? 1.f : 0.2f, o.z > 0.f ? 1.f : 0.2f, o.w > 0.f ? 1.f : 0.2f); }
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <class F>
+__global__ __launch_bounds__(256) void k_map(long npix, int C4, F f) {
+    long items = npix * C4;
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        long q = it / C4;
+        int c = (int)(it - q * C4) * 4;
+        f(q, c);
+    }
+}
+template <class F>
+int run_map(long npix, int C, F f, hipStream_t st) {
+    int C4 = (C + 3) / 4;
+    long items = npix * C4;
+    if (items <= 0) return 0;
+    long blocks = (items + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((k_map<F>), dim3((unsigned)blocks), dim3(256), 0, st, npix, C4, f);
+    return 0;
+}
+
+// ---- functors -------------------------------------------------------------------------------------------------
+struct FCopy {
+    TV s, d; int HW; int acc;
+    __device__ void operator()(long q, int c) const {
+        float4 v = ld4(s.p + tv_off(s, HW, q) + c, c, s.C);
+        float* o = d.p + tv_off(d, HW, q) + c;
+        if (acc) v = v + ld4(o, c, d.C);
+        st4(o, c, d.C, v);
+    }
+};
+struct FFill {
+    TV d; int HW; float val;
+    __device__ void operator()(long q, int c) const { st4(d.p + tv_off(d, HW, q) + c, c, d.C, make_float4(val, val, val, val)); }
+};
+struct FPool2 {  // q indexes OUTPUT pixels (F.avg_pool2d(x, 2): residual_block.py:56, same_block.py:40, representation_network.py:41)
+    TV in, out;
+    __device__ void operator()(long q, int c) const {
+        int HWo = out.H * out.W;
+        long n = q / HWo; int rem = (int)(q - n * HWo); int y = rem / out.W, x = rem - y * out.W;
+        const float* b = in.p + n * in.sn + ((long)(2 * y) * in.W + 2 * x) * in.ld + c;
+        float4 v = ld4(b, c, in.C) + ld4(b + in.ld, c, in.C) + ld4(b + (long)in.W * in.ld, c, in.C) + ld4(b + (long)(in.W + 1) * in.ld, c, in.C);
+        st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, 0.25f * v);
+    }
+};
+struct FPool2Bwd {  // q indexes INPUT pixels; din += dout/4
+    TV dout, din;
+    __device__ void operator()(long q, int c) const {
+        int HWi = din.H * din.W;
+        long n = q / HWi; int rem = (int)(q - n * HWi); int y = rem / din.W, x = rem - y * din.W;
+        float4 g = ld4(dout.p + n * dout.sn + ((long)(y >> 1) * dout.W + (x >> 1)) * dout.ld + c, c, dout.C);
+        float* o = din.p + n * din.sn + (long)rem * din.ld + c;
+        st4(o, c, din.C, ld4(o, c, din.C) + 0.25f * g);
+    }
+};
+struct FUp2 {  // bilinear x2, align_corners=False (up_block.py:35,43); q indexes OUTPUT pixels
+    TV in, out;
+    __device__ void operator()(long q, int c) const {
+        int HWo = out.H * out.W;
+        long n = q / HWo; int rem = (int)(q - n * HWo); int y = rem / out.W, x = rem - y * out.W;
+        int iy = y >> 1, ix = x >> 1;
+        int y0, y1, x0, x1; float wy1, wx1;
+        if (y & 1) { y0 = iy; y1 = iy + 1 < in.H ? iy + 1 : in.H - 1; wy1 = 0.25f; } else { y0 = iy > 0 ? iy - 1 : 0; y1 = iy; wy1 = iy > 0 ? 0.75f : 0.f; }
+        if (x & 1) { x0 = ix; x1 = ix + 1 < in.W ? ix + 1 : in.W - 1; wx1 = 0.25f; } else { x0 = ix > 0 ? ix - 1 : 0; x1 = ix; wx1 = ix > 0 ? 0.75f : 0.f; }
+        float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        const float* b = in.p + n * in.sn + c;
+        float4 v00 = ld4(b + ((long)y0 * in.W + x0) * in.ld, c, in.C), v01 = ld4(b + ((long)y0 * in.W + x1) * in.ld, c, in.C);
+        float4 v10 = ld4(b + ((long)y1 * in.W + x0) * in.ld, c, in.C), v11 = ld4(b + ((long)y1 * in.W + x1) * in.ld, c, in.C);
+        float4 r = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+        st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, r);
+    }
+};
+struct FUp2Bwd {  // q indexes INPUT pixels: din += sum_{a,b} w_a w_b dout[clamp(2i-1+a), clamp(2j-1+b)], w = {.25,.75,.75,.25}
+    TV dout, din;
+    __device__ void operator()(long q, int c) const {
+        int HWi = din.H * din.W;
+        long n = q / HWi; int rem = (int)(q - n * HWi); int i = rem / din.W, j = rem - i * din.W;
+        const float w[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* b = dout.p + n * dout.sn + c;
+        for (int a = 0; a < 4; a++) {
+            int r = 2 * i - 1 + a; r = r < 0 ? 0 : (r >= dout.H ? dout.H - 1 : r);
+            for (int e = 0; e < 4; e++) {
+                int s = 2 * j - 1 + e; s = s < 0 ? 0 : (s >= dout.W ? dout.W - 1 : s);
+                acc = acc + (w[a] * w[e]) * ld4(b + ((long)r * dout.W + s) * dout.ld, c, dout.C);
+            }
+        }
+        float* o = din.p + n * din.sn + (long)rem * din.ld + c;
+        st4(o, c, din.C, ld4(o, c, din.C) + acc);
+    }
+};
+struct FBnApply {  // out = act(x*scale+shift + second), second = x2*scale2+shift2 | x2 | 0   (residual_block.py:57-68)
+    TV x, x2, out; const float *scale, *shift, *scale2, *shift2; int HW; int has2; int act;
+    __device__ void operator()(long q, int c) const {
+        float4 v = ld4(x.p + tv_off(x, HW, q) + c, c, x.C) * ld4(scale + c, c, x.C) + ld4(shift + c, c, x.C);
+        if (has2) {
+            float4 r = ld4(x2.p + tv_off(x2, HW, q) + c, c, x2.C);
+            if (scale2) r = r * ld4(scale2 + c, c, x.C) + ld4(shift2 + c, c, x.C);
+            v = v + r;
+        }
+        if (act) v = lrelu4(v);
+        st4(out.p + tv_off(out, HW, q) + c, c, out.C, v);
+    }
+};
+struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*lrelu'(out)
+    TV dout, outm, x, dx; const float *mean, *invstd, *gamma; const double* sums; int HW; int act; float invM;
+    __device__ void operator()(long q, int c) const {
+        float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C);
+        if (act) dz = dz * lmask4(ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
+        float4 xv = ld4(x.p + tv_off(x, HW, q) + c, c, x.C);
+        float4 mu = ld4(mean + c, c, x.C), is = ld4(invstd + c, c, x.C), ga = ld4(gamma + c, c, x.C);
+        float s1[4], s2[4];
+        for (int e = 0; e < 4; e++) { bool ok = c + e < x.C; s1[e] = ok ? (float)(sums[2 * (c + e)] * invM) : 0.f; s2[e] = ok ? (float)(sums[2 * (c + e) + 1] * invM) : 0.f; }
+        float4 xh = (xv - mu) * is;
+        float4 g = ga * is * (dz - make_float4(s1[0], s1[1], s1[2], s1[3]) - xh * make_float4(s2[0], s2[1], s2[2], s2[3]));
+        float* o = dx.p + tv_off(dx, HW, q) + c;
+        st4(o, c, dx.C, ld4(o, c, dx.C) + g);
+    }
+};
+struct FActBwdAdd {  // dres += dout * lrelu'(out)
+    TV dout, outm, dres; int HW;
+    __device__ void operator()(long q, int c) const {
+        float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C) * lmask4(ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
+        float* o = dres.p + tv_off(dres, HW, q) + c;
+        st4(o, c, dres.C, ld4(o, c, dres.C) + dz);
+    }
+};
+struct FLstmFwd {  // gates (pre-activation, channel order [i|f|o|g] x C) -> post-activation in place; c' = f*c + i*g; h' = o*tanh(c')
+    TV gates, cprev, h, cn; int HW;   // convolutional_lstm_cell.py:92-101
+    __device__ void operator()(long q, int c) const {
+        int C = h.C;
+        float* gp = gates.p + tv_off(gates, HW, q) + c;
+        float4 gi = ld4(gp, c, C), gf = ld4(gp + C, c, C), go = ld4(gp + 2 * C, c, C), gg = ld4(gp + 3 * C, c, C);
+        float4 cp = ld4(cprev.p + tv_off(cprev, HW, q) + c, c, C);
+        float4 i4 = make_float4(sigm(gi.x), sigm(gi.y), sigm(gi.z), sigm(gi.w));
+        float4 f4 = make_float4(sigm(gf.x), sigm(gf.y), sigm(gf.z), sigm(gf.w));
+        float4 o4 = make_float4(sigm(go.x), sigm(go.y), sigm(go.z), sigm(go.w));
+        float4 g4 = make_float4(tanhf(gg.x), tanhf(gg.y), tanhf(gg.z), tanhf(gg.w));
+        float4 cc = f4 * cp + i4 * g4;
+        float4 hh = o4 * make_float4(tanhf(cc.x), tanhf(cc.y), tanhf(cc.z), tanhf(cc.w));
+        st4(gp, c, C, i4); st4(gp + C, c, C, f4); st4(gp + 2 * C, c, C, o4); st4(gp + 3 * C, c, C, g4);
+        st4(cn.p + tv_off(cn, HW, q) + c, c, C, cc);
+        st4(h.p + tv_off(h, HW, q) + c, c, C, hh);
+    }
+};
+struct FLstmBwd {
+    TV gates, cprev, cn, dh, dc, dgates, dcprev; int HW;
+    __device__ void operator()(long q, int c) const {
+        int C = dh.C;
+        const float* gp = gates.p + tv_off(gates, HW, q) + c;
+        float4 i4 = ld4(gp, c, C), f4 = ld4(gp + C, c, C), o4 = ld4(gp + 2 * C, c, C), g4 = ld4(gp + 3 * C, c, C);
+        float4 cp = ld4(cprev.p + tv_off(cprev, HW, q) + c, c, C), cc = ld4(cn.p + tv_off(cn, HW, q) + c, c, C);
+        float4 gh = ld4(dh.p + tv_off(dh, HW, q) + c, c, C), gc = ld4(dc.p + tv_off(dc, HW, q) + c, c, C);
+        float4 tc = make_float4(tanhf(cc.x), tanhf(cc.y), tanhf(cc.z), tanhf(cc.w));
+        float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 d_o = gh * tc;
+        float4 dcc = gc + gh * o4 * (one - tc * tc);
+        float4 d_i = dcc * g4, d_f = dcc * cp, d_g = dcc * i4;
+        float* dg = dgates.p + tv_off(dgates, HW, q) + c;
+        st4(dg, c, C, d_i * i4 * (one - i4));
+        st4(dg + C, c, C, d_f * f4 * (one - f4));
+        st4(dg + 2 * C, c, C, d_o * o4 * (one - o4));
+        st4(dg + 3 * C, c, C, d_g * (one - g4 * g4));
+        float* dp = dcprev.p + tv_off(dcprev, HW, q) + c;
+        st4(dp, c, C, ld4(dp, c, C) + dcc * f4);
+    }
+};
+struct FTanhBwd {
+    TV dy, y, dz; int HW;
+    __device__ void operator()(long q, int c) const {
+        float4 yv = ld4(y.p + tv_off(y, HW, q) + c, c, y.C);
+        float4 g = ld4(dy.p + tv_off(dy, HW, q) + c, c, dy.C) * (make_float4(1.f, 1.f, 1.f, 1.f) - yv * yv);
+        st4(dz.p + tv_off(dz, HW, q) + c, c, dz.C, g);
+    }
+};
+struct FAttnMul {  // attentive = state * sigmoid(x[..., C-1])  (representation_network.py:47-57, action_network.py:78)
+    TV x, out, att; int HW;
+    __device__ void operator()(long q, int c) const {
+        const float* xp = x.p + tv_off(x, HW, q);
+        float a = sigm(xp[x.C - 1]);
+        st4(out.p + tv_off(out, HW, q) + c, c, out.C, a * ld4(xp + c, c, out.C));
+        if (c == 0 && att.p) att.p[tv_off(att, HW, q)] = a;
+    }
+};
+struct FAttnMulBwd {  // per pixel (C4 == 1)
+    TV x, dout, datt, dx; int HW;
+    __device__ void operator()(long q, int) const {
+        const float* xp = x.p + tv_off(x, HW, q);
+        const float* gp = dout.p + tv_off(dout, HW, q);
+        float* dp = dx.p + tv_off(dx, HW, q);
+        int Cs = x.C - 1;
+        float a = sigm(xp[Cs]);
+        float dot = 0.f;
+        for (int c = 0; c < Cs; c++) { float g = gp[c]; dot += g * xp[c]; dp[c] += g * a; }
+        if (datt.p) dot += datt.p[tv_off(datt, HW, q)];
+        dp[Cs] += dot * a * (1.f - a);
+    }
+};
+struct FGapBwd {
+    TV dx; const float* dout; int HW; float inv;
+    __device__ void operator()(long q, int c) const {
+        long n = q / HW;
+        float* o = dx.p + tv_off(dx, HW, q) + c;
+        st4(o, c, dx.C, ld4(o, c, dx.C) + inv * ld4(dout + n * dx.C + c, c, dx.C));
+    }
+};
+struct FNchwToNhwc {  // per pixel; pad channels [C, ld) are zero-filled
+    const float* src; long src_sn; TV d; int HW;
+    __device__ void operator()(long q, int) const {
+        long n = q / HW; long pix = q - n * HW;
+        float* o = d.p + n * d.sn + pix * d.ld;
+        for (int c = 0; c < d.C; c++) o[c] = src[n * src_sn + (long)c * HW + pix];
+        for (int c = d.C; c < d.ld && c < ((d.C + 3) & ~3); c++) o[c] = 0.f;
+    }
+};
+struct FNhwcToNchw {
+    TV s; float* dst; long dst_sn; int HW; int acc;
+    __device__ void operator()(long q, int) const {
+        long n = q / HW; long pix = q - n * HW;
+        const float* i = s.p + n * s.sn + pix * s.ld;
+        for (int c = 0; c < s.C; c++) { float* o = dst + n * dst_sn + (long)c * HW + pix; *o = acc ? *o + i[c] : i[c]; }
+    }
+};
+
+// ---- per-channel reductions -------------------------------------------------------------------------------------
+// MODE 0: sums[c][0..1] += (sum x, sum x^2)                         (BatchNorm batch statistics)
+// MODE 1: sums[c][0..1] += (sum dz, sum dz*xhat), dz = dout*mask     (BatchNorm backward)
+// MODE 2: outf[(n*out_sn) + c] += scale * sum x                      (per-sample spatial sum: GAP, broadcast-input grads)
+// MODE 3: outf[c] += sum x                                           (bias gradient)
+struct RedArgs {
+    TV x, dout, outm; const float *mean, *invstd; double* sums; float* outf; long out_sn; float scale; int act; int pix_per_block;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
+    __shared__ double sh[256 * 8];
+    const int C = a.x.C, C4 = (C + 3) / 4;
+    const int C4b = C4 < 256 ? C4 : 256;
+    const int PT = 256 / C4b;
+    const int tid = threadIdx.x, pt = tid / C4b, j = tid - pt * C4b;
+    const int HW = a.x.H * a.x.W;
+    // MODE 2 reduces within one sample: blockIdx.y = sample
+    long qbeg, qend;
+    if (MODE == 2) { qbeg = (long)blockIdx.y * HW + (long)blockIdx.x * a.pix_per_block; long e = qbeg + a.pix_per_block; long lim = (long)(blockIdx.y + 1) * HW; qend = e < lim ? e : lim; }
+    else { long P = (long)a.x.N * HW; qbeg = (long)blockIdx.x * a.pix_per_block; long e = qbeg + a.pix_per_block; qend = e < P ? e : P; }
+    double s[8];
+    for (int e = 0; e < 8; e++) s[e] = 0.0;
+    if (pt < PT) {
+        for (int jj = j; jj < C4; jj += C4b) {   // C4 <= 256 in practice -> single trip
+            int c = jj * 4;
+            for (long q = qbeg + pt; q < qend; q += PT) {
+                float4 xv = ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C);
+                if (MODE == 0) {
+                    s[0] += xv.x; s[1] += xv.y; s[2] += xv.z; s[3] += xv.w;
+                    s[4] += (double)xv.x * xv.x; s[5] += (double)xv.y * xv.y; s[6] += (double)xv.z * xv.z; s[7] += (double)xv.w * xv.w;
+                } else if (MODE == 1) {
+                    float4 dz = ld4(a.dout.p + tv_off(a.dout, HW, q) + c, c, C);
+                    if (a.act) dz = dz * lmask4(ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
+                    float4 xh = (xv - ld4(a.mean + c, c, C)) * ld4(a.invstd + c, c, C);
+                    s[0] += dz.x; s[1] += dz.y; s[2] += dz.z; s[3] += dz.w;
+                    s[4] += (double)dz.x * xh.x; s[5] += (double)dz.y * xh.y; s[6] += (double)dz.z * xh.z; s[7] += (double)dz.w * xh.w;
+                } else {
+                    s[0] += xv.x; s[1] += xv.y; s[2] += xv.z; s[3] += xv.w;
+                }
+            }
+        }
+    }
+    for (int e = 0; e < 8; e++) sh[tid * 8 + e] = s[e];
+    __syncthreads();
+    if (pt == 0 && j < C4) {
+        for (int p = 1; p < PT; p++)
+            for (int e = 0; e < 8; e++) s[e] += sh[(p * C4b + j) * 8 + e];
+        int c = j * 4;
+        for (int e = 0; e < 4; e++) {
+            if (c + e >= C) break;
+            if (MODE <= 1) { atomicAdd(&a.sums[2 * (c + e)], s[e]); atomicAdd(&a.sums[2 * (c + e) + 1], s[4 + e]); }
+            else if (MODE == 2) atomicAdd(&a.outf[(long)blockIdx.y * a.out_sn + c + e], (float)(s[e] * a.scale));
+            else atomicAdd(&a.outf[c + e], (float)s[e]);
+        }
+    }
+}
+
+template <int MODE>
+int run_reduce(RedArgs a, hipStream_t st) {
+    int HW = a.x.H * a.x.W;
+    long P = (long)a.x.N * HW;
+    if ((a.x.C + 3) / 4 > 256) return -1;
+    if (MODE == 2) {
+        int ppb = HW > 4096 ? 4096 : HW;
+        a.pix_per_block = ppb;
+        hipLaunchKernelGGL((k_reduce<MODE>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
+    } else {
+        long ppb = (P + 1023) / 1024;
+        if (ppb < 64) ppb = 64;
+        a.pix_per_block = (int)ppb;
+        hipLaunchKernelGGL((k_reduce<MODE>), dim3(cdiv(P, ppb)), dim3(256), 0, st, a);
+    }
+    return 0;
+}
+
+// BN statistics -> (mean, invstd, scale, shift) + running-stat update (nn.BatchNorm2d train / eval semantics)
+__global__ void k_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
+                              int training, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m, is;
+    if (training) {
+        double mu = sums[2 * c] / count;
+        double var = sums[2 * c + 1] / count - mu * mu;
+        if (var < 0) var = 0;
+        m = (float)mu;
+        is = (float)(1.0 / sqrt(var + (double)eps));
+        double unb = count > 1 ? var * count / (count - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    } else {
+        m = rmean[c];
+        is = 1.f / sqrtf(rvar[c] + eps);
+    }
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = m; invstd[c] = is; scale[c] = g * is; shift[c] = b - m * g * is;
+}
+__global__ void k_bn_param_grad(const double* sums, int C, float* dgamma, float* dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += (float)sums[2 * c];
+    dgamma[c] += (float)sums[2 * c + 1];
+}
+__global__ void k_batch_sum(const float* src, long sn, long n_el, int N, float* dst) {  // dst[i] += sum_n src[n*sn+i]
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    float s = 0.f;
+    for (int n = 0; n < N; n++) s += src[n * sn + i];
+    dst[i] += s;
+}
+
+}  // namespace
+
+int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FCopy{s, d, d.H * d.W, acc}, st); }
+int pw_fill(const TV& d, float v, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FFill{d, d.H * d.W, v}, st); }
+int pw_pool2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out}, st); }
+int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din}, st); }
+int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
+int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
+int pw_stats(const TV& x, double* sums, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; return run_reduce<0>(a, st); }
+int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
+                   float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, (double)count, gamma, beta, rmean, rvar, C, training, 0.1f, 1e-5f, mean, invstd, scale, shift);
+    return 0;
+}
+int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st) {
+    FBnApply f{x, x2 ? *x2 : x, out, scale, shift, scale2, shift2, x.H * x.W, x2 ? 1 : 0, act};
+    return run_map((long)x.N * x.H * x.W, x.C, f, st);
+}
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, hipStream_t st) {
+    RedArgs a{}; a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
+    return run_reduce<1>(a, st);
+}
+int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                    const TV& dx, float* dgamma, float* dbeta, hipStream_t st) {
+    long M = (long)x.N * x.H * x.W;
+    FBnBwdApply f{dout, outm ? *outm : dout, x, dx, mean, invstd, gamma, sums, x.H * x.W, outm ? 1 : 0, (float)(1.0 / (double)M)};
+    run_map(M, x.C, f, st);
+    if (dgamma) hipLaunchKernelGGL(k_bn_param_grad, dim3(cdiv(x.C, 64)), dim3(64), 0, st, sums, x.C, dgamma, dbeta);
+    return 0;
+}
+int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st) { return run_map((long)dres.N * dres.H * dres.W, dres.C, FActBwdAdd{dout, outm, dres, dres.H * dres.W}, st); }
+int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st) { return run_map((long)h.N * h.H * h.W, h.C, FLstmFwd{gates, cprev, h, cn, h.H * h.W}, st); }
+int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st) {
+    return run_map((long)dh.N * dh.H * dh.W, dh.C, FLstmBwd{gates, cprev, cn, dh, dc, dgates, dcprev, dh.H * dh.W}, st);
+}
+int pw_tanh_bwd(const TV& dy, const TV& y, const TV& dz, hipStream_t st) { return run_map((long)y.N * y.H * y.W, y.C, FTanhBwd{dy, y, dz, y.H * y.W}, st); }
+int pw_attn_mul(const TV& x, const TV& out, const TV& att, hipStream_t st) { return run_map((long)x.N * x.H * x.W, out.C, FAttnMul{x, out, att, x.H * x.W}, st); }
+int pw_attn_mul_bwd(const TV& x, const TV& dout, const TV& datt, const TV& dx, hipStream_t st) { return run_map((long)x.N * x.H * x.W, 1, FAttnMulBwd{x, dout, datt, dx, x.H * x.W}, st); }
+int pw_gap(const TV& x, float* out, hipStream_t st) {
+    hipMemsetAsync(out, 0, sizeof(float) * (size_t)x.N * x.C, st);
+    RedArgs a{}; a.x = x; a.outf = out; a.out_sn = x.C; a.scale = 1.f / (float)(x.H * x.W);
+    return run_reduce<2>(a, st);
+}
+int pw_gap_bwd(const float* dout, const TV& dx, hipStream_t st) { return run_map((long)dx.N * dx.H * dx.W, dx.C, FGapBwd{dx, dout, dx.H * dx.W, 1.f / (float)(dx.H * dx.W)}, st); }
+int pw_colsum(const TV& x, float* out, hipStream_t st) { RedArgs a{}; a.x = x; a.outf = out; return run_reduce<3>(a, st); }
+int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st) { RedArgs a{}; a.x = x; a.outf = out; a.out_sn = out_sn; a.scale = 1.f; return run_reduce<2>(a, st); }
+int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st) { return run_map((long)d.N * d.H * d.W, 1, FNchwToNhwc{src, src_sn, d, d.H * d.W}, st); }
+int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st) { return run_map((long)s.N * s.H * s.W, 1, FNhwcToNchw{s, dst, dst_sn, s.H * s.W, acc}, st); }
+int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_batch_sum, dim3(cdiv(n_el, 256)), dim3(256), 0, st, src, sn, n_el, N, dst);
+    return 0;
+}

@@ -1,0 +1,13 @@
+"""TEST ONLY: build + load the host functional-simulator build of the kernel sources (libcaddy_emu.so)."""
+import ctypes as C
+
+from playablevideogeneration_amd.csrc import build as B
+
+_emu = None
+
+
+def load_emu():
+    global _emu
+    if _emu is None:
+        _emu = C.CDLL(B.build_emu())
+    return _emu

@@ -1,0 +1,365 @@
+"""Per-kernel parity cases shared by the simulator tests (CPU, `-m "not gpu"`) and the GPU tests (`-m gpu`).
+
+Every case takes (lib, dev): `lib` is a ctypes handle exposing the C-ABI kernel entry points, `dev` the torch device the
+buffers live on ("cpu" for the simulator, "cuda" on the MI355X).  References are plain torch fp32 ops on CPU.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from playablevideogeneration_amd._lib import TV, ConvArgs, ConvSrc, PackDesc, WgradArgs, round_up, CONV_BK
+
+
+def nhwc(x_nchw, ld=None, dev="cpu"):
+    """NCHW cpu tensor -> (buffer (N,H,W,ld) on dev, with channels [C,ld) poisoned by NaN-free garbage)."""
+    N, Cc, H, W = x_nchw.shape
+    ld = ld or round_up(Cc, 4)
+    buf = torch.full((N, H, W, ld), 7.5)
+    buf[..., :Cc] = x_nchw.permute(0, 2, 3, 1)
+    return buf.contiguous().to(dev)
+
+
+def tv(buf, Cc, n_stride=None, ptr_off=0):
+    N, H, W, ld = buf.shape
+    t = TV(buf.data_ptr() + 4 * ptr_off, N, H, W, Cc, n_stride if n_stride is not None else H * W * ld, ld)
+    t._keep = buf          # keep the storage alive for as long as the view object lives
+    return t
+
+
+def to_nchw(buf, Cc):
+    return buf[..., :Cc].permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def stream(dev):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream if dev != "cpu" else 0)
+
+
+def sync(dev):
+    if dev != "cpu":
+        torch.cuda.synchronize()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def make_pack(ws, segs, KS, lib):
+    """ws: list of OIHW cpu tensors (stacked along O); segs: list of (ref channel offset, C)."""
+    d = PackDesc()
+    d.nw, d.Co_each, d.Cin, d.KS = len(ws), ws[0].shape[0], ws[0].shape[1], KS
+    d.nseg = len(segs)
+    kt = 0
+    for i, (off, c) in enumerate(segs):
+        d.seg_off[i], d.seg_C[i], d.seg_Cpad[i] = off, c, round_up(c, CONV_BK)
+        kt += round_up(c, CONV_BK)
+    d.Cout = d.nw * d.Co_each
+    d.Cout_pad = round_up(d.Cout, lib.caddy_k_conv_pick_bn(d.Cout))
+    d.Ktot = kt
+    return d
+
+
+def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5):
+    """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd."""
+    g = torch.Generator().manual_seed(seed)
+    Cin = sum(c for c, _ in segs)
+    xs = []
+    for c, bc in segs:
+        xs.append(torch.randn(N, c, generator=g) if bc else torch.randn(N, c, H, W, generator=g))
+    ws = [(torch.randn(Cout // nw, Cin, KS, KS, generator=g) / (Cin * KS * KS) ** 0.5) for _ in range(nw)]
+    b = torch.randn(Cout, generator=g) if bias else None
+    # reference
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    ws_r = [w.clone().requires_grad_(True) for w in ws]
+    full = torch.cat([x[:, :, None, None].expand(-1, -1, H, W) if bc else x for x, (c, bc) in zip(xs_r, segs)], dim=1)
+    y_ref = F.conv2d(full, torch.cat(ws_r, 0), b, padding=KS // 2)
+    if act == 1:
+        y_ref = torch.tanh(y_ref)
+    dy = torch.randn(y_ref.shape, generator=g)
+    # device buffers
+    st = stream(dev)
+    ws_d = [w.contiguous().to(dev) for w in ws]
+    gws_d = [torch.zeros_like(w) for w in ws_d]
+    offs, o = [], 0
+    for c, _ in segs:
+        offs.append((o, c)); o += c
+    d = make_pack(ws, offs, KS, lib)
+    for i in range(nw):
+        d.w[i], d.gw[i] = ws_d[i].data_ptr(), gws_d[i].data_ptr()
+    taps = KS * KS
+    wp = torch.full((taps * d.Cout_pad * d.Ktot,), 3.0, device=dev)
+    assert lib.caddy_k_pack_fwd(C.byref(d), P(wp), st) == 0
+    a = ConvArgs()
+    bufs = []
+    for i, ((c, bc), x) in enumerate(zip(segs, xs)):
+        if bc:
+            bb = torch.full((N, 16), 7.5); bb[:, :c] = x; bb = bb.to(dev)
+            a.src[i] = ConvSrc(bb.data_ptr(), 16, 16, c, round_up(c, CONV_BK), 1)
+        else:
+            bb = nhwc(x, dev=dev)
+            a.src[i] = ConvSrc(bb.data_ptr(), H * W * bb.shape[3], bb.shape[3], c, round_up(c, CONV_BK), 0)
+        bufs.append(bb)
+    a.nsrc, a.N, a.H, a.W, a.KS = len(segs), N, H, W, KS
+    a.wp, a.Ktot, a.Cout, a.Cout_pad = wp.data_ptr(), d.Ktot, Cout, d.Cout_pad
+    b_d = b.to(dev) if bias else None
+    a.bias = b_d.data_ptr() if bias else None
+    a.act = act
+    out_ld = round_up(Cout, 4) + 4
+    out = torch.full((N, H, W, out_ld), 9.0, device=dev)
+    a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0
+    assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    sync(dev)
+    y = to_nchw(out, Cout)
+    err = (y - y_ref.detach()).abs().max().item()
+    assert err < tol, ("fwd", err)
+    assert torch.all(out[..., Cout:] == 9.0)            # pad channels untouched
+    if not check_bwd:
+        return
+    y_ref.backward(dy)
+    # the kernels receive the gradient w.r.t. the pre-activation (tanh' is a separate element-wise kernel)
+    dz = dy * (1 - y_ref.detach() ** 2) if act == 1 else dy
+    dz_d = nhwc(dz, dev=dev)
+    # wgrad
+    dwp = torch.zeros_like(wp)
+    wa = WgradArgs()
+    for i in range(len(segs)):
+        wa.src[i] = a.src[i]
+    wa.nsrc, wa.N, wa.H, wa.W, wa.KS = a.nsrc, N, H, W, KS
+    wa.dy, wa.dy_sn, wa.dy_ld = dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3]
+    wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs = Cout, d.Cout_pad, d.Ktot, dwp.data_ptr(), 0
+    assert lib.caddy_k_conv_wgrad(C.byref(wa), st) == 0
+    assert lib.caddy_k_unpack_wgrad(C.byref(d), P(dwp), st) == 0
+    sync(dev)
+    for i in range(nw):
+        e = (gws_d[i].cpu() - ws_r[i].grad).abs().max().item()
+        assert e < tol * max(1.0, ws_r[i].grad.abs().max().item()) * 4, ("wgrad", i, e)
+    # dgrad per segment = conv of dz with flipped/transposed weights
+    for si, ((c, bc), x_r) in enumerate(zip(segs, xs_r)):
+        bn = lib.caddy_k_conv_pick_bn(c)
+        cd_pad, kd = round_up(c, bn), round_up(Cout, CONV_BK)
+        wpd = torch.full((taps * cd_pad * kd,), 3.0, device=dev)
+        assert lib.caddy_k_pack_dgrad(C.byref(d), si, P(wpd), cd_pad, kd, st) == 0
+        da = ConvArgs()
+        da.src[0] = ConvSrc(dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3], Cout, kd, 0)
+        da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, KS
+        da.wp, da.Ktot, da.Cout, da.Cout_pad, da.bias, da.act = wpd.data_ptr(), kd, c, cd_pad, None, 0
+        gx = torch.ones((N, H, W, round_up(c, 4)), device=dev)      # accumulate on top of ones
+        da.out, da.out_sn, da.out_ld, da.accumulate = gx.data_ptr(), H * W * gx.shape[3], gx.shape[3], 1
+        assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0
+        sync(dev)
+        got = to_nchw(gx, c) - 1.0
+        if bc:
+            got = got.sum(dim=(2, 3))
+        e = (got - x_r.grad).abs().max().item()
+        assert e < tol * 8 * max(1.0, x_r.grad.abs().max().item()), ("dgrad", si, e)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# element-wise / reduction kernels
+# ------------------------------------------------------------------------------------------------------------------
+def _rand(g, *shape):
+    return torch.randn(*shape, generator=g)
+
+
+def pool_up_case(lib, dev, N=2, Cc=6, H=4, W=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    x = _rand(g, N, Cc, 2 * H, 2 * W).requires_grad_(True)
+    y_ref = F.avg_pool2d(x, 2)
+    dy = _rand(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xb, yb = nhwc(x.detach(), dev=dev), torch.zeros(N, H, W, round_up(Cc, 4), device=dev)
+    assert lib.caddy_k_pool2(C.byref(tv(xb, Cc)), C.byref(tv(yb, Cc)), st) == 0
+    gx = torch.ones_like(xb)
+    assert lib.caddy_k_pool2_bwd(C.byref(tv(nhwc(dy, dev=dev), Cc)), C.byref(tv(gx, Cc)), st) == 0
+    sync(dev)
+    assert (to_nchw(yb, Cc) - y_ref.detach()).abs().max() < 1e-6
+    assert (to_nchw(gx, Cc) - 1 - x.grad).abs().max() < 1e-6
+    # bilinear x2
+    x = _rand(g, N, Cc, H, W).requires_grad_(True)
+    y_ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    dy = _rand(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xb, yb = nhwc(x.detach(), dev=dev), torch.zeros(N, 2 * H, 2 * W, round_up(Cc, 4), device=dev)
+    assert lib.caddy_k_up2(C.byref(tv(xb, Cc)), C.byref(tv(yb, Cc)), st) == 0
+    gx = torch.ones_like(xb)
+    assert lib.caddy_k_up2_bwd(C.byref(tv(nhwc(dy, dev=dev), Cc)), C.byref(tv(gx, Cc)), st) == 0
+    sync(dev)
+    assert (to_nchw(yb, Cc) - y_ref.detach()).abs().max() < 1e-6
+    assert (to_nchw(gx, Cc) - 1 - x.grad).abs().max() < 2e-6
+
+
+def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed=0):
+    """out = lrelu(BN(x) + second) with second in {None, 'plain', 'bn'}; forward, running stats, backward."""
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    x = (_rand(g, N, Cc, H, W) * 2 + 0.5).requires_grad_(True)
+    x2 = _rand(g, N, Cc, H, W).requires_grad_(True)
+    gam, bet = (1 + 0.1 * _rand(g, Cc)).requires_grad_(True), (0.1 * _rand(g, Cc)).requires_grad_(True)
+    gam2, bet2 = (1 + 0.1 * _rand(g, Cc)).requires_grad_(True), (0.1 * _rand(g, Cc)).requires_grad_(True)
+    rm, rv, rm2, rv2 = 0.1 * _rand(g, Cc), 1 + 0.2 * torch.rand(Cc, generator=g), 0.1 * _rand(g, Cc), 1 + 0.2 * torch.rand(Cc, generator=g)
+    rm_r, rv_r, rm2_r, rv2_r = rm.clone(), rv.clone(), rm2.clone(), rv2.clone()
+    y = F.batch_norm(x, rm_r, rv_r, gam, bet, bool(training), 0.1, 1e-5)
+    if second == "bn":
+        y = y + F.batch_norm(x2, rm2_r, rv2_r, gam2, bet2, bool(training), 0.1, 1e-5)
+    elif second == "plain":
+        y = y + x2
+    if act:
+        y = F.leaky_relu(y, 0.2)
+    dy = _rand(g, *y.shape)
+    y.backward(dy)
+    M = N * H * W
+
+    def run_bn(xt, gm, bt, rmean, rvar):
+        xb = nhwc(xt.detach(), dev=dev)
+        sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+        if training:
+            assert lib.caddy_k_stats(C.byref(tv(xb, Cc)), P(sums), st) == 0
+        o = [torch.zeros(Cc, device=dev) for _ in range(4)]
+        gmd, btd, rmd, rvd = gm.detach().to(dev), bt.detach().to(dev), rmean.to(dev), rvar.to(dev)
+        assert lib.caddy_k_bn_finalize(P(sums), C.c_long(M), P(gmd), P(btd), P(rmd), P(rvd), Cc, training, *[P(t) for t in o], st) == 0
+        return xb, o, gmd, rmd, rvd
+
+    xb, (mean, invstd, scale, shift), gmd, rmd, rvd = run_bn(x, gam, bet, rm, rv)
+    x2b = None
+    if second == "bn":
+        x2b, (mean2, invstd2, scale2, shift2), gmd2, rmd2, rvd2 = run_bn(x2, gam2, bet2, rm2, rv2)
+    elif second == "plain":
+        x2b = nhwc(x2.detach(), dev=dev)
+    out = torch.zeros_like(xb)
+    x2tv = tv(x2b, Cc) if x2b is not None else None
+    assert lib.caddy_k_bn_apply(C.byref(tv(xb, Cc)), P(scale), P(shift), C.byref(x2tv) if x2tv else None,
+                                P(scale2) if second == "bn" else None, P(shift2) if second == "bn" else None, act, C.byref(tv(out, Cc)), st) == 0
+    sync(dev)
+    assert (to_nchw(out, Cc) - y.detach()).abs().max() < 2e-6
+    if training:
+        assert (rmd.cpu() - rm_r).abs().max() < 1e-6 and (rvd.cpu() - rv_r).abs().max() < 1e-6
+    else:
+        return
+    # backward
+    dyb = nhwc(dy, dev=dev)
+    outm = C.byref(tv(out, Cc)) if act else None
+
+    def bwd(xbuf, mean_, invstd_, gmd_, xref, gref, bref):
+        sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+        assert lib.caddy_k_bn_bwd_reduce(C.byref(tv(dyb, Cc)), outm, C.byref(tv(xbuf, Cc)), P(mean_), P(invstd_), P(sums), st) == 0
+        dx = torch.ones_like(xbuf)
+        dg, db = torch.ones(Cc, device=dev), torch.ones(Cc, device=dev)
+        assert lib.caddy_k_bn_bwd_apply(C.byref(tv(dyb, Cc)), outm, C.byref(tv(xbuf, Cc)), P(mean_), P(invstd_), P(gmd_), P(sums),
+                                        C.byref(tv(dx, Cc)), P(dg), P(db), st) == 0
+        sync(dev)
+        assert (to_nchw(dx, Cc) - 1 - xref.grad).abs().max() < 5e-6 * max(1.0, xref.grad.abs().max().item())
+        assert (dg.cpu() - 1 - gref.grad).abs().max() < 2e-5 * max(1.0, gref.grad.abs().max().item())
+        assert (db.cpu() - 1 - bref.grad).abs().max() < 2e-5 * max(1.0, bref.grad.abs().max().item())
+
+    bwd(xb, mean, invstd, gmd, x, gam, bet)
+    if second == "bn":
+        bwd(x2b, mean2, invstd2, gmd2, x2, gam2, bet2)
+    elif second == "plain":
+        dres = torch.ones_like(x2b)
+        if act:
+            assert lib.caddy_k_act_bwd_add(C.byref(tv(dyb, Cc)), C.byref(tv(out, Cc)), C.byref(tv(dres, Cc)), st) == 0
+        else:
+            assert lib.caddy_k_copy(C.byref(tv(dyb, Cc)), C.byref(tv(dres, Cc)), 1, st) == 0
+        sync(dev)
+        assert (to_nchw(dres, Cc) - 1 - x2.grad).abs().max() < 2e-6
+
+
+def lstm_case(lib, dev, N=2, Cc=12, H=3, W=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    pre = _rand(g, N, 4 * Cc, H, W).requires_grad_(True)
+    cp = _rand(g, N, Cc, H, W).requires_grad_(True)
+    i, f, o, gg = pre[:, :Cc].sigmoid(), pre[:, Cc:2 * Cc].sigmoid(), pre[:, 2 * Cc:3 * Cc].sigmoid(), pre[:, 3 * Cc:].tanh()
+    c = f * cp + i * gg
+    h = o * torch.tanh(c)
+    dh, dc = _rand(g, *h.shape), _rand(g, *c.shape)
+    (h * dh).sum().backward(retain_graph=True)
+    (c * dc).sum().backward()
+    gates = nhwc(pre.detach(), dev=dev)
+    cpb = nhwc(cp.detach(), dev=dev)
+    hb, cb = torch.zeros_like(cpb), torch.zeros_like(cpb)
+    assert lib.caddy_k_lstm_fwd(C.byref(tv(gates, 4 * Cc)), C.byref(tv(cpb, Cc)), C.byref(tv(hb, Cc)), C.byref(tv(cb, Cc)), st) == 0
+    dgates, dcp = torch.zeros_like(gates), torch.ones_like(cpb)
+    assert lib.caddy_k_lstm_bwd(C.byref(tv(gates, 4 * Cc)), C.byref(tv(cpb, Cc)), C.byref(tv(cb, Cc)), C.byref(tv(nhwc(dh, dev=dev), Cc)),
+                                C.byref(tv(nhwc(dc, dev=dev), Cc)), C.byref(tv(dgates, 4 * Cc)), C.byref(tv(dcp, Cc)), st) == 0
+    sync(dev)
+    assert (to_nchw(hb, Cc) - h.detach()).abs().max() < 2e-6 and (to_nchw(cb, Cc) - c.detach()).abs().max() < 2e-6
+    assert (to_nchw(dgates, 4 * Cc) - pre.grad).abs().max() < 5e-6
+    assert (to_nchw(dcp, Cc) - 1 - cp.grad).abs().max() < 5e-6
+
+
+def misc_case(lib, dev, N=3, H=4, W=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    # attention gate
+    x = _rand(g, N, 65, H, W).requires_grad_(True)
+    att = torch.sigmoid(x[:, 64:])
+    out = x[:, :64] * att
+    dout, datt = _rand(g, *out.shape), _rand(g, *att.shape)
+    (out * dout).sum().backward(retain_graph=True)
+    (att * datt).sum().backward()
+    xb = nhwc(x.detach(), ld=68, dev=dev)
+    ob, ab = torch.zeros(N, H, W, 64, device=dev), torch.zeros(N, H, W, 4, device=dev)
+    assert lib.caddy_k_attn_mul(C.byref(tv(xb, 65)), C.byref(tv(ob, 64)), C.byref(tv(ab, 1)), st) == 0
+    dx = torch.ones_like(xb)
+    assert lib.caddy_k_attn_mul_bwd(C.byref(tv(xb, 65)), C.byref(tv(nhwc(dout, dev=dev), 64)), C.byref(tv(nhwc(datt, dev=dev), 1)), C.byref(tv(dx, 65)), st) == 0
+    sync(dev)
+    assert (to_nchw(ob, 64) - out.detach()).abs().max() < 2e-6 and (to_nchw(ab, 1) - att.detach()).abs().max() < 2e-6
+    assert (to_nchw(dx, 65) - 1 - x.grad).abs().max() < 1e-5
+    # GAP fwd/bwd, colsum, spatial sum, tanh bwd
+    x = _rand(g, N, 10, H, W)
+    xb = nhwc(x, dev=dev)
+    gap = torch.zeros(N, 10, device=dev)
+    assert lib.caddy_k_gap(C.byref(tv(xb, 10)), P(gap), st) == 0
+    dgap = _rand(g, N, 10).to(dev)
+    dx = torch.ones_like(xb)
+    assert lib.caddy_k_gap_bwd(P(dgap), C.byref(tv(dx, 10)), st) == 0
+    cs = torch.ones(10, device=dev)
+    assert lib.caddy_k_colsum(C.byref(tv(xb, 10)), P(cs), st) == 0
+    ss = torch.ones(N, 16, device=dev)
+    assert lib.caddy_k_spatial_sum(C.byref(tv(xb, 10)), P(ss), C.c_long(16), st) == 0
+    y = torch.tanh(_rand(g, N, 3, H, W)); dy = _rand(g, N, 3, H, W)
+    dz = torch.zeros(N, H, W, 4, device=dev)
+    assert lib.caddy_k_tanh_bwd(C.byref(tv(nhwc(dy, dev=dev), 3)), C.byref(tv(nhwc(y, dev=dev), 3)), C.byref(tv(dz, 3)), st) == 0
+    sync(dev)
+    assert (gap.cpu() - x.mean(dim=(2, 3))).abs().max() < 2e-6
+    assert (to_nchw(dx, 10) - 1 - (dgap.cpu() / (H * W))[:, :, None, None]).abs().max() < 2e-6
+    assert (cs.cpu() - 1 - x.sum(dim=(0, 2, 3))).abs().max() < 2e-5
+    assert (ss.cpu()[:, :10] - 1 - x.sum(dim=(2, 3))).abs().max() < 2e-5 and torch.all(ss.cpu()[:, 10:] == 1)
+    assert (to_nchw(dz, 3) - dy * (1 - y * y)).abs().max() < 2e-6
+    # layout conversion with strides (time-slice of a (B,T,C,H,W) tensor) + batch sum
+    B, T, Cc = 2, 3, 6
+    src = _rand(g, B, T, Cc, H, W).to(dev)
+    d = torch.zeros(B, H, W, 8, device=dev)
+    assert lib.caddy_k_nchw_to_nhwc(C.c_void_p(src.data_ptr() + 4 * Cc * H * W), C.c_long(T * Cc * H * W), C.byref(tv(d, Cc)), st) == 0
+    back = torch.zeros(B, T, Cc, H, W, device=dev)
+    assert lib.caddy_k_nhwc_to_nchw(C.byref(tv(d, Cc)), C.c_void_p(back.data_ptr() + 4 * 2 * Cc * H * W), C.c_long(T * Cc * H * W), 0, st) == 0
+    bs = torch.ones(Cc * H * W, device=dev)
+    assert lib.caddy_k_batch_sum(P(src), C.c_long(T * Cc * H * W), C.c_long(Cc * H * W), B, P(bs), st) == 0
+    sync(dev)
+    assert torch.equal(to_nchw(d, Cc), src[:, 1].cpu()) and torch.all(d[..., Cc:] == 0)
+    assert torch.equal(back[:, 2].cpu(), src[:, 1].cpu())
+    assert (bs.cpu() - 1 - src[:, 0].cpu().sum(0).flatten()).abs().max() < 1e-5
+    # strided copy into a channel slice of a wider buffer
+    wide = torch.zeros(B, H, W, 16, device=dev)
+    s6 = nhwc(src[:, 0].cpu(), dev=dev)
+    assert lib.caddy_k_copy(C.byref(tv(s6, Cc)), C.byref(tv(wide, Cc, ptr_off=4)), 0, st) == 0
+    sync(dev)
+    assert torch.equal(wide[..., 4:4 + Cc].cpu(), s6[..., :Cc].cpu()) and torch.all(wide[..., :4] == 0) and torch.all(wide[..., 4 + Cc:] == 0)
+
+
+def adam_case(lib, dev, n=1000, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p = _rand(g, n); gr = _rand(g, n)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=4e-4, weight_decay=1e-6)
+    pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in (1, 2, 3):
+        pr.grad = gr.clone() * step
+        opt.step()
+        gd = (gr * step).to(dev)
+        assert lib.caddy_k_adam(P(pd), P(gd), P(m), P(v), C.c_long(n), C.c_float(4e-4), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+                                C.c_float(1e-6), step, C.c_float(1.0), stream(dev)) == 0
+    sync(dev)
+    assert (pd.cpu() - pr.detach()).abs().max() < 1e-6

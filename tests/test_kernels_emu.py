@@ -1,0 +1,39 @@
+"""HIP kernel sources executed on the host functional simulator (tests/emu) and compared with torch CPU ops."""
+import pytest
+
+from tests import kernel_cases as K
+from tests.emu.loader import load_emu
+
+pytestmark = pytest.mark.emu
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=2, H=6, W=5, segs=[(16, 0)], Cout=32, KS=3),
+    dict(N=1, H=9, W=7, segs=[(5, 0)], Cout=3, KS=7, bias=True, act=1),
+    dict(N=2, H=4, W=4, segs=[(20, 0), (9, 1), (24, 0)], Cout=64, KS=3, nw=4, bias=True),
+    dict(N=3, H=8, W=8, segs=[(32, 0)], Cout=65, KS=1),
+    dict(N=2, H=12, W=12, segs=[(8, 0), (4, 1)], Cout=136, KS=3),
+])
+def test_conv(kw):
+    K.conv_case(load_emu(), "cpu", **kw)
+
+
+def test_pool_upsample():
+    K.pool_up_case(load_emu(), "cpu")
+
+
+@pytest.mark.parametrize("second,act,training", [("bn", 1, 1), ("plain", 1, 1), (None, 0, 1), (None, 1, 0), ("plain", 0, 1)])
+def test_batchnorm(second, act, training):
+    K.bn_case(load_emu(), "cpu", second=second, act=act, training=training)
+
+
+def test_lstm_gates():
+    K.lstm_case(load_emu(), "cpu")
+
+
+def test_misc_pointwise():
+    K.misc_case(load_emu(), "cpu")
+
+
+def test_adam():
+    K.adam_case(load_emu(), "cpu")

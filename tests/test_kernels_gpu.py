@@ -1,0 +1,52 @@
+"""Per-kernel parity on the MI355X: the same cases as tests/test_kernels_emu.py, through the C-ABI of libcaddy_hip.so."""
+import pytest
+import torch
+
+from tests import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from playablevideogeneration_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _lib.load()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=2, H=6, W=5, segs=[(16, 0)], Cout=32, KS=3),
+    dict(N=1, H=9, W=7, segs=[(5, 0)], Cout=3, KS=7, bias=True, act=1),
+    dict(N=2, H=4, W=4, segs=[(20, 0), (9, 1), (24, 0)], Cout=64, KS=3, nw=4, bias=True),
+    dict(N=3, H=8, W=8, segs=[(32, 0)], Cout=65, KS=1),
+    dict(N=2, H=12, W=12, segs=[(8, 0), (4, 1)], Cout=136, KS=3),
+    dict(N=4, H=32, W=32, segs=[(64, 0), (9, 1), (128, 0)], Cout=512, KS=3, nw=4, bias=True, tol=5e-5),   # BAIR LSTM0 shape
+    dict(N=2, H=64, W=64, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, tol=5e-5),
+    dict(N=2, H=48, W=40, segs=[(64, 0)], Cout=32, KS=3, tol=5e-5),
+])
+def test_conv(lib, kw):
+    K.conv_case(lib, "cuda", **kw)
+
+
+def test_pool_upsample(lib):
+    K.pool_up_case(lib, "cuda")
+    K.pool_up_case(lib, "cuda", N=3, Cc=64, H=16, W=24, seed=1)
+
+
+@pytest.mark.parametrize("second,act,training", [("bn", 1, 1), ("plain", 1, 1), (None, 0, 1), (None, 1, 0), ("plain", 0, 1)])
+def test_batchnorm(lib, second, act, training):
+    K.bn_case(lib, "cuda", second=second, act=act, training=training)
+    K.bn_case(lib, "cuda", N=4, Cc=65, H=32, W=32, second=second, act=act, training=training, seed=2)
+
+
+def test_lstm_gates(lib):
+    K.lstm_case(lib, "cuda")
+    K.lstm_case(lib, "cuda", N=4, Cc=128, H=16, W=16, seed=3)
+
+
+def test_misc_pointwise(lib):
+    K.misc_case(lib, "cuda")
+
+
+def test_adam(lib):
+    K.adam_case(lib, "cuda", n=100003)
