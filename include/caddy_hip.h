@@ -1,0 +1,134 @@
+/* caddy_hip.h -- C ABI of libcaddy_hip.so: the MI355X-native (gfx950) CADDY hot path.
+ *
+ * Drop-in boundary.  The reference is pure Python, so the "FFI" a maintainer binds is ctypes
+ * (see INTEGRATION.md); every entry point takes raw device pointers + sizes and returns an int status
+ * (0 = ok, negative = error, text via caddy_last_error()).  Nothing here allocates device memory: the caller hands over
+ * one workspace (caddy_workspace_bytes) and the flat parameter / gradient buffers (caddy_param_floats /
+ * caddy_trainable_floats floats), laid out per caddy_param_info_get -- tensors at the boundary are in the reference's
+ * state_dict format (OIHW fp32, names of /root/reference model/main_model/model.py's state_dict).
+ *
+ * Each function cites the reference interface it replaces (paths relative to the reference repository).
+ */
+#ifndef CADDY_HIP_H
+#define CADDY_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct caddy_ctx caddy_ctx;
+
+/* Hyper-parameters read by the hot path (model/main_model/model.py:28-38, "Config keys" in SURVEY.md section 8a). */
+typedef struct caddy_config {
+    int variant;        /* 0: model.main_model.model, 1: model.reduced_model.model (config["model"]["architecture"]) */
+    int batch;          /* B: clips per forward (per GPU) */
+    int seq_len;        /* T: observations per clip */
+    int height, width;  /* frame size, multiples of 16 */
+    int stacking;       /* training.batching.observation_stacking */
+    int actions;        /* data.actions_count */
+    int action_dim;     /* model.action_network.action_space_dimension */
+    int hidden;         /* model.dynamics_network.hidden_state_size (128 main / 64 reduced) */
+    int use_gumbel, hard_gumbel, use_variations;   /* model.action_network.* */
+    float centroid_alpha;                          /* model.centroid_estimator.alpha */
+} caddy_config;
+
+typedef struct caddy_param_info {
+    char name[128];   /* reference state_dict key */
+    long offset;      /* float offset into the flat parameter buffer (and, for kind 0, the flat gradient buffer) */
+    int ndim;
+    int shape[4];
+    int kind;         /* 0 trainable parameter, 1 BatchNorm running statistic, 2 non-trainable parameter (centroids) */
+} caddy_param_info;
+
+/* Noise drawn by the reference from torch's CPU generator, in its call order; device pointers. */
+typedef struct caddy_noise {
+    const float* eps_states;      /* (B*T, Da)      action_network.py:45 via :92  (first A call)            */
+    const float* eps_dirs;        /* (B, T-1, Da)   action_network.py:45 via :108 (first A call)            */
+    const float* gumbel_uniform;  /* (B*(T-1), K)   gumbel_softmax.py:33                                    */
+    const float* eps_states_rec;  /* second A call (reconstructed states), model.py:277                     */
+    const float* eps_dirs_rec;
+} caddy_noise;
+
+/* Loss weights of Trainer.compute_losses (training/trainer.py:494-500); the VGG perceptual term is not part of this
+ * library ("parity unpinned"). mi_ema: SmoothMutualInformationLoss state (K*K floats, device) or NULL. */
+typedef struct caddy_loss_cfg {
+    double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda;
+    float* mi_ema;
+    float mi_ema_alpha;
+    int update_mi_ema;
+} caddy_loss_cfg;
+
+enum { CADDY_LOSS_TOTAL = 0, CADDY_LOSS_REC, CADDY_LOSS_STATES, CADDY_LOSS_ENTROPY, CADDY_LOSS_DIRKL, CADDY_LOSS_MI,
+       CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2, CADDY_LOSS_SLOTS = 16 };
+
+/* Output ids of caddy_get_output: 0..19 = positions of the 20-tuple returned by Model.forward_full_model
+ * (model/main_model/model.py:280-286); 100+r = r-th entry of the multi-resolution list (tuple position 1). */
+enum { CADDY_OUT_MULTIRES0 = 100 };
+
+const char* caddy_last_error(void);
+
+/* --- parameters: replaces nn.Module.state_dict()/load_state_dict()/parameters() (training/trainer.py:36,80-122) --- */
+int caddy_param_count(const caddy_config* cfg);
+int caddy_param_info_get(const caddy_config* cfg, int index, caddy_param_info* out);
+long caddy_param_floats(const caddy_config* cfg);       /* size of the flat parameter buffer (all kinds) */
+long caddy_trainable_floats(const caddy_config* cfg);   /* kind-0 entries come first: [0, trainable) */
+
+/* --- context --- */
+size_t caddy_workspace_bytes(const caddy_config* cfg);
+caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes);
+void caddy_ctx_destroy(caddy_ctx* ctx);
+int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
+
+/* --- Model.forward(batch_tuple, ground_truth_observations_init, gumbel_temperature=...) in full-model mode:
+ *     model/main_model/model.py:57-82 -> forward_full_model :84-286.  obs: (B,T,3S,H,W) fp32 device, reference layout.
+ *     training != 0: train-mode BatchNorm + centroid EMA + backward tape; 0: eval mode (evaluation/evaluator.py:125).
+ *     samples_in / variations_in (nullable): outputs of an evaluation action_sampler / action_variation_sampler. --- */
+int caddy_forward_full(caddy_ctx* ctx, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training,
+                       const float* samples_in, const float* variations_in);
+int caddy_get_output(caddy_ctx* ctx, int id, void* dst);      /* copy one output, converted to the reference layout */
+/* d(loss)/d(output) after caddy_loss_backward, same layout (what autograd holds in `.grad` of a retained output);
+ * available for ids 0, 100-102, 2, 3, 4, 6, 8, 9, 10, 12, 15, 16, 18. */
+int caddy_get_output_grad(caddy_ctx* ctx, int id, void* dst);
+
+/* --- losses + loss.backward(): training/trainer.py:447-500,585 fused into one pass (L1 multi-resolution, states MSE,
+ *     entropy, direction KL, (smooth) mutual information, action-state KL) followed by BPTT through D, R, E, A.
+ *     Gradients land in the flat gradient buffer (reference layout).  losses_host: CADDY_LOSS_SLOTS doubles (host). --- */
+int caddy_loss_backward(caddy_ctx* ctx, const caddy_loss_cfg* cfg, double* losses_host);
+
+/* --- optimizer.step(): torch.optim.Adam with L2 weight decay (training/trainer.py:36,586); m, v: trainable floats --- */
+int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int step, float grad_scale);
+
+/* --- play.py roll-out: Model.start_inference (model.py:561-568) / Model.generate_next (model.py:570-607), eval mode.
+ *     observation: (3S,H,W); variation: (Da) or NULL (= zeros, noise=False); frame_out: (3,H,W); obs_out: (3S,H,W). --- */
+int caddy_start_inference(caddy_ctx* ctx);
+int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
+
+/* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last
+ *     forward, converted to (N,C,H,W) --- */
+int caddy_debug_count(caddy_ctx* ctx);
+int caddy_debug_dims(caddy_ctx* ctx, int i, int* nhwc4);
+int caddy_debug_get(caddy_ctx* ctx, int i, int grad, float* dst_nchw);
+
+/* --- BatchNorm bookkeeping: number of train-mode calls of BN layer `i` since creation (num_batches_tracked) --- */
+int caddy_bn_layer_count(caddy_ctx* ctx);
+long caddy_bn_calls(caddy_ctx* ctx, int i, char* name_out128);
+
+/* --- per-kernel entry points (unit-parity tests); argument structs are declared in csrc/common.h, pack.h --- */
+struct ConvArgs; struct WgradArgs; struct PackDesc; struct TV;
+int caddy_k_conv_fwd(const struct ConvArgs* a, void* stream);
+int caddy_k_conv_wgrad(const struct WgradArgs* a, void* stream);
+int caddy_k_conv_pick_bn(int cout);
+int caddy_k_pack_fwd(const struct PackDesc* d, float* wp, void* stream);
+int caddy_k_pack_dgrad(const struct PackDesc* d, int seg, float* wpd, int Cd_pad, int Kd, void* stream);
+int caddy_k_unpack_wgrad(const struct PackDesc* d, const float* dwp, void* stream);
+int caddy_k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale, void* stream);
+/* (pointwise kernels: caddy_k_copy, caddy_k_pool2[_bwd], caddy_k_up2[_bwd], caddy_k_stats, caddy_k_bn_finalize, caddy_k_bn_apply,
+ *  caddy_k_bn_bwd_reduce, caddy_k_bn_bwd_apply, caddy_k_act_bwd_add, caddy_k_lstm_fwd, caddy_k_lstm_bwd, caddy_k_tanh_bwd,
+ *  caddy_k_attn_mul[_bwd], caddy_k_gap[_bwd], caddy_k_colsum, caddy_k_spatial_sum, caddy_k_nchw_to_nhwc, caddy_k_nhwc_to_nchw,
+ *  caddy_k_batch_sum -- see csrc/capi_kernels.cpp for the exact signatures) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+#pragma once
+#include "common.h"
+
+#define AUX_LD 16   // per-(b,t) auxiliary input row of R: [action sample (K) | variation (Da) | zero pad]
+
+enum { LOSS_TOTAL = 0, LOSS_REC, LOSS_STATES, LOSS_ENTROPY, LOSS_DIRKL, LOSS_MI, LOSS_STATEKL, LOSS_HIDDEN, LOSS_L1_R0, LOSS_L1_R1, LOSS_L1_R2, LOSS_SLOTS = 16 };
+
+struct LossWeights { double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda; };
+
+// linear layers of the action network (boundary layout, straight views into the flat parameter / gradient buffers)
+struct HeadParams {
+    int F, Da, K;
+    const float *Wm, *bm, *Wv, *bv, *Wf, *bf;
+    float *dWm, *dbm, *dWv, *dbv, *dWf, *dbf;
+};
+// per-call buffers of one action-network evaluation over (B, T)
+struct HeadBufs {
+    const float* feat;          // (B*T, F) pooled features
+    const float *eps_s, *eps_d, *unif;   // noise: (B*T,Da), (B*(T-1),Da), (B*(T-1),K)
+    float *mu, *raw;            // (B*T, Da)
+    float *sdist, *ssamp;       // (B*T, 2, Da), (B*T, Da)            action_states_distribution / sampled_action_states
+    float *ddist, *dirs;        // (B*(T-1), 2, Da), (B*(T-1), Da)    action_directions_distribution / sampled_action_directions
+    float *logits, *logp, *prob;  // (B*(T-1), K)
+    float *ysoft, *samples, *variations, *aux, *cen_used;
+    long long* selected;        // (B*(T-1)) int64 arg-max
+    // gradients
+    float *d_feat, *d_logits, *d_ddist, *d_sdist, *d_aux, *g_dmu, *g_dvar;
+};
+struct SampleCfg {
+    int mode;                   // 0: softmax probabilities, 1: Gumbel-softmax, 2: externally supplied samples
+    int hard, training, use_variations;
+    float tau, alpha;
+    float* centroids;           // (K, Da) estimated_centroids (updated in place in training mode)
+    const float* samples_in;    // mode 2
+    const float* variations_in; // optional external variations (evaluation action_variation_sampler)
+};
+struct SmallLossArgs {
+    int K, Da, NS, NT;
+    const float *p, *q, *logp;  // softmax(logits), softmax(reconstructed logits), log_softmax(logits)   (NS, K)
+    const float *ddist, *sdist, *sdist_r;
+    float *d_logits, *d_logits_r, *d_ddist, *d_sdist_r;
+    float* ema; float ema_alpha; int update_ema;   // SmoothMutualInformationLoss state (K,K) or null
+    float mi_lamb, w_mi, w_entropy, w_dirkl, w_statekl;
+    double* acc;
+};
+
+int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st);
+int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, hipStream_t st);
+int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st);
+int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st);
+int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st);
+int loss_small(const SmallLossArgs& a, hipStream_t st);
+int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, hipStream_t st);

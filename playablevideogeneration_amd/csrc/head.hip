@@ -1,0 +1,399 @@
+// Small-tensor kernels of the hot path: action-network tail (action_network.py:86-118), Gumbel-softmax sampling
+// (gumbel_softmax.py:25-72), centroid EMA + variations (centroid_estimator.py:38-94) and the fused loss terms with their
+// gradient seeds (training/losses.py; training/trainer.py:447-500).  N = B*T samples (~128): latency-bound, not
+// roofline-relevant; the L1 / MSE losses over frames and states are HBM-bound streaming reductions.
+#include "common.h"
+#include "head.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < nw; i++) t += sh[i];
+    return t;
+}
+
+// ---- A tail, part 1: mu / |raw| / sampled action states, one thread per (n, d) --------------------------------------
+__global__ void k_head_fc(HeadBufs h, HeadParams p, int NBT) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NBT * p.Da) return;
+    int n = i / p.Da, d = i - n * p.Da;
+    const float* f = h.feat + (long)n * p.F;
+    float m = p.bm[d], r = p.bv[d];
+    for (int k = 0; k < p.F; k++) { m = fmaf(p.Wm[d * p.F + k], f[k], m); r = fmaf(p.Wv[d * p.F + k], f[k], r); }
+    float var = fabsf(r);
+    h.mu[i] = m; h.raw[i] = r;
+    h.sdist[(long)n * 2 * p.Da + d] = m; h.sdist[(long)n * 2 * p.Da + p.Da + d] = var;
+    h.ssamp[i] = h.eps_s[i] * sqrtf(var) + m;
+}
+// ---- part 2: direction distribution, sampled direction, logits; one thread per (b, t<T-1) ---------------------------
+__global__ void k_head_dirs(HeadBufs h, HeadParams p, int B, int T) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= B * (T - 1)) return;
+    int b = n / (T - 1), t = n - b * (T - 1);
+    int s0 = (b * T + t) * p.Da, s1 = s0 + p.Da;
+    float dv[8];
+    for (int d = 0; d < p.Da; d++) {
+        float dmu = h.mu[s1 + d] - h.mu[s0 + d];
+        float dvar = fabsf(h.raw[s1 + d]) + fabsf(h.raw[s0 + d]);
+        h.ddist[(long)n * 2 * p.Da + d] = dmu; h.ddist[(long)n * 2 * p.Da + p.Da + d] = dvar;
+        dv[d] = h.eps_d[n * p.Da + d] * sqrtf(dvar) + dmu;
+        h.dirs[n * p.Da + d] = dv[d];
+    }
+    for (int k = 0; k < p.K; k++) {
+        float l = p.bf[k];
+        for (int d = 0; d < p.Da; d++) l = fmaf(p.Wf[k * p.Da + d], dv[d], l);
+        h.logits[n * p.K + k] = l;
+    }
+}
+// ---- sampling: softmax / log-softmax, centroid EMA (train), Gumbel sample, variations, arg-max.  Single block. --------
+__global__ void k_head_sample(HeadBufs h, HeadParams p, SampleCfg c, int NS) {
+    __shared__ float cen[16 * 8];
+    const int K = p.K, Da = p.Da;
+    for (int n = threadIdx.x; n < NS; n += blockDim.x) {
+        const float* l = h.logits + n * K;
+        float mx = l[0];
+        for (int k = 1; k < K; k++) mx = fmaxf(mx, l[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; k++) se += expf(l[k] - mx);
+        float lse = mx + logf(se);
+        for (int k = 0; k < K; k++) { h.logp[n * K + k] = l[k] - lse; h.prob[n * K + k] = expf(l[k] - lse); }
+    }
+    __syncthreads();
+    if (threadIdx.x < K * Da) {
+        int k = threadIdx.x / Da, d = threadIdx.x - k * Da;
+        float cv = c.centroids[k * Da + d];
+        if (c.training) {   // centroid_estimator.py:61-68 (means of the direction distribution, soft assignments)
+            float num = 0.f, den = 0.f;
+            for (int n = 0; n < NS; n++) { float pk = h.prob[n * K + k]; num += pk * h.ddist[(long)n * 2 * Da + d]; den += pk; }
+            cv = cv * (1.f - c.alpha) + (num / den) * c.alpha;
+            c.centroids[k * Da + d] = cv;
+        }
+        cen[k * Da + d] = cv;
+        h.cen_used[k * Da + d] = cv;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < NS; n += blockDim.x) {
+        float y[16];
+        if (c.mode == 2) {            // externally supplied samples (evaluation action_sampler, model.py:173-174)
+            for (int k = 0; k < K; k++) y[k] = c.samples_in[n * K + k];
+        } else if (c.mode == 1) {     // Gumbel-softmax (gumbel_softmax.py:33-45)
+            float z[16], mx = -1e30f;
+            for (int k = 0; k < K; k++) {
+                float g = -logf(-logf(h.unif[n * K + k] + 1e-20f) + 1e-20f);
+                z[k] = (h.logp[n * K + k] + g) / c.tau;
+                mx = fmaxf(mx, z[k]);
+            }
+            float se = 0.f;
+            for (int k = 0; k < K; k++) { y[k] = expf(z[k] - mx); se += y[k]; }
+            for (int k = 0; k < K; k++) y[k] /= se;
+        } else {
+            for (int k = 0; k < K; k++) y[k] = h.prob[n * K + k];
+        }
+        int am = 0;
+        for (int k = 1; k < K; k++) if (y[k] > y[am]) am = k;
+        for (int k = 0; k < K; k++) h.ysoft[n * K + k] = y[k];
+        if (c.mode == 1 && c.hard) { for (int k = 0; k < K; k++) y[k] = (k == am) ? 1.f : 0.f; }   // straight-through value
+        h.selected[n] = am;
+        float* aux = h.aux + (long)n * AUX_LD;
+        float sy = 0.f;
+        for (int k = 0; k < K; k++) { aux[k] = y[k]; h.samples[n * K + k] = y[k]; sy += y[k]; }
+        for (int d = 0; d < Da; d++) {
+            float v;
+            if (c.variations_in) v = c.variations_in[n * Da + d];
+            else {
+                v = 0.f;
+                for (int k = 0; k < K; k++) v += y[k] * (h.dirs[n * Da + d] - cen[k * Da + d]);
+                if (!c.use_variations) v = v * 0.f;
+            }
+            aux[K + d] = v; h.variations[n * Da + d] = v;
+        }
+        for (int k = K + Da; k < AUX_LD; k++) aux[k] = 0.f;
+    }
+}
+
+// ---- backward, phase 1: per (b, t<T-1): sampling -> logits -> direction sample -> (d_dmu, d_dvar) ------------------
+__global__ void k_head_bwd1(HeadBufs h, HeadParams p, SampleCfg c, int NS, int first_call) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NS) return;
+    const int K = p.K, Da = p.Da;
+    float dl[16], dd[8];
+    for (int k = 0; k < K; k++) dl[k] = h.d_logits[n * K + k];
+    for (int d = 0; d < Da; d++) dd[d] = 0.f;
+    if (first_call && c.mode != 2) {
+        const float* ga = h.d_aux + (long)n * AUX_LD;
+        float da[16];
+        for (int k = 0; k < K; k++) da[k] = ga[k];
+        if (c.use_variations && !c.variations_in) {   // v = sum_k a_k (d - c_k)
+            float sy = 0.f;
+            for (int k = 0; k < K; k++) sy += h.samples[n * K + k];
+            for (int d = 0; d < Da; d++) {
+                float gv = ga[K + d];
+                dd[d] += gv * sy;
+                for (int k = 0; k < K; k++) da[k] += gv * (h.dirs[n * Da + d] - h.cen_used[k * Da + d]);
+            }
+        }
+        const float* y = h.ysoft + n * K;
+        float dot = 0.f;
+        for (int k = 0; k < K; k++) dot += y[k] * da[k];
+        if (c.mode == 1) {   // y = softmax((logp+g)/tau); logp = log_softmax(logits)
+            float dz[16], sdz = 0.f;
+            for (int k = 0; k < K; k++) { dz[k] = y[k] * (da[k] - dot) / c.tau; sdz += dz[k]; }
+            for (int k = 0; k < K; k++) dl[k] += dz[k] - h.prob[n * K + k] * sdz;
+        } else {             // samples = softmax(logits)
+            for (int k = 0; k < K; k++) dl[k] += y[k] * (da[k] - dot);
+        }
+    }
+    for (int k = 0; k < K; k++) {
+        atomicAdd(&p.dbf[k], dl[k]);
+        for (int d = 0; d < Da; d++) { atomicAdd(&p.dWf[k * Da + d], dl[k] * h.dirs[n * Da + d]); dd[d] += p.Wf[k * Da + d] * dl[k]; }
+    }
+    for (int d = 0; d < Da; d++) {
+        float dvar = h.ddist[(long)n * 2 * Da + Da + d];
+        h.g_dmu[n * Da + d] = dd[d] + h.d_ddist[(long)n * 2 * Da + d];
+        h.g_dvar[n * Da + d] = dd[d] * h.eps_d[n * Da + d] * 0.5f / sqrtf(dvar) + h.d_ddist[(long)n * 2 * Da + Da + d];
+    }
+}
+// ---- phase 2: per (b, t): fold pred/succ grads, abs, FC backward -> d_feat + FC weight grads ------------------------
+__global__ void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= B * T) return;
+    const int Da = p.Da;
+    int b = n / T, t = n - b * T;
+    float gm[8], gr[8];
+    for (int d = 0; d < Da; d++) {
+        float gmu = h.d_sdist[(long)n * 2 * Da + d], gvar = h.d_sdist[(long)n * 2 * Da + Da + d];
+        if (t >= 1) { int m = b * (T - 1) + t - 1; gmu += h.g_dmu[m * Da + d]; gvar += h.g_dvar[m * Da + d]; }
+        if (t < T - 1) { int m = b * (T - 1) + t; gmu -= h.g_dmu[m * Da + d]; gvar += h.g_dvar[m * Da + d]; }
+        float raw = h.raw[n * Da + d];
+        gm[d] = gmu;
+        gr[d] = gvar * (raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f));
+        atomicAdd(&p.dbm[d], gm[d]); atomicAdd(&p.dbv[d], gr[d]);
+    }
+    const float* f = h.feat + (long)n * p.F;
+    float* df = h.d_feat + (long)n * p.F;
+    for (int k = 0; k < p.F; k++) {
+        float acc = 0.f;
+        for (int d = 0; d < Da; d++) {
+            acc += p.Wm[d * p.F + k] * gm[d] + p.Wv[d * p.F + k] * gr[d];
+            atomicAdd(&p.dWm[d * p.F + k], gm[d] * f[k]); atomicAdd(&p.dWv[d * p.F + k], gr[d] * f[k]);
+        }
+        df[k] = acc;
+    }
+}
+
+// ---- losses ------------------------------------------------------------------------------------------------------------
+// L1 between the resized ground-truth frame and a reconstruction (ObservationsLoss, losses.py:61-118): bilinear with
+// align_corners=False at integer factors 1 / 2 / 4 == identity / 2x2 mean / mean of the central 2x2 of each 4x4 block.
+__global__ __launch_bounds__(256) void k_loss_l1(TV gt, TV rec, TV drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc) {
+    __shared__ double sh[8];
+    const int HW = rec.H * rec.W;
+    const long npix = (long)rec.N * HW;
+    double s = 0.0;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < npix; q += (long)gridDim.x * blockDim.x) {
+        long fr = q / HW; int rem = (int)(q - fr * HW); int y = rem / rec.W, x = rem - y * rec.W;
+        long b = fr / Trec, t = fr - b * Trec;
+        const float* g = gt.p + (b * Tobs + t + t_off) * gt.sn;
+        const float* r = rec.p + fr * rec.sn + (long)rem * rec.ld;
+        float* dr = drec.p + fr * drec.sn + (long)rem * drec.ld;
+        for (int ch = 0; ch < 3; ch++) {
+            float gv;
+            if (f == 1) gv = g[((long)y * gt.W + x) * gt.ld + ch];
+            else {
+                int y0 = f == 2 ? 2 * y : 4 * y + 1, x0 = f == 2 ? 2 * x : 4 * x + 1;
+                const float* gp = g + ((long)y0 * gt.W + x0) * gt.ld + ch;
+                gv = 0.5f * (0.5f * gp[0] + 0.5f * gp[gt.ld]) + 0.5f * (0.5f * gp[(long)gt.W * gt.ld] + 0.5f * gp[(long)(gt.W + 1) * gt.ld]);
+            }
+            float d = r[ch] - gv;
+            s += fabsf(d);
+            dr[ch] += gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+// MSE(a.detach(), b) over the first C channels (StatesLoss / HiddenStatesLoss, losses.py:14-53); db += gscale*2*(b-a)
+__global__ __launch_bounds__(256) void k_loss_mse(TV a, TV b, TV db, float gscale, double* acc) {
+    __shared__ double sh[8];
+    const int HW = a.H * a.W, C = a.C;
+    const long items = (long)a.N * HW * C;
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        long q = i / C; int c = (int)(i - q * C);
+        long n = q / HW; long pix = q - n * HW;
+        float d = b.p[n * b.sn + pix * b.ld + c] - a.p[n * a.sn + pix * a.ld + c];
+        s += (double)d * d;
+        db.p[n * db.sn + pix * db.ld + c] += gscale * 2.f * d;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+// entropy + KL(dir || N(0,1)) + (smooth) mutual information + KL(general gaussian); single block; writes gradient seeds.
+__global__ void k_loss_small(SmallLossArgs a) {
+    __shared__ float Pm[16 * 16], Gm[16 * 16], rowv[16], colv[16];
+    __shared__ double sh[8];
+    __shared__ float Ssum;
+    const int K = a.K, Da = a.Da, NS = a.NS, NT = a.NT;
+    const float FEPS = 2.220446049250313e-16f;   // sys.float_info.epsilon (losses.py:270)
+    // joint matrix P = sum_n p_n q_n^T
+    if (threadIdx.x < K * K) {
+        int i = threadIdx.x / K, j = threadIdx.x - i * K;
+        float s = 0.f;
+        for (int n = 0; n < NS; n++) s += a.p[n * K + i] * a.q[n * K + j];
+        Pm[i * 16 + j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < K; i++) for (int j = 0; j < K; j++) s += Pm[i * 16 + j]; Ssum = s; }
+    __syncthreads();
+    float sym = 0.f, mp = 0.f;
+    int mi = threadIdx.x / K, mj = threadIdx.x - mi * K;
+    if (threadIdx.x < K * K) {
+        sym = 0.5f * (Pm[mi * 16 + mj] + Pm[mj * 16 + mi]);
+        mp = sym / Ssum;
+        if (a.ema) { mp = a.ema[mi * K + mj] * (1.f - a.ema_alpha) + mp * a.ema_alpha; }
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) { Gm[mi * 16 + mj] = mp; if (a.ema && a.update_ema) a.ema[mi * K + mj] = mp; }
+    __syncthreads();
+    if (threadIdx.x < K) { float r = 0.f, c = 0.f; for (int j = 0; j < K; j++) { r += Gm[threadIdx.x * 16 + j]; c += Gm[j * 16 + threadIdx.x]; } rowv[threadIdx.x] = r; colv[threadIdx.x] = c; }
+    __syncthreads();
+    double mi_term = 0.0;
+    float Mc = 0.f, Rc = 0.f, Cc = 0.f;
+    if (threadIdx.x < K * K) {
+        Mc = mp < FEPS ? FEPS : mp; Rc = rowv[mi] < FEPS ? FEPS : rowv[mi]; Cc = colv[mj] < FEPS ? FEPS : colv[mj];
+        mi_term = -(double)(Mc * (logf(Mc) - a.mi_lamb * logf(Rc) - a.mi_lamb * logf(Cc)));
+    }
+    double mi_loss = block_sum(mi_term, sh);
+    __syncthreads();
+    if (threadIdx.x < K * K) Pm[mi * 16 + mj] = Mc;   // clamped matrix
+    __syncthreads();
+    if (threadIdx.x < K * K) {
+        float g = 0.f;
+        if (mp >= FEPS) g += -(logf(Mc) - a.mi_lamb * logf(Rc) - a.mi_lamb * logf(Cc)) - 1.f;
+        if (rowv[mi] >= FEPS) { float s = 0.f; for (int k = 0; k < K; k++) s += Pm[mi * 16 + k]; g += a.mi_lamb * s / Rc; }
+        if (colv[mj] >= FEPS) { float s = 0.f; for (int k = 0; k < K; k++) s += Pm[k * 16 + mj]; g += a.mi_lamb * s / Cc; }
+        Gm[mi * 16 + mj] = g * (a.ema ? a.ema_alpha : 1.f) * a.w_mi;     // d total / d m
+    }
+    __syncthreads();
+    // m = sym / S : g_sym = g_m / S - sum(g_m * sym) / S^2   (sym recomputed from P kept in registers: sym)
+    double gs = block_sum(threadIdx.x < K * K ? (double)Gm[mi * 16 + mj] * sym : 0.0, sh);
+    __syncthreads();
+    float gsym = 0.f;
+    if (threadIdx.x < K * K) gsym = Gm[mi * 16 + mj] / Ssum - (float)gs / (Ssum * Ssum);
+    __syncthreads();
+    if (threadIdx.x < K * K) Pm[mi * 16 + mj] = gsym;
+    __syncthreads();
+    if (threadIdx.x < K * K) Gm[mi * 16 + mj] = 0.5f * (Pm[mi * 16 + mj] + Pm[mj * 16 + mi]);   // g_P
+    __syncthreads();
+    // per-sample terms
+    double ent = 0.0, kl = 0.0;
+    for (int n = threadIdx.x; n < NS; n += blockDim.x) {
+        const float* pp = a.p + n * K; const float* qq = a.q + n * K; const float* lp = a.logp + n * K;
+        float gp[16], gq[16], dotp = 0.f, dotq = 0.f, h = 0.f;
+        for (int i = 0; i < K; i++) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = 0; j < K; j++) { s1 += Gm[i * 16 + j] * qq[j]; s2 += Gm[j * 16 + i] * pp[j]; }
+            gp[i] = s1; gq[i] = s2; dotp += pp[i] * s1; dotq += qq[i] * s2; h += pp[i] * lp[i];
+        }
+        ent += -(double)h;
+        for (int i = 0; i < K; i++) {
+            float ge = -(a.w_entropy / NS) * pp[i] * (lp[i] - h);
+            a.d_logits[n * K + i] += pp[i] * (gp[i] - dotp) + ge;
+            a.d_logits_r[n * K + i] += qq[i] * (gq[i] - dotq);
+        }
+        for (int d = 0; d < Da; d++) {
+            float mu = a.ddist[(long)n * 2 * Da + d], var = a.ddist[(long)n * 2 * Da + Da + d];
+            kl += (double)(1.f + logf(var) - mu * mu - var);
+            a.d_ddist[(long)n * 2 * Da + d] += a.w_dirkl * mu / NS;
+            a.d_ddist[(long)n * 2 * Da + Da + d] += a.w_dirkl * (-0.5f) * (1.f / var - 1.f) / NS;
+        }
+    }
+    double skl = 0.0;
+    for (int n = threadIdx.x; n < NT; n += blockDim.x) {
+        for (int d = 0; d < Da; d++) {
+            float mu = a.sdist_r[(long)n * 2 * Da + d], var = a.sdist_r[(long)n * 2 * Da + Da + d];
+            float rmu = a.sdist[(long)n * 2 * Da + d], rvar = a.sdist[(long)n * 2 * Da + Da + d];
+            float lv = logf(var), rlv = logf(rvar);
+            float cv = fmaxf(var, 0.05f), crv = fmaxf(rvar, 0.05f);
+            skl += (double)(rlv - lv - 1.f + cv / crv + (rmu - mu) * (rmu - mu) / crv);
+            a.d_sdist_r[(long)n * 2 * Da + d] += a.w_statekl * (mu - rmu) / crv / NT;
+        }
+    }
+    ent = block_sum(ent, sh); __syncthreads();
+    kl = block_sum(kl, sh); __syncthreads();
+    skl = block_sum(skl, sh);
+    if (threadIdx.x == 0) {
+        a.acc[LOSS_ENTROPY] = ent / NS;
+        a.acc[LOSS_DIRKL] = -0.5 * kl / NS;
+        a.acc[LOSS_MI] = mi_loss;
+        a.acc[LOSS_STATEKL] = 0.5 * skl / NT;
+    }
+}
+__global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1, double n2, double nstates, double nhidden) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double r0 = acc[LOSS_L1_R0] / n0, r1 = acc[LOSS_L1_R1] / n1, r2 = acc[LOSS_L1_R2] / n2;
+    acc[LOSS_L1_R0] = r0; acc[LOSS_L1_R1] = r1; acc[LOSS_L1_R2] = r2;
+    acc[LOSS_REC] = (r0 + r1 + r2) / 3.0;
+    acc[LOSS_STATES] = acc[LOSS_STATES] / nstates;
+    acc[LOSS_HIDDEN] = nhidden > 0 ? acc[LOSS_HIDDEN] / nhidden : 0.0;
+    acc[LOSS_TOTAL] = w.rec * acc[LOSS_REC] + w.states * acc[LOSS_STATES] + w.entropy * acc[LOSS_ENTROPY] + w.dir_kl * acc[LOSS_DIRKL] +
+                      w.mi * acc[LOSS_MI] + w.state_kl * acc[LOSS_STATEKL] + w.hidden * acc[LOSS_HIDDEN];
+}
+__global__ void k_softmax_rows(const float* logits, float* prob, float* logp, int NS, int K) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NS) return;
+    const float* l = logits + n * K;
+    float mx = l[0];
+    for (int k = 1; k < K; k++) mx = fmaxf(mx, l[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; k++) se += expf(l[k] - mx);
+    float lse = mx + logf(se);
+    for (int k = 0; k < K; k++) { if (logp) logp[n * K + k] = l[k] - lse; prob[n * K + k] = expf(l[k] - lse); }
+}
+}  // namespace
+
+int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st) {
+    hipLaunchKernelGGL(k_softmax_rows, dim3(cdiv(NS, 64)), dim3(64), 0, st, logits, prob, logp, NS, K);
+    return 0;
+}
+int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st) {
+    hipLaunchKernelGGL(k_head_fc, dim3(cdiv((long)B * T * p.Da, 128)), dim3(128), 0, st, h, p, B * T);
+    hipLaunchKernelGGL(k_head_dirs, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, B, T);
+    return 0;
+}
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, hipStream_t st) {
+    if (p.K > 16 || p.Da > 8 || p.K + p.Da > AUX_LD) return -1;
+    hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c, NS);
+    return 0;
+}
+int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {
+    hipLaunchKernelGGL(k_head_bwd1, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, c, B * (T - 1), first_call);
+    hipLaunchKernelGGL(k_head_bwd2, dim3(cdiv((long)B * T, 64)), dim3(64), 0, st, h, p, B, T);
+    return 0;
+}
+int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st) {
+    long npix = (long)rec.N * rec.H * rec.W;
+    long blocks = (npix + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_loss_l1, dim3((unsigned)blocks), dim3(256), 0, st, gt, rec, drec, f, t_off, Tobs, Trec, gscale, acc);
+    return 0;
+}
+int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st) {
+    long items = (long)a.N * a.H * a.W * a.C;
+    long blocks = (items + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_loss_mse, dim3((unsigned)blocks), dim3(256), 0, st, a, b, db, gscale, acc);
+    return 0;
+}
+int loss_small(const SmallLossArgs& a, hipStream_t st) {
+    if (a.K > 16 || a.Da > 8) return -1;
+    hipLaunchKernelGGL(k_loss_small, dim3(1), dim3(256), 0, st, a);
+    return 0;
+}
+int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden);
+    return 0;
+}

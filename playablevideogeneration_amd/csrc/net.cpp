@@ -1,0 +1,738 @@
+// Driver of the CADDY hot path: parameter table, layer construction, E / R / D / A graphs, tape-based BPTT.
+// Reference behaviour: model/main_model/model.py (forward_full_model :84-286, generate_next :570-607) and the
+// reduced variant (model/reduced_model/rendering_network.py:30-42).  All device work goes through the kernels of
+// conv_mfma.hip / pointwise.hip / head.hip / pack.hip on one HIP stream; nothing here allocates device memory.
+#include "net.h"
+#include <cstdio>
+#include <cstring>
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+extern "C" const char* caddy_last_error(void) { return g_err.c_str(); }
+
+#define RUN(expr) do { if (!dry) ck((expr), #expr); } while (0)
+
+void caddy_ctx::ck(int rc, const char* what) {
+    if (rc != 0 && !fail) { fail = true; set_error(std::string("kernel launch failed: ") + what); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// parameter table (names = reference state_dict keys; see oracle/caddy_oracle.py param_table for the same list)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct TB {
+    std::vector<ParamEntry>& t;
+    void add(const std::string& n, std::initializer_list<int> shp, int kind) {
+        ParamEntry e; e.name = n; e.ndim = (int)shp.size(); e.kind = kind; e.numel = 1; e.offset = -1;
+        int i = 0; for (int s : shp) { e.shape[i++] = s; e.numel *= s; }
+        for (; i < 4; i++) e.shape[i] = 1;
+        t.push_back(e);
+    }
+    void bn(const std::string& p, int c) { add(p + ".weight", {c}, 0); add(p + ".bias", {c}, 0); add(p + ".running_mean", {c}, 1); add(p + ".running_var", {c}, 1); }
+    void res(const std::string& p, int cin, int cout, int ds) {
+        add(p + ".conv1.weight", {cout, cin, 3, 3}, 0); bn(p + ".bn1", cout);
+        add(p + ".conv2.weight", {cout, cout, 3, 3}, 0); bn(p + ".bn2", cout);
+        if (ds != 1 || cin != cout) { add(p + ".downsample.0.weight", {cout, cin, 1, 1}, 0); bn(p + ".downsample.2", cout); }
+    }
+};
+const int E_BLOCKS[6][3] = {{16, 16, 1}, {16, 32, 2}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}, {64, 65, 1}};  // representation_network.py:22-29
+void dec_widths(const caddy_config& c, int w[4]) {
+    if (c.variant == 0) { w[0] = 128; w[1] = 128; w[2] = 64; w[3] = 32; } else { w[0] = 64; w[1] = 64; w[2] = 32; w[3] = 16; }
+}
+}  // namespace
+
+void build_param_table(const caddy_config& c, std::vector<ParamEntry>& t, long* n_floats, long* n_train) {
+    t.clear();
+    TB b{t};
+    const int Cs = 64, aux = c.actions + c.action_dim, Ch = c.hidden, hs = c.height / 8, ws = c.width / 8;
+    b.add("state_to_hidden_state_layer.0.weight", {Ch, Cs, 3, 3}, 0); b.add("state_to_hidden_state_layer.0.bias", {Ch}, 0);
+    std::string p = "action_network.0";
+    b.res(p + ".residuals.0", Cs, 2 * Cs, 2); b.res(p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
+    b.add(p + ".mean_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".mean_fc.bias", {c.action_dim}, 0);
+    b.add(p + ".variance_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".variance_fc.bias", {c.action_dim}, 0);
+    b.add(p + ".final_fc.weight", {c.actions, c.action_dim}, 0); b.add(p + ".final_fc.bias", {c.actions}, 0);
+    const int lc[3][2] = {{Cs + aux, Ch}, {2 * Ch + aux, 2 * Ch}, {Ch + aux, Ch}};
+    for (int i = 0; i < 3; i++) {
+        std::string q = "dynamics_network.recurrent_layers_blocks." + std::to_string(i);
+        int hh = i == 1 ? hs / 2 : hs, ww = i == 1 ? ws / 2 : ws, co = lc[i][1], ci = lc[i][0];
+        b.add(q + ".0.initial_hidden_state", {co, hh, ww}, 0); b.add(q + ".0.initial_hidden_cell_state", {co, hh, ww}, 0);
+        const char* gn[4] = {"input_gate", "forget_gate", "output_gate", "cell_gate"};
+        for (int g = 0; g < 4; g++) b.add(q + ".0.cell." + gn[g] + ".weight", {co, ci + co, 3, 3}, 0);
+        for (int g = 0; g < 4; g++) b.add(q + ".0.cell." + gn[g] + ".bias", {co}, 0);    // contiguous: one packed bias [i|f|o|g]
+        b.bn(q + ".1", co);
+    }
+    std::string q = "dynamics_network.non_recurrent_blocks";
+    b.add(q + ".0.conv1.weight", {2 * Ch, Ch + aux, 3, 3}, 0); b.bn(q + ".0.bn1", 2 * Ch);
+    b.add(q + ".1.conv.weight", {Ch, 2 * Ch + aux, 3, 3}, 0); b.bn(q + ".1.norm", Ch);
+    b.add(q + ".2.conv1.weight", {Ch, Ch + aux, 3, 3}, 0); b.bn(q + ".2.bn1", Ch);
+    q = "representation_network";
+    b.add(q + ".conv1.weight", {16, 3 * c.stacking, 3, 3}, 0); b.bn(q + ".bn1", 16);
+    for (int i = 0; i < 6; i++) b.res(q + ".residuals." + std::to_string(i), E_BLOCKS[i][0], E_BLOCKS[i][1], E_BLOCKS[i][2]);
+    int w[4]; dec_widths(c, w);
+    q = "rendering_network";
+    b.add(q + ".upsample_blocks.0.0.conv.weight", {w[1], w[0], 3, 3}, 0); b.bn(q + ".upsample_blocks.0.0.norm", w[1]);
+    b.res(q + ".upsample_blocks.0.1", w[1], w[1], 1);
+    b.add(q + ".upsample_blocks.1.0.conv.weight", {w[2], w[1], 3, 3}, 0); b.bn(q + ".upsample_blocks.1.0.norm", w[2]);
+    b.res(q + ".upsample_blocks.1.1", w[2], w[2], 1);
+    b.add(q + ".upsample_blocks.2.conv.weight", {w[3], w[2], 3, 3}, 0); b.bn(q + ".upsample_blocks.2.norm", w[3]);
+    for (int i = 0; i < 3; i++) {
+        int ks = i == 2 ? 7 : 3;
+        b.add(q + ".final_blocks." + std::to_string(i) + ".conv.weight", {3, w[i + 1], ks, ks}, 0);
+        b.add(q + ".final_blocks." + std::to_string(i) + ".conv.bias", {3}, 0);
+    }
+    b.add("centroid_estimator.estimated_centroids", {c.actions, c.action_dim}, 2);
+    long off = 0;
+    for (int kind : {0, 2, 1}) {
+        for (auto& e : t) if (e.kind == kind) { e.offset = off; off += (e.numel + 3) / 4 * 4; }
+        if (kind == 0) *n_train = off;
+    }
+    *n_floats = off;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+const ParamEntry& find(caddy_ctx* c, const std::string& n) {
+    for (auto& e : c->table) if (e.name == n) return e;
+    set_error("unknown parameter " + n); c->fail = true;
+    return c->table[0];
+}
+float* PP(caddy_ctx* c, const std::string& n) { return c->P + find(c, n).offset; }
+float* GP(caddy_ctx* c, const std::string& n) { return c->G + find(c, n).offset; }
+
+void make_conv(caddy_ctx* c, ConvL& L, const std::vector<std::string>& wn, const std::string& bias, int KS, const std::vector<int>& segC) {
+    const ParamEntry& e0 = find(c, wn[0]);
+    PackDesc& d = L.pd;
+    d.nw = (int)wn.size(); d.Co_each = e0.shape[0]; d.Cin = e0.shape[1]; d.KS = KS; d.nseg = (int)segC.size();
+    int off = 0, kt = 0;
+    for (int s = 0; s < d.nseg; s++) { d.seg_off[s] = off; d.seg_C[s] = segC[s]; d.seg_Cpad[s] = round_up(segC[s], CONV_BK); off += segC[s]; kt += d.seg_Cpad[s]; }
+    if (off != d.Cin) { set_error("segment mismatch for " + wn[0]); c->fail = true; }
+    for (int i = 0; i < d.nw; i++) { d.w[i] = PP(c, wn[i]); d.gw[i] = GP(c, wn[i]); }
+    d.Cout = d.nw * d.Co_each; d.Cout_pad = round_up(d.Cout, conv_pick_bn(d.Cout)); d.Ktot = kt;
+    L.wp_floats = (size_t)KS * KS * d.Cout_pad * d.Ktot;
+    L.wp = (float*)c->persist.alloc(L.wp_floats * 4);
+    L.dwp = (float*)c->persist.alloc(L.wp_floats * 4);
+    L.kd = round_up(d.Cout, CONV_BK);
+    for (int s = 0; s < d.nseg; s++) {
+        L.cd_pad[s] = round_up(segC[s], conv_pick_bn(segC[s]));
+        L.wpd[s] = (float*)c->persist.alloc((size_t)KS * KS * L.cd_pad[s] * L.kd * 4);
+    }
+    if (!bias.empty()) { L.bias = PP(c, bias); L.dbias = GP(c, bias); }
+    c->convs.push_back(&L);
+}
+void make_bn(caddy_ctx* c, BNL& b, const std::string& p) {
+    const ParamEntry& e = find(c, p + ".weight");
+    b.name = p; b.C = e.shape[0];
+    b.gamma = PP(c, p + ".weight"); b.beta = PP(c, p + ".bias"); b.dgamma = GP(c, p + ".weight"); b.dbeta = GP(c, p + ".bias");
+    b.rmean = PP(c, p + ".running_mean"); b.rvar = PP(c, p + ".running_var");
+    c->bns.push_back(&b);
+}
+void make_res(caddy_ctx* c, ResL& R, const std::string& p, int cin, int cout, int ds) {
+    R.ds = ds;
+    make_conv(c, R.conv1, {p + ".conv1.weight"}, "", 3, {cin}); make_bn(c, R.bn1, p + ".bn1");
+    make_conv(c, R.conv2, {p + ".conv2.weight"}, "", 3, {cout}); make_bn(c, R.bn2, p + ".bn2");
+    R.has_down = ds != 1 || cin != cout;
+    if (R.has_down) { make_conv(c, R.down, {p + ".downsample.0.weight"}, "", 1, {cin}); make_bn(c, R.bnd, p + ".downsample.2"); }
+}
+T4 palloc(caddy_ctx* c, int N, int H, int W, int C) {   // persistent tensor with its own gradient buffer
+    int ld = round_up(C, 4);
+    size_t n = (size_t)N * H * W * ld * 4;
+    T4 t; t.d = (float*)c->persist.alloc(n); t.g = (float*)c->persist.alloc(n);
+    t.N = N; t.H = H; t.W = W; t.C = C; t.sn = (long)H * W * ld; t.ld = ld;
+    return t;
+}
+void build_layers(caddy_ctx* c) {
+    const caddy_config& g = c->cfg;
+    const int Cs = 64, aux = g.actions + g.action_dim, Ch = g.hidden;
+    c->hs = g.height / 8; c->ws = g.width / 8;
+    make_conv(c, c->s2h, {"state_to_hidden_state_layer.0.weight"}, "state_to_hidden_state_layer.0.bias", 3, {Cs});
+    std::string p = "action_network.0";
+    make_res(c, c->a_res[0], p + ".residuals.0", Cs, 2 * Cs, 2); make_res(c, c->a_res[1], p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
+    HeadParams& h = c->hp;
+    h.F = 2 * Cs; h.Da = g.action_dim; h.K = g.actions;
+    h.Wm = PP(c, p + ".mean_fc.weight"); h.bm = PP(c, p + ".mean_fc.bias"); h.Wv = PP(c, p + ".variance_fc.weight"); h.bv = PP(c, p + ".variance_fc.bias");
+    h.Wf = PP(c, p + ".final_fc.weight"); h.bf = PP(c, p + ".final_fc.bias");
+    h.dWm = GP(c, p + ".mean_fc.weight"); h.dbm = GP(c, p + ".mean_fc.bias"); h.dWv = GP(c, p + ".variance_fc.weight"); h.dbv = GP(c, p + ".variance_fc.bias");
+    h.dWf = GP(c, p + ".final_fc.weight"); h.dbf = GP(c, p + ".final_fc.bias");
+    const int lc[3][2] = {{Cs, Ch}, {2 * Ch, 2 * Ch}, {Ch, Ch}};
+    for (int i = 0; i < 3; i++) {
+        std::string q = "dynamics_network.recurrent_layers_blocks." + std::to_string(i);
+        LstmL& L = c->lstm[i];
+        L.C = lc[i][1]; L.Hs = i == 1 ? c->hs / 2 : c->hs; L.Ws = i == 1 ? c->ws / 2 : c->ws;
+        make_conv(c, L.gates, {q + ".0.cell.input_gate.weight", q + ".0.cell.forget_gate.weight", q + ".0.cell.output_gate.weight", q + ".0.cell.cell_gate.weight"},
+                  q + ".0.cell.input_gate.bias", 3, {lc[i][0], aux, L.C});
+        make_bn(c, L.bn, q + ".1");
+        L.init_h = PP(c, q + ".0.initial_hidden_state"); L.init_c = PP(c, q + ".0.initial_hidden_cell_state");
+        L.ginit_h = GP(c, q + ".0.initial_hidden_state"); L.ginit_c = GP(c, q + ".0.initial_hidden_cell_state");
+        L.ih = palloc(c, 1, L.Hs, L.Ws, L.C); L.ic = palloc(c, 1, L.Hs, L.Ws, L.C);
+        L.ph = palloc(c, g.batch, L.Hs, L.Ws, L.C); L.pc = palloc(c, g.batch, L.Hs, L.Ws, L.C);
+        L.h.d = nullptr; L.c.d = nullptr;
+    }
+    std::string q = "dynamics_network.non_recurrent_blocks";
+    make_conv(c, c->r_c0, {q + ".0.conv1.weight"}, "", 3, {Ch, aux}); make_bn(c, c->r_bn0, q + ".0.bn1");
+    make_conv(c, c->r_c1, {q + ".1.conv.weight"}, "", 3, {2 * Ch, aux}); make_bn(c, c->r_bn1, q + ".1.norm");
+    make_conv(c, c->r_c2, {q + ".2.conv1.weight"}, "", 3, {Ch, aux}); make_bn(c, c->r_bn2, q + ".2.bn1");
+    q = "representation_network";
+    make_conv(c, c->e_stem, {q + ".conv1.weight"}, "", 3, {3 * g.stacking}); make_bn(c, c->e_bn1, q + ".bn1");
+    for (int i = 0; i < 6; i++) make_res(c, c->e_res[i], q + ".residuals." + std::to_string(i), E_BLOCKS[i][0], E_BLOCKS[i][1], E_BLOCKS[i][2]);
+    int w[4]; dec_widths(g, w);
+    q = "rendering_network";
+    for (int i = 0; i < 3; i++) {
+        std::string u = q + ".upsample_blocks." + std::to_string(i) + (i < 2 ? ".0" : "");
+        make_conv(c, c->d_up[i], {u + ".conv.weight"}, "", 3, {w[i]}); make_bn(c, c->d_norm[i], u + ".norm");
+        if (i < 2) make_res(c, c->d_res[i], q + ".upsample_blocks." + std::to_string(i) + ".1", w[i + 1], w[i + 1], 1);
+        std::string f = q + ".final_blocks." + std::to_string(i) + ".conv";
+        make_conv(c, c->d_final[i], {f + ".weight"}, f + ".bias", i == 2 ? 7 : 3, {w[i + 1]});
+    }
+    c->centroids = PP(c, "centroid_estimator.estimated_centroids");
+    c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ops
+// ---------------------------------------------------------------------------------------------------------------------
+T4 caddy_ctx::alloc(int N, int H, int W, int C, int ld) {
+    if (!ld) ld = round_up(C, 4);
+    float* d = (float*)act.alloc((size_t)N * H * W * ld * 4);
+    T4 t{d, (float*)((char*)d + grad_delta), N, H, W, C, (long)H * W * ld, ld};
+    dbg.push_back(t);
+    return t;
+}
+float* caddy_ctx::falloc(size_t n) { return (float*)act.alloc(n * 4); }
+double* caddy_ctx::dalloc(size_t n) { return (double*)act.alloc(n * 8); }
+static inline float* tw(caddy_ctx* c, float* p) { return (float*)((char*)p + c->grad_delta); }
+static inline T4 tslice(const T4& bt, int B, int T, int t) { T4 r = bt; r.d = bt.d + (long)t * bt.sn; r.g = bt.g + (long)t * bt.sn; r.N = B; r.sn = (long)T * bt.sn; return r; }
+static inline T4 chan(const T4& t, int c0, int C) { T4 r = t; r.d += c0; r.g += c0; r.C = C; return r; }
+
+static void fill_srcs(ConvSrc* dst, const Seg* segs, int nseg) {
+    for (int s = 0; s < nseg; s++) {
+        const T4& t = segs[s].t;
+        dst[s] = ConvSrc{t.d, t.sn, t.ld, t.C, round_up(t.C, CONV_BK), segs[s].bcast};
+    }
+}
+
+T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into) {
+    int N = 0, H = 0, W = 0;
+    for (int s = 0; s < nseg; s++) if (!segs[s].bcast) { N = segs[s].t.N; H = segs[s].t.H; W = segs[s].t.W; break; }
+    T4 out = into ? *into : alloc(N, H, W, L.pd.Cout);
+    ConvArgs a{};
+    fill_srcs(a.src, segs, nseg);
+    a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
+    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0;
+    RUN(conv_fwd_launch(a, stream));
+    if (recording) {
+        T4 dz{}; if (actf == 1) dz = alloc(N, H, W, L.pd.Cout);
+        Seg sg[CONV_MAX_SRC]; T4 tmp[CONV_MAX_SRC];
+        for (int s = 0; s < nseg; s++) { sg[s] = segs[s]; if (segs[s].bcast && segs[s].need_grad) tmp[s] = alloc(N, H, W, segs[s].t.C); }
+        ConvL* Lp = &L;
+        tape.push_back([=]() {
+            TV dzv = gv(out);
+            if (actf == 1) { RUN(pw_tanh_bwd(gv(out), dv(out), dv(dz), stream)); dzv = dv(dz); }
+            WgradArgs w{};
+            fill_srcs(w.src, sg, nseg);
+            w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
+            w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
+            RUN(conv_wgrad_launch(w, stream));
+            if (Lp->dbias) RUN(pw_colsum(dzv, Lp->dbias, stream));
+            for (int s = 0; s < nseg; s++) {
+                if (!sg[s].need_grad) continue;
+                ConvArgs d{};
+                d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
+                d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
+                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0;
+                if (!sg[s].bcast) { d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = 1; RUN(conv_fwd_launch(d, stream)); }
+                else {
+                    d.out = tmp[s].d; d.out_sn = tmp[s].sn; d.out_ld = tmp[s].ld; d.accumulate = 0;
+                    RUN(conv_fwd_launch(d, stream));
+                    RUN(pw_spatial_sum(dv(tmp[s]), sg[s].t.g, sg[s].t.sn, stream));
+                }
+            }
+        });
+    }
+    return out;
+}
+
+T4 caddy_ctx::pool2(const T4& x) {
+    T4 o = alloc(x.N, x.H / 2, x.W / 2, x.C);
+    RUN(pw_pool2(dv(x), dv(o), stream));
+    if (recording) tape.push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), stream)); });
+    return o;
+}
+T4 caddy_ctx::up2(const T4& x) {
+    T4 o = alloc(x.N, x.H * 2, x.W * 2, x.C);
+    RUN(pw_up2(dv(x), dv(o), stream));
+    if (recording) tape.push_back([=]() { RUN(pw_up2_bwd(gv(o), gv(x), stream)); });
+    return o;
+}
+
+struct BNStash { float *mean, *invstd, *scale, *shift; double* sums; };
+static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
+    BNStash s; float* f = c->falloc(4 * (size_t)round_up(bn.C, 4));
+    int cp = round_up(bn.C, 4);
+    c->dbg.push_back(T4{f, f, 1, 1, 1, 4 * cp, 4 * cp, 4 * cp});
+    s.mean = f; s.invstd = f + cp; s.scale = f + 2 * cp; s.shift = f + 3 * cp; s.sums = c->dalloc(2 * (size_t)bn.C);
+    bool dry = c->dry;
+    if (c->training) {
+        if (!dry) hipMemsetAsync(s.sums, 0, sizeof(double) * 2 * bn.C, c->stream);
+        if (!dry) c->ck(pw_stats(dv(x), s.sums, c->stream), "pw_stats");
+        if (!dry) bn.calls++;
+    }
+    if (!dry) c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, c->training ? 1 : 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
+    return s;
+}
+T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into) {
+    T4 out = into ? *into : alloc(x.N, x.H, x.W, x.C);
+    BNStash s1 = bn_forward(this, x, bn), s2{};
+    if (x2 && bn2) s2 = bn_forward(this, *x2, *bn2);
+    TV x2v{}; if (x2) x2v = dv(*x2);
+    RUN(pw_bn_apply(dv(x), s1.scale, s1.shift, x2 ? &x2v : nullptr, bn2 ? s2.scale : nullptr, bn2 ? s2.shift : nullptr, actf ? 1 : 0, dv(out), stream));
+    if (recording) {
+        T4 x2c{}; if (x2) x2c = *x2;
+        bool has2 = x2 != nullptr; BNL* b1 = &bn; BNL* b2 = bn2;
+        tape.push_back([=]() {
+            TV om = dv(out);
+            const TV* omp = actf ? &om : nullptr;
+            if (!dry) hipMemsetAsync(s1.sums, 0, sizeof(double) * 2 * b1->C, stream);
+            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, stream));
+            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), b1->dgamma, b1->dbeta, stream));
+            if (has2 && b2) {
+                if (!dry) hipMemsetAsync(s2.sums, 0, sizeof(double) * 2 * b2->C, stream);
+                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, stream));
+                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), b2->dgamma, b2->dbeta, stream));
+            } else if (has2) {
+                if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream));
+                else RUN(pw_copy(gv(out), gv(x2c), 1, stream));
+            }
+        });
+    }
+    return out;
+}
+
+// ResidualBlock (model/layers/residual_block.py:51-68)
+T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
+    Seg sx{x, 0, true};
+    T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr);
+    if (R.ds == 2) c1 = pool2(c1);
+    T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr);
+    Seg sa{a1, 0, true};
+    T4 c2 = conv(R.conv2, &sa, 1, 0, nullptr);
+    if (R.has_down) {
+        T4 idn = conv(R.down, &sx, 1, 0, nullptr);
+        if (R.ds == 2) idn = pool2(idn);
+        return bn_act(c2, R.bn2, &idn, &R.bnd, true, into);
+    }
+    return bn_act(c2, R.bn2, &x, nullptr, true, into);
+}
+
+// RepresentationNetwork.forward (model/main_model/representation_network.py:32-58); output keeps the 65th (attention) channel
+T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
+    Seg so{obs_in, 0, input_grad};
+    T4 x = conv(e_stem, &so, 1, 0, nullptr);
+    x = pool2(x);
+    x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr);
+    for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr);
+    T4 dst = into ? *into : alloc(x.N, hs, ws, 65, 68);
+    return resblock(e_res[5], x, &dst);
+}
+
+void caddy_ctx::copy_op(const T4& src, const T4& dst) {
+    RUN(pw_copy(dv(src), dv(dst), 0, stream));
+    if (recording) tape.push_back([=]() { RUN(pw_copy(gv(dst), gv(src), 1, stream)); });
+}
+
+// ConvLSTM step (convolutional_lstm.py:50-74, convolutional_lstm_cell.py:88-101) followed by its BatchNorm
+T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
+    LstmL& L = lstm[i];
+    const int B = x.N;
+    bool persistent = !training && !recording && L.h.d == L.ph.d && L.h.d != nullptr;
+    T4 hprev, cprev;
+    if (L.h.d == nullptr) {   // lazily created from the learned initial state, repeated over the batch
+        hprev = alloc(B, L.Hs, L.Ws, L.C); cprev = alloc(B, L.Hs, L.Ws, L.C);
+        T4 ih = L.ih, ic = L.ic; ih.sn = 0; ic.sn = 0; ih.N = B; ic.N = B;
+        RUN(pw_copy(dv(ih), dv(hprev), 0, stream)); RUN(pw_copy(dv(ic), dv(cprev), 0, stream));
+        if (recording) {
+            T4 ihg = L.ih, icg = L.ic;
+            tape.push_back([=]() {
+                RUN(pw_batch_sum(hprev.g, hprev.sn, hprev.sn, B, ihg.g, stream));
+                RUN(pw_batch_sum(cprev.g, cprev.sn, cprev.sn, B, icg.g, stream));
+            });
+        }
+    } else { hprev = L.h; cprev = L.c; }
+    Seg sg[3] = {{x, 0, true}, {aux, 1, true}, {hprev, 0, true}};
+    T4 gates = conv(L.gates, sg, 3, 0, nullptr);
+    T4 hn, cn;
+    if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
+    RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
+    if (recording) tape.push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
+    L.h = hn; L.c = cn;
+    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr);
+}
+
+// ConvDynamicsNetwork.forward (model/main_model/conv_dynamics_network.py:111-133)
+T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
+    T4 x = lstm_step(0, state, aux);
+    Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
+    x = conv(r_c0, s0, 2, 0, nullptr);
+    x = pool2(x);
+    x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr);
+    x = lstm_step(1, x, aux);
+    Seg s1[2] = {{x, 0, true}, {aux, 1, true}};
+    x = conv(r_c1, s1, 2, 0, nullptr);
+    x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr);
+    x = up2(x);
+    x = lstm_step(2, x, aux);
+    Seg s2[2] = {{x, 0, true}, {aux, 1, true}};
+    x = conv(r_c2, s2, 2, 0, nullptr);
+    return bn_act(x, r_bn2, nullptr, nullptr, true, into);
+}
+
+// RenderingNetwork.forward (model/main_model/rendering_network.py:52-71): three upsampling stages, each with a tanh head
+void caddy_ctx::render(const T4& hdn, int slot, int nslots) {
+    T4 x = hdn;
+    const int B = hdn.N;
+    for (int i = 0; i < 3; i++) {
+        T4 u = up2(x);
+        Seg su{u, 0, true};
+        T4 c = conv(d_up[i], &su, 1, 0, nullptr);
+        x = bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr);
+        if (i < 2) x = resblock(d_res[i], x, nullptr);
+        T4 dst = tslice(frames[2 - i], B, nslots, slot);
+        Seg sx{x, 0, true};
+        conv(d_final[i], &sx, 1, 1, &dst);
+    }
+}
+
+// ActionNetwork.forward (model/main_model/action_network.py:62-118) + sampling (model.py:166-201) for the first call
+void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, const float* eps_d, const float* unif, bool first,
+                           const float* samples_in, const float* variations_in) {
+    const int B = cfg.batch, T = cfg.seq_len, K = cfg.actions, Da = cfg.action_dim, NT = B * T, NS = B * (T - 1);
+    H.x65 = x65;
+    T4 st = alloc(NT, hs, ws, 64);
+    H.att = alloc(NT, hs, ws, 1);
+    RUN(pw_attn_mul(dv(x65), dv(st), dv(H.att), stream));
+    if (recording) { T4 att = H.att; tape.push_back([=]() { TV none{}; (void)att; RUN(pw_attn_mul_bwd(dv(x65), gv(st), none, gv(x65), stream)); }); }
+    T4 r = resblock(a_res[0], st, nullptr);
+    r = resblock(a_res[1], r, nullptr);
+    HeadBufs& b = H.b;
+    float* feat = falloc((size_t)NT * hp.F);
+    RUN(pw_gap(dv(r), feat, stream));
+    b.feat = feat; b.d_feat = tw(this, feat);
+    if (recording) { float* df = b.d_feat; tape.push_back([=]() { RUN(pw_gap_bwd(df, gv(r), stream)); }); }
+    b.eps_s = eps_s; b.eps_d = eps_d; b.unif = unif;
+    b.mu = falloc((size_t)NT * Da); b.raw = falloc((size_t)NT * Da);
+    b.sdist = falloc((size_t)NT * 2 * Da); b.ssamp = falloc((size_t)NT * Da);
+    b.ddist = falloc((size_t)NS * 2 * Da); b.dirs = falloc((size_t)NS * Da);
+    b.logits = falloc((size_t)NS * K); b.logp = falloc((size_t)NS * K); b.prob = falloc((size_t)NS * K);
+    b.ysoft = falloc((size_t)NS * K); b.samples = falloc((size_t)NS * K); b.variations = falloc((size_t)NS * Da);
+    b.aux = falloc((size_t)NS * AUX_LD); b.cen_used = falloc(16 * 8);
+    b.selected = (long long*)act.alloc(sizeof(long long) * NS);
+    b.g_dmu = falloc((size_t)NS * Da); b.g_dvar = falloc((size_t)NS * Da);
+    b.d_logits = tw(this, b.logits); b.d_ddist = tw(this, b.ddist); b.d_sdist = tw(this, b.sdist); b.d_aux = tw(this, b.aux);
+    RUN(head_forward(b, hp, B, T, stream));
+    SampleCfg& sc = H.sc;
+    sc = SampleCfg{};
+    sc.mode = samples_in ? 2 : (cfg.use_gumbel ? 1 : 0); sc.hard = cfg.hard_gumbel; sc.training = training ? 1 : 0; sc.use_variations = cfg.use_variations;
+    sc.tau = tau; sc.alpha = cfg.centroid_alpha; sc.centroids = centroids; sc.samples_in = samples_in; sc.variations_in = variations_in;
+    if (first) RUN(head_sample(b, hp, sc, NS, stream));
+    if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tape.push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
+}
+
+void caddy_ctx::pack_all() {
+    for (ConvL* L : convs) {
+        RUN(pack_fwd(L->pd, L->wp, stream));
+        for (int s = 0; s < L->pd.nseg; s++) RUN(pack_dgrad(L->pd, s, L->wpd[s], L->cd_pad[s], L->kd, stream));
+    }
+    for (int i = 0; i < 3; i++) {   // learned initial LSTM states: (C,h,w) -> (1,h,w,C)
+        RUN(pw_nchw_to_nhwc(lstm[i].init_h, 0, dv(lstm[i].ih), stream));
+        RUN(pw_nchw_to_nhwc(lstm[i].init_c, 0, dv(lstm[i].ic), stream));
+    }
+}
+void caddy_ctx::unpack_all() {
+    for (ConvL* L : convs) RUN(unpack_wgrad(L->pd, L->dwp, stream));
+    for (int i = 0; i < 3; i++) {
+        RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, stream));
+        RUN(pw_nhwc_to_nchw(gv(lstm[i].ic), lstm[i].ginit_c, 0, 0, stream));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward_full_model (model/main_model/model.py:84-286)
+// ---------------------------------------------------------------------------------------------------------------------
+static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, const caddy_noise* nz, int training,
+                        const float* samples_in, const float* variations_in) {
+    const caddy_config& g = c->cfg;
+    const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
+    bool dry = c->dry;
+    if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
+    c->act.reset(); c->tape.clear(); c->dbg.clear();
+    c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau;
+    for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
+    c->pack_all();
+    caddy_noise z{}; if (nz) z = *nz;
+    // observations -> NHWC
+    c->obs = c->alloc(B * T, H, W, 3 * S);
+    if (!dry) c->ck(pw_nchw_to_nhwc(obs, (long)3 * S * H * W, dv(c->obs), c->stream), "obs layout");
+    c->x65_gt = c->encode(c->obs, false, nullptr);
+    c->action_net(c->x65_gt, c->head1, z.eps_states, z.eps_dirs, z.gumbel_uniform, true, samples_in, variations_in);
+    c->rec_x65 = c->alloc(B * T, c->hs, c->ws, 65, 68);
+    c->hidden = c->alloc(B * (T - 1), c->hs, c->ws, g.hidden);
+    for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(B * (T - 1), H >> r, W >> r, 3);
+    for (int t = 0; t < gt_init && t < T; t++) c->copy_op(tslice(c->x65_gt, B, T, t), tslice(c->rec_x65, B, T, t));
+    T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
+    for (int t = 0; t < T - 1; t++) {
+        T4 state = chan(tslice(c->rec_x65, B, T, t), 0, 64);
+        T4 aux = tslice(aux_all, B, T - 1, t);
+        T4 hslot = tslice(c->hidden, B, T - 1, t);
+        T4 hdn = c->dynamics(state, aux, &hslot);
+        c->render(hdn, t, T - 1);
+        if (t + 1 >= gt_init) {   // feed the reconstruction back through E (model.py:249-258, compute_current_observation :499-543)
+            int idx = t + 1, start = idx - S + 1;
+            T4 fb;
+            if (S == 1) fb = tslice(c->frames[0], B, T - 1, t);
+            else {
+                fb = c->alloc(B, H, W, 3 * S);
+                int j = 0;
+                for (int f = idx; f >= (start > gt_init ? start : gt_init); f--, j++)
+                    c->copy_op(tslice(c->frames[0], B, T - 1, f - 1), chan(fb, 3 * j, 3));
+                if (start < gt_init) {
+                    int nch = (gt_init - start) * 3;
+                    T4 src = chan(tslice(c->obs, B, T, gt_init - 1), 0, nch);
+                    if (!dry) c->ck(pw_copy(dv(src), dv(chan(fb, 3 * j, nch)), 0, c->stream), "gt portion");
+                }
+            }
+            T4 dst = tslice(c->rec_x65, B, T, t + 1);
+            c->encode(fb, true, &dst);
+        }
+    }
+    c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
+    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions);
+    c->have_forward = true;
+    return c->fail ? -1 : 0;
+}
+
+static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_host) {
+    if (!c->have_forward || !c->recording) { set_error("caddy_loss_backward needs a preceding training-mode caddy_forward_full"); return -2; }
+    const caddy_config& g = c->cfg;
+    const int B = g.batch, T = g.seq_len, K = g.actions, Da = g.action_dim;
+    bool dry = c->dry;
+    hipStream_t st = c->stream;
+    if (!dry) {
+        hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);
+        hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
+        for (ConvL* L : c->convs) hipMemsetAsync(L->dwp, 0, L->wp_floats * 4, st);
+        for (int i = 0; i < 3; i++) { hipMemsetAsync(c->lstm[i].ih.g, 0, c->lstm[i].ih.sn * 4, st); hipMemsetAsync(c->lstm[i].ic.g, 0, c->lstm[i].ic.sn * 4, st); }
+        hipMemsetAsync(c->loss_acc, 0, sizeof(double) * LOSS_SLOTS, st);
+    }
+    LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda};
+    double nr[3];
+    for (int r = 0; r < 3; r++) {
+        const T4& f = c->frames[r];
+        nr[r] = (double)f.N * 3 * f.H * f.W;
+        if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, 1, T, T - 1, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, st), "loss_l1");
+    }
+    T4 sa = chan(c->x65_gt, 0, 64), sb = chan(c->rec_x65, 0, 64);
+    double nst = (double)sa.N * 64 * sa.H * sa.W;
+    if (!dry) c->ck(loss_mse(dv(sa), dv(sb), gv(sb), (float)(w.states / nst), c->loss_acc + LOSS_STATES, st), "loss_mse");
+    if (!dry) c->ck(head_softmax(c->head2.b.logits, c->q_prob, nullptr, B * (T - 1), K, st), "softmax");
+    SmallLossArgs a{};
+    a.K = K; a.Da = Da; a.NS = B * (T - 1); a.NT = B * T;
+    a.p = c->head1.b.prob; a.q = c->q_prob; a.logp = c->head1.b.logp;
+    a.ddist = c->head1.b.ddist; a.sdist = c->head1.b.sdist; a.sdist_r = c->head2.b.sdist;
+    a.d_logits = c->head1.b.d_logits; a.d_logits_r = c->head2.b.d_logits; a.d_ddist = c->head1.b.d_ddist; a.d_sdist_r = c->head2.b.d_sdist;
+    a.ema = lc->mi_ema; a.ema_alpha = lc->mi_ema_alpha; a.update_ema = lc->update_mi_ema;
+    a.mi_lamb = (float)w.mi_entropy_lambda; a.w_mi = (float)w.mi; a.w_entropy = (float)w.entropy; a.w_dirkl = (float)w.dir_kl; a.w_statekl = (float)w.state_kl;
+    a.acc = c->loss_acc;
+    if (!dry) c->ck(loss_small(a, st), "loss_small");
+    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, 0.0, st), "loss_finalize");
+    for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
+    c->unpack_all();
+    if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
+    return c->fail ? -1 : 0;
+}
+
+// Model.generate_next (model/main_model/model.py:570-607), batch 1, eval mode, persistent ConvLSTM state
+static int generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
+    const caddy_config& g = c->cfg;
+    const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
+    bool dry = c->dry;
+    if (action < 0 || action >= K) { set_error("action out of range"); return -2; }
+    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false;
+    T4 o = c->alloc(1, H, W, 3 * S);
+    if (!dry) c->ck(pw_nchw_to_nhwc(observation, 0, dv(o), c->stream), "obs layout");
+    T4 x65 = c->encode(o, false, nullptr);
+    float* aux = c->falloc(AUX_LD);
+    if (!dry) {
+        hipMemsetAsync(aux, 0, AUX_LD * 4, c->stream);
+        c->ck(pw_fill(TV{aux + action, 1, 1, 1, 1, 4, 4}, 1.f, c->stream), "one-hot action");
+        if (variation) hipMemcpyAsync(aux + K, variation, 4 * Da, hipMemcpyDeviceToDevice, c->stream);
+    }
+    T4 auxv{aux, aux, 1, 1, 1, K + Da, AUX_LD, AUX_LD};
+    T4 hdn = c->dynamics(chan(x65, 0, 64), auxv, nullptr);
+    for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(1, H >> r, W >> r, 3);
+    c->render(hdn, 0, 1);
+    if (!dry) {
+        c->ck(pw_nhwc_to_nchw(dv(c->frames[0]), frame_out, (long)3 * H * W, 0, c->stream), "frame out");
+        if (obs_out) {
+            hipMemcpyAsync(obs_out, frame_out, sizeof(float) * 3 * H * W, hipMemcpyDeviceToDevice, c->stream);
+            if (S > 1) hipMemcpyAsync(obs_out + 3 * H * W, observation, sizeof(float) * 3 * (S - 1) * H * W, hipMemcpyDeviceToDevice, c->stream);
+        }
+    }
+    return c->fail ? -1 : 0;
+}
+
+static int start_inference(caddy_ctx* c) {
+    bool dry = c->dry;
+    c->training = false; c->recording = false;
+    c->pack_all();
+    for (int i = 0; i < 3; i++) {
+        LstmL& L = c->lstm[i];
+        T4 ih = L.ih, ic = L.ic; ih.sn = 0; ic.sn = 0; ih.N = 1; ic.N = 1;
+        T4 ph = L.ph, pc = L.pc; ph.N = 1; pc.N = 1;
+        if (!dry) { c->ck(pw_copy(dv(ih), dv(ph), 0, c->stream), "init h"); c->ck(pw_copy(dv(ic), dv(pc), 0, c->stream), "init c"); }
+        L.h = L.ph; L.c = L.pc; L.h.N = 1; L.c.N = 1;
+    }
+    return c->fail ? -1 : 0;
+}
+
+static int get_output(caddy_ctx* c, int id, void* dst, bool grad) {
+    if (!c->have_forward) { set_error("no forward results available"); return -2; }
+    const caddy_config& g = c->cfg;
+    const int B = g.batch, T = g.seq_len, K = g.actions, Da = g.action_dim;
+    hipStream_t st = c->stream;
+    auto nchw = [&](const T4& t) { return pw_nhwc_to_nchw(grad ? gv(t) : dv(t), (float*)dst, (long)t.C * t.H * t.W, 0, st); };
+    auto raw = [&](const void* p, size_t bytes) { hipMemcpyAsync(dst, grad ? (const char*)p + c->grad_delta : (const char*)p, bytes, hipMemcpyDeviceToDevice, st); return 0; };
+    if (grad && (id == 5 || id == 7 || id == 11 || id == 13 || id == 14 || id == 17 || id == 19)) { set_error("no gradient is kept for this output"); return -2; }
+    const HeadBufs& a = c->head1.b; const HeadBufs& r = c->head2.b;
+    const size_t NS = (size_t)B * (T - 1), NT = (size_t)B * T;
+    switch (id) {
+        case 0: case 100: return nchw(c->frames[0]);
+        case 101: return nchw(c->frames[1]);
+        case 102: return nchw(c->frames[2]);
+        case 2: return nchw(chan(c->rec_x65, 0, 64));
+        case 3: return nchw(chan(c->x65_gt, 0, 64));
+        case 4: return nchw(c->hidden);
+        case 5: return raw(a.selected, NS * sizeof(long long));
+        case 6: return raw(a.logits, NS * K * 4);
+        case 7: return raw(a.samples, NS * K * 4);
+        case 8: return nchw(c->head1.att);
+        case 9: {   // attention of the reconstructed states without the first (ground-truth) one
+            T4 t = c->head2.att;
+            TV v{(grad ? t.g : t.d) + t.sn, B, (T - 1) * t.H, t.W, 1, (long)T * t.sn, t.ld};
+            return pw_nhwc_to_nchw(v, (float*)dst, (long)(T - 1) * t.H * t.W, 0, st);
+        }
+        case 10: return raw(a.ddist, NS * 2 * Da * 4);
+        case 11: return raw(a.dirs, NS * Da * 4);
+        case 12: return raw(a.sdist, NT * 2 * Da * 4);
+        case 13: return raw(a.ssamp, NT * Da * 4);
+        case 14: return raw(a.variations, NS * Da * 4);
+        case 15: return raw(r.logits, NS * K * 4);
+        case 16: return raw(r.ddist, NS * 2 * Da * 4);
+        case 17: return raw(r.dirs, NS * Da * 4);
+        case 18: return raw(r.sdist, NT * 2 * Da * 4);
+        case 19: return raw(r.ssamp, NT * Da * 4);
+    }
+    set_error("unknown output id"); return -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+static bool check_cfg(const caddy_config* g) {
+    if (!g || g->batch < 1 || g->seq_len < 2 || g->height % 16 || g->width % 16 || g->height < 16 || g->width < 16 || g->stacking < 1 ||
+        g->actions < 1 || g->actions > 16 || g->action_dim < 1 || g->action_dim > 8 || g->actions + g->action_dim > AUX_LD ||
+        (g->variant != 0 && g->variant != 1) || g->hidden != (g->variant == 0 ? 128 : 64)) {
+        set_error("invalid caddy_config (H, W multiples of 16; hidden 128 for main / 64 for reduced; K<=16; Da<=8)");
+        return false;
+    }
+    return true;
+}
+static caddy_ctx* make_ctx(const caddy_config* cfg, float* params, float* grads, void* ws, size_t act_cap) {
+    caddy_ctx* c = new caddy_ctx();
+    c->cfg = *cfg; c->dry = ws == nullptr; c->P = params; c->G = grads;
+    build_param_table(*cfg, c->table, &c->n_floats, &c->n_train);
+    c->persist.base = (char*)ws; c->persist.cap = (size_t)-1;
+    build_layers(c);
+    size_t pbytes = (c->persist.high + 4095) & ~(size_t)4095;
+    c->act.base = (char*)ws + pbytes; c->act.cap = act_cap; c->grad_delta = act_cap;
+    return c;
+}
+
+extern "C" {
+int caddy_param_count(const caddy_config* cfg) {
+    if (!check_cfg(cfg)) return -1;
+    std::vector<ParamEntry> t; long a, b; build_param_table(*cfg, t, &a, &b); return (int)t.size();
+}
+int caddy_param_info_get(const caddy_config* cfg, int i, caddy_param_info* out) {
+    if (!check_cfg(cfg)) return -1;
+    std::vector<ParamEntry> t; long a, b; build_param_table(*cfg, t, &a, &b);
+    if (i < 0 || i >= (int)t.size()) { set_error("index"); return -1; }
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", t[i].name.c_str());
+    out->offset = t[i].offset; out->ndim = t[i].ndim; out->kind = t[i].kind;
+    for (int k = 0; k < 4; k++) out->shape[k] = t[i].shape[k];
+    return 0;
+}
+long caddy_param_floats(const caddy_config* cfg) { if (!check_cfg(cfg)) return -1; std::vector<ParamEntry> t; long a, b; build_param_table(*cfg, t, &a, &b); return a; }
+long caddy_trainable_floats(const caddy_config* cfg) { if (!check_cfg(cfg)) return -1; std::vector<ParamEntry> t; long a, b; build_param_table(*cfg, t, &a, &b); return b; }
+
+static void dry_sizes(const caddy_config* cfg, size_t* persist, size_t* act) {
+    caddy_ctx* c = make_ctx(cfg, nullptr, nullptr, nullptr, (size_t)1 << 50);
+    forward_full(c, nullptr, 1, 1.f, nullptr, 1, nullptr, nullptr);
+    *persist = (c->persist.high + 4095) & ~(size_t)4095;
+    *act = (c->act.high + 4095) & ~(size_t)4095;
+    delete c;
+}
+size_t caddy_workspace_bytes(const caddy_config* cfg) {
+    if (!check_cfg(cfg)) return 0;
+    size_t p, a; dry_sizes(cfg, &p, &a);
+    return p + 2 * a + 4096;
+}
+caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes) {
+    if (!check_cfg(cfg)) return nullptr;
+    if (!params || !grads || !workspace) { set_error("null buffer"); return nullptr; }
+    size_t p, a; dry_sizes(cfg, &p, &a);
+    if (workspace_bytes < p + 2 * a) { set_error("workspace too small (see caddy_workspace_bytes)"); return nullptr; }
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { set_error("buffers must be 256-byte (workspace) / 16-byte (params, grads) aligned"); return nullptr; }
+    caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
+    if (c->fail) { delete c; return nullptr; }
+    return c;
+}
+void caddy_ctx_destroy(caddy_ctx* c) { delete c; }
+int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+int caddy_forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training, const float* samples_in, const float* variations_in) {
+    c->fail = false;
+    if (!obs || !noise) { set_error("null input"); return -2; }
+    return forward_full(c, obs, gt_init, tau, noise, training, samples_in, variations_in);
+}
+int caddy_get_output(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, false); }
+int caddy_get_output_grad(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, true); }
+int caddy_loss_backward(caddy_ctx* c, const caddy_loss_cfg* cfg, double* losses_host) { c->fail = false; return loss_backward(c, cfg, losses_host); }
+int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
+    return adam_launch(c->P, c->G, m, v, c->n_train, lr, b1, b2, eps, wd, step, gscale, c->stream);
+}
+int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
+int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
+    c->fail = false;
+    if (!observation || !frame_out) { set_error("null input"); return -2; }
+    if (c->lstm[0].h.d != c->lstm[0].ph.d || c->lstm[0].h.d == nullptr) { set_error("call caddy_start_inference first"); return -2; }
+    return generate_next(c, observation, action, variation, frame_out, obs_out);
+}
+int caddy_debug_count(caddy_ctx* c) { return (int)c->dbg.size(); }
+int caddy_debug_dims(caddy_ctx* c, int i, int* nhwc4) {
+    if (i < 0 || i >= (int)c->dbg.size()) return -1;
+    nhwc4[0] = c->dbg[i].N; nhwc4[1] = c->dbg[i].H; nhwc4[2] = c->dbg[i].W; nhwc4[3] = c->dbg[i].C; return 0;
+}
+int caddy_debug_get(caddy_ctx* c, int i, int grad, float* dst_nchw) {
+    if (i < 0 || i >= (int)c->dbg.size()) return -1;
+    const T4& t = c->dbg[i];
+    return pw_nhwc_to_nchw(grad ? gv(t) : dv(t), dst_nchw, (long)t.C * t.H * t.W, 0, c->stream);
+}
+int caddy_bn_layer_count(caddy_ctx* c) { return (int)c->bns.size(); }
+long caddy_bn_calls(caddy_ctx* c, int i, char* name_out128) {
+    if (i < 0 || i >= (int)c->bns.size()) return -1;
+    if (name_out128) snprintf(name_out128, 128, "%s", c->bns[i]->name.c_str());
+    return c->bns[i]->calls;
+}
+}

@@ -1,0 +1,107 @@
+// Host-side driver of the CADDY hot path: owns the packed weights, the activation / gradient arenas carved out of the
+// caller's workspace, and a tape that replays the forward graph in reverse for BPTT.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+#include "caddy_hip.h"
+#include "common.h"
+#include "head.h"
+#include "pack.h"
+#include "pointwise.h"
+
+struct T4 {            // activation + gradient views with identical geometry
+    float* d; float* g;
+    int N, H, W, C; long sn; int ld;
+};
+static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
+static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
+
+struct ParamEntry { std::string name; long offset; int ndim; int shape[4]; int kind; long numel; };
+
+struct Arena {
+    char* base = nullptr; size_t cap = 0, off = 0, high = 0;
+    void* alloc(size_t bytes) {
+        size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        if (off > high) high = off;
+        return base + a;
+    }
+    void reset() { off = 0; }
+};
+
+struct ConvL {
+    PackDesc pd{};
+    float* wp = nullptr; float* dwp = nullptr;
+    float* wpd[CONV_MAX_SRC] = {nullptr, nullptr, nullptr};
+    int cd_pad[CONV_MAX_SRC] = {0, 0, 0};
+    int kd = 0;
+    const float* bias = nullptr; float* dbias = nullptr;
+    size_t wp_floats = 0;
+};
+struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0; };
+struct ResL { ConvL conv1, conv2, down; BNL bn1, bn2, bnd; bool has_down = false; int ds = 1; };
+struct LstmL { ConvL gates; BNL bn; float *init_h, *init_c, *ginit_h, *ginit_c;   // boundary (C,h,w) params + grads
+               T4 ih, ic;        // HWC copies (1,h,w,C) in the persistent arena (data + grad)
+               T4 h, c;          // current state
+               T4 ph, pc;        // persistent inference state (B,h,w,C)
+               int C, Hs, Ws; };
+struct Seg { T4 t; int bcast; bool need_grad; };
+
+struct HeadState { HeadBufs b{}; SampleCfg sc{}; T4 x65; T4 att; };
+
+struct caddy_ctx {
+    caddy_config cfg{};
+    bool dry = false;
+    bool fail = false;
+    bool training = true;
+    bool recording = false;
+    hipStream_t stream = nullptr;
+    float* P = nullptr; float* G = nullptr;
+    std::vector<ParamEntry> table;
+    long n_floats = 0, n_train = 0;
+    Arena persist, act;
+    size_t grad_delta = 0;           // byte distance between an activation and its gradient
+    std::vector<std::function<void()>> tape;
+    std::vector<T4> dbg;             // every alloc() of the current forward (debug introspection, caddy_debug_*)
+    std::vector<ConvL*> convs;
+    std::vector<BNL*> bns;
+    // layers
+    ConvL e_stem; BNL e_bn1; ResL e_res[6];
+    ResL a_res[2]; HeadParams hp{};
+    LstmL lstm[3]; ConvL r_c0, r_c1, r_c2; BNL r_bn0, r_bn1, r_bn2;
+    ConvL d_up[3]; BNL d_norm[3]; ResL d_res[2]; ConvL d_final[3];
+    ConvL s2h;
+    float* centroids = nullptr;
+    // per-forward state
+    int gt_init = 0; float tau = 1.f;
+    T4 obs, x65_gt, rec_x65, hidden, frames[3], attn_gt;
+    HeadState head1, head2;
+    float *q_prob = nullptr;
+    double* loss_acc = nullptr;
+    bool have_forward = false;
+    int hs, ws;   // state resolution
+
+    // ---- helpers ----
+    T4 alloc(int N, int H, int W, int C, int ld = 0);
+    float* falloc(size_t n);
+    double* dalloc(size_t n);
+    T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into);
+    T4 pool2(const T4& x);
+    T4 up2(const T4& x);
+    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into);
+    T4 resblock(ResL& R, const T4& x, const T4* into);
+    T4 encode(const T4& obs_in, bool input_grad, const T4* into);
+    T4 lstm_step(int i, const T4& x, const T4& aux);
+    T4 dynamics(const T4& state, const T4& aux, const T4* into);
+    void render(const T4& hdn, int slot, int nslots);
+    void action_net(const T4& x65, HeadState& hs_, const float* eps_s, const float* eps_d, const float* unif, bool first,
+                    const float* samples_in, const float* variations_in);
+    void copy_op(const T4& src, const T4& dst);
+    void pack_all();
+    void unpack_all();
+    void ck(int rc, const char* what);
+};
+
+void build_param_table(const caddy_config& c, std::vector<ParamEntry>& t, long* n_floats, long* n_train);
+void set_error(const std::string& s);

@@ -61,6 +61,14 @@ struct FCopy {
         st4(o, c, d.C, v);
     }
 };
+struct FCopy1 {  // scalar variant for views whose base / pitch is not 16-byte aligned (channel-offset slices)
+    TV s, d; int HW; int acc;
+    __device__ void operator()(long q, int) const {
+        const float* i = s.p + tv_off(s, HW, q);
+        float* o = d.p + tv_off(d, HW, q);
+        for (int c = 0; c < d.C; c++) o[c] = acc ? o[c] + i[c] : i[c];
+    }
+};
 struct FFill {
     TV d; int HW; float val;
     __device__ void operator()(long q, int c) const { st4(d.p + tv_off(d, HW, q) + c, c, d.C, make_float4(val, val, val, val)); }
@@ -367,7 +375,11 @@ __global__ void k_batch_sum(const float* src, long sn, long n_el, int N, float* 
 
 }  // namespace
 
-int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FCopy{s, d, d.H * d.W, acc}, st); }
+int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) {
+    bool aligned = !(((uintptr_t)s.p | (uintptr_t)d.p) & 15) && !((s.ld | d.ld) & 3) && !((s.sn | d.sn) & 3);
+    if (!aligned) return run_map((long)d.N * d.H * d.W, 1, FCopy1{s, d, d.H * d.W, acc}, st);
+    return run_map((long)d.N * d.H * d.W, d.C, FCopy{s, d, d.H * d.W, acc}, st);
+}
 int pw_fill(const TV& d, float v, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FFill{d, d.H * d.W, v}, st); }
 int pw_pool2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out}, st); }
 int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din}, st); }

@@ -1,0 +1,225 @@
+"""Thin Python driver over the C-ABI (include/caddy_hip.h): owns the flat parameter / gradient / workspace buffers
+(torch tensors = device memory only) and turns raw output buffers into the reference's 20-tuple.
+
+`Engine` mirrors what reference callers do with the model object: forward in full-model mode,
+loss + backward, optimiser step, start_inference / generate_next.  `lib` may be injected by the tests (host simulator
+build of the same kernel sources); the default is the gfx950 library and there is no CPU fallback.
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+LOSS_NAMES = ["total", "rec", "states", "entropy", "dir_kl", "mi", "state_kl", "hidden", "l1_r0", "l1_r1", "l1_r2"]
+
+
+class CaddyConfig(C.Structure):
+    _fields_ = [("variant", C.c_int), ("batch", C.c_int), ("seq_len", C.c_int), ("height", C.c_int), ("width", C.c_int),
+                ("stacking", C.c_int), ("actions", C.c_int), ("action_dim", C.c_int), ("hidden", C.c_int),
+                ("use_gumbel", C.c_int), ("hard_gumbel", C.c_int), ("use_variations", C.c_int), ("centroid_alpha", C.c_float)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("offset", C.c_long), ("ndim", C.c_int), ("shape", C.c_int * 4), ("kind", C.c_int)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("eps_states", C.c_void_p), ("eps_dirs", C.c_void_p), ("gumbel_uniform", C.c_void_p),
+                ("eps_states_rec", C.c_void_p), ("eps_dirs_rec", C.c_void_p)]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [("rec", C.c_double), ("states", C.c_double), ("entropy", C.c_double), ("dir_kl", C.c_double), ("mi", C.c_double),
+                ("state_kl", C.c_double), ("hidden", C.c_double), ("mi_entropy_lambda", C.c_double),
+                ("mi_ema", C.c_void_p), ("mi_ema_alpha", C.c_float), ("update_mi_ema", C.c_int)]
+
+
+def _bind(lib):
+    if getattr(lib, "_caddy_bound", False):
+        return lib
+    lib.caddy_last_error.restype = C.c_char_p
+    lib.caddy_param_floats.restype = C.c_long
+    lib.caddy_trainable_floats.restype = C.c_long
+    lib.caddy_workspace_bytes.restype = C.c_size_t
+    lib.caddy_ctx_create.restype = C.c_void_p
+    lib.caddy_ctx_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.caddy_ctx_destroy.argtypes = [C.c_void_p]
+    lib.caddy_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_forward_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.caddy_get_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.caddy_get_output_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.caddy_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.caddy_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
+    lib.caddy_start_inference.argtypes = [C.c_void_p]
+    lib.caddy_generate_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.caddy_bn_layer_count.argtypes = [C.c_void_p]
+    lib.caddy_bn_calls.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    lib.caddy_bn_calls.restype = C.c_long
+    lib._caddy_bound = True
+    return lib
+
+
+class CaddyError(Exception):
+    pass
+
+
+class Engine:
+    def __init__(self, *, variant: str, batch: int, seq_len: int, height: int, width: int, stacking: int, actions: int,
+                 action_dim: int, hidden: int, use_gumbel=True, hard_gumbel=False, use_variations=True, centroid_alpha=0.1,
+                 device="cuda", lib=None):
+        self.lib = _bind(lib if lib is not None else _lib.load())
+        self.device = torch.device(device)
+        self.cfg = CaddyConfig(0 if variant == "main" else 1, batch, seq_len, height, width, stacking, actions, action_dim, hidden,
+                               int(use_gumbel), int(hard_gumbel), int(use_variations), centroid_alpha)
+        self.B, self.T, self.H, self.W, self.S, self.K, self.Da, self.Ch = batch, seq_len, height, width, stacking, actions, action_dim, hidden
+        n = self.lib.caddy_param_floats(C.byref(self.cfg))
+        if n <= 0:
+            raise CaddyError(self._err())
+        self.n_floats, self.n_train = n, self.lib.caddy_trainable_floats(C.byref(self.cfg))
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.device)
+        self.table = []
+        info = ParamInfo()
+        for i in range(self.lib.caddy_param_count(C.byref(self.cfg))):
+            self.lib.caddy_param_info_get(C.byref(self.cfg), i, C.byref(info))
+            self.table.append((info.name.decode(), info.offset, tuple(info.shape[:info.ndim]), info.kind))
+        self.ws_bytes = self.lib.caddy_workspace_bytes(C.byref(self.cfg))
+        raw = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-raw.data_ptr()) % 256
+        self._ws_raw, self._ws_ptr = raw, raw.data_ptr() + off
+        self.ctx = self.lib.caddy_ctx_create(C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self._ws_ptr, self.ws_bytes)
+        if not self.ctx:
+            raise CaddyError(self._err())
+        self.adam_m = self.adam_v = None
+        self.mi_ema = None
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "ctx", None):
+            self.lib.caddy_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _err(self):
+        return (self.lib.caddy_last_error() or b"").decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CaddyError(self._err() or f"caddy error {rc}")
+
+    def _stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        self.lib.caddy_set_stream(self.ctx, s)
+
+    # ---- parameters (reference state_dict names / layouts) ----
+    def view(self, name_or_entry) -> torch.Tensor:
+        e = name_or_entry if isinstance(name_or_entry, tuple) else next(t for t in self.table if t[0] == name_or_entry)
+        n = 1
+        for s in e[2]:
+            n *= s
+        return self.params[e[1]:e[1] + n].view(e[2])
+
+    def grad_view(self, name) -> torch.Tensor:
+        e = next(t for t in self.table if t[0] == name)
+        assert e[3] == 0
+        n = 1
+        for s in e[2]:
+            n *= s
+        return self.grads[e[1]:e[1] + n].view(e[2])
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for e in self.table:
+            self.view(e).copy_(sd[e[0]].detach().to(self.device, torch.float32))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {e[0]: self.view(e).detach().clone() for e in self.table}
+
+    # ---- forward (Model.forward, full-model mode) ----
+    def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
+                     samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None) -> List:
+        B, T, S, H, W, K, Da, Ch = self.B, self.T, self.S, self.H, self.W, self.K, self.Da, self.Ch
+        assert tuple(obs.shape) == (B, T, 3 * S, H, W), obs.shape
+        dev = self.device
+        obs = obs.to(dev, torch.float32).contiguous()
+        nz = {k: v.to(dev, torch.float32).contiguous() for k, v in noise.items()}
+        cn = Noise(nz["eps_states"].data_ptr(), nz["eps_dirs"].data_ptr(), nz["gumbel_uniform"].data_ptr(),
+                   nz["eps_states_rec"].data_ptr(), nz["eps_dirs_rec"].data_ptr())
+        si = samples_in.to(dev, torch.float32).contiguous() if samples_in is not None else None
+        vi = variations_in.to(dev, torch.float32).contiguous() if variations_in is not None else None
+        self._keep = [obs, nz, si, vi]
+        self._stream()
+        self._check(self.lib.caddy_forward_full(self.ctx, obs.data_ptr(), gt_init, float(tau), C.byref(cn), int(training),
+                                                si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
+        hs, ws = H // 8, W // 8
+        f32 = dict(dtype=torch.float32, device=dev)
+        shapes = {0: (B, T - 1, 3, H, W), 2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, T - 1, Ch, hs, ws), 6: (B, T - 1, K),
+                  7: (B, T - 1, K), 8: (B, T, 1, hs, ws), 9: (B, T - 1, 1, hs, ws), 10: (B, T - 1, 2, Da), 11: (B, T - 1, Da),
+                  12: (B, T, 2, Da), 13: (B, T, Da), 14: (B, T - 1, Da), 15: (B, T - 1, K), 16: (B, T - 1, 2, Da), 17: (B, T - 1, Da),
+                  18: (B, T, 2, Da), 19: (B, T, Da)}
+        out = [None] * 20
+        for i, shp in shapes.items():
+            t = torch.empty(shp, **f32)
+            self._check(self.lib.caddy_get_output(self.ctx, i, t.data_ptr()))
+            out[i] = t
+        sel = torch.empty((B, T - 1), dtype=torch.int64, device=dev)
+        self._check(self.lib.caddy_get_output(self.ctx, 5, sel.data_ptr()))
+        out[5] = sel
+        multi = [out[0]]
+        for r in (1, 2):
+            t = torch.empty((B, T - 1, 3, H >> r, W >> r), **f32)
+            self._check(self.lib.caddy_get_output(self.ctx, 100 + r, t.data_ptr()))
+            multi.append(t)
+        out[1] = multi
+        return out
+
+    def output_grad(self, idx: int, like: torch.Tensor) -> torch.Tensor:
+        """d(loss)/d(output idx) after loss_backward (debug / autograd bridge)."""
+        g = torch.empty_like(like)
+        self._stream()
+        self._check(self.lib.caddy_get_output_grad(self.ctx, idx, g.data_ptr()))
+        return g
+
+    # ---- losses + backward (Trainer.compute_losses terms + loss.backward()) ----
+    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True) -> Dict[str, float]:
+        if smooth_mi and self.mi_ema is None:
+            self.mi_ema = torch.full((self.K, self.K), 1.0 / (self.K * self.K), dtype=torch.float32, device=self.device)
+        lc = LossCfg(weights.get("rec", 0.0), weights.get("states", 0.0), weights.get("entropy", 0.0), weights.get("dir_kl", 0.0),
+                     weights.get("mi", 0.0), weights.get("state_kl", 0.0), weights.get("hidden", 0.0), weights.get("mi_entropy", 1.0),
+                     self.mi_ema.data_ptr() if smooth_mi else None, mi_alpha, int(update_mi_ema))
+        host = (C.c_double * 16)()
+        self._stream()
+        self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), host))
+        return {n: host[i] for i, n in enumerate(LOSS_NAMES)}
+
+    def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0):
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(self.grads), torch.zeros_like(self.grads)
+        self._stream()
+        self._check(self.lib.caddy_adam_step(self.ctx, self.adam_m.data_ptr(), self.adam_v.data_ptr(), lr, betas[0], betas[1], eps,
+                                             weight_decay, step, grad_scale))
+
+    # ---- roll-out (Model.start_inference / generate_next) ----
+    def start_inference(self):
+        self._stream()
+        self._check(self.lib.caddy_start_inference(self.ctx))
+
+    def generate_next(self, observation: torch.Tensor, action: int, variation: Optional[torch.Tensor] = None):
+        S, H, W = self.S, self.H, self.W
+        obs = observation.to(self.device, torch.float32).contiguous()
+        assert tuple(obs.shape) == (3 * S, H, W)
+        frame = torch.empty((3, H, W), dtype=torch.float32, device=self.device)
+        nxt = torch.empty((3 * S, H, W), dtype=torch.float32, device=self.device)
+        v = variation.to(self.device, torch.float32).contiguous() if variation is not None else None
+        self._stream()
+        self._check(self.lib.caddy_generate_next(self.ctx, obs.data_ptr(), int(action), v.data_ptr() if v is not None else None,
+                                                 frame.data_ptr(), nxt.data_ptr()))
+        return frame, nxt
+
+    def bn_calls(self) -> Dict[str, int]:
+        buf = C.create_string_buffer(128)
+        res = {}
+        for i in range(self.lib.caddy_bn_layer_count(self.ctx)):
+            n = self.lib.caddy_bn_calls(self.ctx, i, buf)
+            res[buf.value.decode()] = n
+        return res

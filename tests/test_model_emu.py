@@ -1,0 +1,31 @@
+"""Whole hot path (C++ driver + every HIP kernel) on the host functional simulator vs oracle and reference goldens."""
+import pytest
+
+from tests import model_cases as M
+from tests.emu.loader import load_emu
+
+pytestmark = pytest.mark.emu
+
+
+def test_single_step_gradients_tight():
+    M.single_step_grad_case(load_emu(), "cpu")
+
+
+def test_full_reduced_s1():
+    M.full_case("full_reduced_s1", load_emu(), "cpu")
+
+
+def test_rollout_reduced():
+    M.rollout_case("rollout_reduced_s1", load_emu(), "cpu")
+
+
+def test_full_main_s1():
+    M.full_case("full_main_s1", load_emu(), "cpu")
+
+
+def test_full_main_s4_hard_gumbel():
+    M.full_case("full_main_s4_hard", load_emu(), "cpu")
+
+
+def test_rollout_main_s4():
+    M.rollout_case("rollout_main_s4", load_emu(), "cpu")
