@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Headline benchmark: CADDY full-model training step (E -> A -> R -> D forward, fused losses, BPTT backward, gradient
+all-reduce for N>1, Adam) on synthetic BAIR-shaped clips -- BASELINE.json configs[1]: 256x256, T=16, B=8 per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` = clips/s over all GPUs with inputs resident in HBM.  `roofline` is for the
+dominant kernel family (fp32-MFMA implicit-GEMM conv), timed with HIP events on the launch stream during extra profiled
+steps; `cpu_baseline` is the CPU oracle (port of the reference arithmetic) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from playablevideogeneration_amd import configs  # noqa: E402
+from playablevideogeneration_amd.engine import Engine  # noqa: E402
+from playablevideogeneration_amd.init import init_parameters  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+# SURVEY.md 8(d) / BASELINE.md section 3, BAIR 256^2 T=16 gt=6: per clip forward 336.08 GFLOP, 2.2374 GB activations, 0.5159 GB weights/call
+ALGO = {"bair256_t16_b8": dict(gflop_clip_fwd=336.08, act_gb_clip_fwd=2.2374, w_gb_fwd=0.5159)}
+
+
+def make_noise(B, T, K, Da, dev, gen):
+    n = T - 1
+    return {"eps_states": torch.randn(B * T, Da, device=dev, generator=gen), "eps_dirs": torch.randn(B * n, Da, device=dev, generator=gen),
+            "gumbel_uniform": torch.rand(B * n, K, device=dev, generator=gen),
+            "eps_states_rec": torch.randn(B * T, Da, device=dev, generator=gen), "eps_dirs_rec": torch.randn(B * n, Da, device=dev, generator=gen)}
+
+
+def cpu_baseline(wl):
+    """Oracle (CPU port of the reference arithmetic) on a bounded sample: 1 clip of the same geometry, forward + losses +
+    backward, 1 warm-up + 1 timed iteration on the host cores."""
+    from oracle import caddy_oracle as O
+    d = O.Dims(variant=wl["variant"], actions=wl["actions"], action_dim=wl["action_dim"], hidden=wl["hidden"], stacking=wl["stacking"],
+               state_res=(wl["height"] // 8, wl["width"] // 8))
+    P = {k: v.clone().requires_grad_(O.is_trainable(k)) for k, v in O.make_params(d, seed=0).items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    obs = torch.rand(1, wl["seq_len"], 3 * wl["stacking"], wl["height"], wl["width"]) * 2 - 1
+    w = dict(O.DEFAULT_LOSS_WEIGHTS)
+    dt = None
+    for it in range(2):
+        t0 = time.time()
+        orc = O.Oracle(d, P, training=True)
+        out = orc.forward_full(obs, wl["gt_init"], tau=wl["tau"])
+        total, _, _ = O.full_model_loss(out, obs, w, mi_ema=torch.full((d.K, d.K), 1.0 / d.K ** 2))
+        total.backward()
+        dt = time.time() - t0
+        for p in P.values():
+            p.grad = None
+        P["centroid_estimator.estimated_centroids"] = P["centroid_estimator.estimated_centroids"].detach()
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}), oracle forward+losses+backward, 1 warm-up + 1 timed iteration"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="bair256_t16_b8", choices=sorted(configs.WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=1)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    wl = configs.WORKLOADS[a.workload]
+    B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
+    eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev)
+    init_parameters(eng, seed=0)                            # identical replicas on every rank
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1     # each rank owns its shard of the global batch
+    step_no = [0]
+
+    def step():
+        step_no[0] += 1
+        eng.forward_full(obs, wl["gt_init"], wl["tau"], make_noise(B, T, K, Da, dev, gen), training=True, fetch_outputs=False)
+        losses = eng.loss_backward(configs.LOSS_WEIGHTS, smooth_mi=True)
+        if world > 1:
+            dist.all_reduce(eng.grads)                      # one flat fp32 buffer (39.4 MB for BAIR-main), sum over ranks
+        eng.adam_step(step_no[0], lr=4e-4, weight_decay=1e-6, grad_scale=1.0 / world)
+        return losses
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        losses = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_step = dt / a.steps * 1e3
+    clips_s = world * B * a.steps / dt
+
+    # live per-kernel timing (HIP events on the launch stream) of extra, untimed-for-throughput steps
+    roof = None
+    if rank == 0 and a.profile_steps > 0:
+        eng.profile_begin()
+        for _ in range(a.profile_steps):
+            step()
+        fam = eng.profile_end()
+        name, (n, fl, ms) = max(fam.items(), key=lambda kv: kv[1][2])
+        tot_ms = sum(v[2] for v in fam.values())
+        roof = {"kernel": name, "bound": "mfma", "achieved": fl / ms / 1e9, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": n // a.profile_steps, "avg_launch_us": ms / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
+                "all_conv_families_ms_per_step": tot_ms / a.profile_steps,
+                "families": {k: {"launches": v[0] // a.profile_steps, "tflops": (v[1] / v[2] / 1e9 if v[2] > 0 else 0.0), "ms": v[2] / a.profile_steps} for k, v in fam.items()}}
+        alg = ALGO.get(a.workload)
+        if alg:   # whole-step figures on SURVEY 8(d)'s algorithmic work: bytes = 3*(B*act + W), flops = 3*B*fwd
+            step_bytes = 3 * (B * alg["act_gb_clip_fwd"] + alg["w_gb_fwd"]) * 1e9
+            step_flops = 3 * B * alg["gflop_clip_fwd"] * 1e9
+            roof["step_hbm_roofline_frac"] = step_bytes / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            roof["step_fp32_matrix_frac"] = step_flops / (ms_step * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * 1e12)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        res = {"metric": "training clips/sec (B x16x256x256)", "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": a.workload, "model": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
+                          "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
+                          "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
+               "loss": losses["total"], "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,12 @@ int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, f
 int caddy_start_inference(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
+/* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.
+ *     out18 = 6 kernel families {k_conv_fwd<2,2,2,2>, <2,1,2,2>, <1,1,4,1>, k_conv_wgrad<2,2,2,2>, <1,2,2,2>, <1,1,1,4>}
+ *             x {launches, algorithmic FLOPs (SURVEY 8d definition), total milliseconds} --- */
+int caddy_profile_begin(caddy_ctx* ctx);
+int caddy_profile_end(caddy_ctx* ctx, double* out18);
+
 /* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last
  *     forward, converted to (N,C,H,W) --- */
 int caddy_debug_count(caddy_ctx* ctx);

@@ -47,7 +47,7 @@ def build(force=False):
     if not force and not _stale(LIB, _deps()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-x", "hip",
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip",
              "-I", HERE, "-I", os.path.join(ROOT, "include")]
     objs = _compile_objects([hipcc] + flags, os.path.join(HERE, "build"), srcs, headers)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

@@ -7,6 +7,13 @@
 #include <cstring>
 
 static thread_local std::string g_err;
+static int finish(caddy_ctx* c) {   // surface asynchronous launch errors of this API call
+    if (!c->dry) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess && !c->fail) { c->fail = true; g_err = std::string("HIP error: ") + hipGetErrorString(e); }
+    }
+    return c->fail ? -1 : 0;
+}
 void set_error(const std::string& s) { g_err = s; }
 extern "C" const char* caddy_last_error(void) { return g_err.c_str(); }
 
@@ -213,6 +220,28 @@ static void fill_srcs(ConvSrc* dst, const Seg* segs, int nseg) {
     }
 }
 
+int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
+    if (!prof) return conv_fwd_launch(a, stream);
+    int bn = conv_pick_bn(a.Cout);
+    ProfRec r{ev(), ev(), bn == 128 ? 0 : (bn == 64 ? 1 : 2), flops};
+    hipEventRecord(r.a, stream);
+    int rc = conv_fwd_launch(a, stream);
+    hipEventRecord(r.b, stream);
+    prof_recs.push_back(r);
+    return rc;
+}
+int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
+    if (!prof) return conv_wgrad_launch(a, stream);
+    int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
+    if (a.Cout_pad % bmo) bmo = 32;
+    ProfRec r{ev(), ev(), bmo == 128 ? 3 : (bmo == 64 ? 4 : 5), flops};
+    hipEventRecord(r.a, stream);
+    int rc = conv_wgrad_launch(a, stream);
+    hipEventRecord(r.b, stream);
+    prof_recs.push_back(r);
+    return rc;
+}
+
 T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into) {
     int N = 0, H = 0, W = 0;
     for (int s = 0; s < nseg; s++) if (!segs[s].bcast) { N = segs[s].t.N; H = segs[s].t.H; W = segs[s].t.W; break; }
@@ -221,7 +250,8 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
     a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0;
-    RUN(conv_fwd_launch(a, stream));
+    const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
+    RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
     if (recording) {
         T4 dz{}; if (actf == 1) dz = alloc(N, H, W, L.pd.Cout);
         Seg sg[CONV_MAX_SRC]; T4 tmp[CONV_MAX_SRC];
@@ -234,7 +264,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             fill_srcs(w.src, sg, nseg);
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
             w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
-            RUN(conv_wgrad_launch(w, stream));
+            RUN(timed_conv_wgrad(w, px_taps * Lp->pd.Cin * Lp->pd.Cout));
             if (Lp->dbias) RUN(pw_colsum(dzv, Lp->dbias, stream));
             for (int s = 0; s < nseg; s++) {
                 if (!sg[s].need_grad) continue;
@@ -242,10 +272,11 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
                 d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0;
-                if (!sg[s].bcast) { d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = 1; RUN(conv_fwd_launch(d, stream)); }
+                const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
+                if (!sg[s].bcast) { d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = 1; RUN(timed_conv_fwd(d, dfl)); }
                 else {
                     d.out = tmp[s].d; d.out_sn = tmp[s].sn; d.out_ld = tmp[s].ld; d.accumulate = 0;
-                    RUN(conv_fwd_launch(d, stream));
+                    RUN(timed_conv_fwd(d, dfl));
                     RUN(pw_spatial_sum(dv(tmp[s]), sg[s].t.g, sg[s].t.sn, stream));
                 }
             }
@@ -509,7 +540,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions);
     c->have_forward = true;
-    return c->fail ? -1 : 0;
+    return finish(c);
 }
 
 static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_host) {
@@ -549,7 +580,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     c->unpack_all();
     if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
-    return c->fail ? -1 : 0;
+    return finish(c);
 }
 
 // Model.generate_next (model/main_model/model.py:570-607), batch 1, eval mode, persistent ConvLSTM state
@@ -718,6 +749,18 @@ int caddy_generate_next(caddy_ctx* c, const float* observation, int action, cons
     if (!observation || !frame_out) { set_error("null input"); return -2; }
     if (c->lstm[0].h.d != c->lstm[0].ph.d || c->lstm[0].h.d == nullptr) { set_error("call caddy_start_inference first"); return -2; }
     return generate_next(c, observation, action, variation, frame_out, obs_out);
+}
+int caddy_profile_begin(caddy_ctx* c) { c->prof = true; c->prof_recs.clear(); c->ev_used = 0; return 0; }
+int caddy_profile_end(caddy_ctx* c, double* out18) {   // 6 kernel families x (launches, algorithmic FLOPs, milliseconds)
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 18; i++) out18[i] = 0.0;
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        out18[r.fam * 3] += 1.0; out18[r.fam * 3 + 1] += r.flops; out18[r.fam * 3 + 2] += ms;
+    }
+    c->prof = false; c->prof_recs.clear();
+    return 0;
 }
 int caddy_debug_count(caddy_ctx* c) { return (int)c->dbg.size(); }
 int caddy_debug_dims(caddy_ctx* c, int i, int* nhwc4) {

@@ -82,6 +82,15 @@ struct caddy_ctx {
     bool have_forward = false;
     int hs, ws;   // state resolution
 
+    // ---- optional per-launch timing of the conv kernels (HIP events on the launch stream; bench.py roofline) ----
+    struct ProfRec { hipEvent_t a, b; int fam; double flops; };
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    hipEvent_t ev() { if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); } return ev_pool[ev_used++]; }
+    int timed_conv_fwd(const ConvArgs& a, double flops);
+    int timed_conv_wgrad(const WgradArgs& a, double flops);
+
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);
     float* falloc(size_t n);

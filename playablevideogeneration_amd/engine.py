@@ -137,7 +137,7 @@ class Engine:
 
     # ---- forward (Model.forward, full-model mode) ----
     def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
-                     samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None) -> List:
+                     samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
         B, T, S, H, W, K, Da, Ch = self.B, self.T, self.S, self.H, self.W, self.K, self.Da, self.Ch
         assert tuple(obs.shape) == (B, T, 3 * S, H, W), obs.shape
         dev = self.device
@@ -151,6 +151,8 @@ class Engine:
         self._stream()
         self._check(self.lib.caddy_forward_full(self.ctx, obs.data_ptr(), gt_init, float(tau), C.byref(cn), int(training),
                                                 si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
+        if not fetch_outputs:      # fused-loss training path: outputs stay in the workspace, only loss scalars leave
+            return None
         hs, ws = H // 8, W // 8
         f32 = dict(dtype=torch.float32, device=dev)
         shapes = {0: (B, T - 1, 3, H, W), 2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, T - 1, Ch, hs, ws), 6: (B, T - 1, K),
@@ -215,6 +217,18 @@ class Engine:
         self._check(self.lib.caddy_generate_next(self.ctx, obs.data_ptr(), int(action), v.data_ptr() if v is not None else None,
                                                  frame.data_ptr(), nxt.data_ptr()))
         return frame, nxt
+
+    CONV_FAMILIES = ["k_conv_fwd<2,2,2,2>", "k_conv_fwd<2,1,2,2>", "k_conv_fwd<1,1,4,1>",
+                     "k_conv_wgrad<2,2,2,2>", "k_conv_wgrad<1,2,2,2>", "k_conv_wgrad<1,1,1,4>"]
+
+    def profile_begin(self):
+        self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))
+
+    def profile_end(self):
+        """-> {kernel family: (launches, algorithmic FLOPs, milliseconds)} measured with HIP events on the launch stream."""
+        out = (C.c_double * 18)()
+        self._check(self.lib.caddy_profile_end(C.c_void_p(self.ctx), out))
+        return {n: (int(out[3 * i]), out[3 * i + 1], out[3 * i + 2]) for i, n in enumerate(self.CONV_FAMILIES)}
 
     def bn_calls(self) -> Dict[str, int]:
         buf = C.create_string_buffer(128)

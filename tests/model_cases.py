@@ -133,6 +133,25 @@ def single_step_grad_case(lib, dev, variant="main", tol=1e-3):
     assert worst[1] < tol, worst
 
 
+def oracle_case(lib, dev, c, fwd_tol=3e-4):
+    """Forward + losses vs the fp32 oracle on an ad-hoc geometry (no golden): outputs, exact action indices, frame MSE."""
+    d, P, obs = H.inputs_of(c)
+    orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        oout = orc.forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+        total, comp, _ = O.full_model_loss(oout, obs, H.LOSS_W, mi_ema=torch.full((d.K, d.K), 1.0 / (d.K * d.K)), mi_alpha=0.2)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    out = eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+    _cmp(out, list(oout), fwd_tol, "vs oracle")
+    assert ((out[0].cpu() - oout[0]) ** 2).mean(dim=(2, 3, 4)).max().item() < 1e-5
+    losses = eng.loss_backward(H.LOSS_W)
+    assert abs(losses["total"] - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert torch.isfinite(eng.grads).all()
+
+
 def rollout_case(name, lib, dev, tol=2e-4):
     c, z = H.load_case(name)
     d, P, obs = H.inputs_of(c)

@@ -1,0 +1,39 @@
+"""Whole hot path on the MI355X through the C-ABI: parity vs oracle + reference goldens, roll-outs, size-independent
+properties at the BASELINE geometry."""
+import pytest
+import torch
+
+from tests import model_cases as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from playablevideogeneration_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib.load()
+
+
+@pytest.mark.parametrize("name", ["full_reduced_s1", "full_main_s1", "full_main_s4_hard"])
+def test_full_model_parity(lib, name):
+    M.full_case(name, lib, "cuda")
+
+
+def test_single_step_gradients_tight(lib):
+    M.single_step_grad_case(lib, "cuda")
+
+
+@pytest.mark.parametrize("name", ["rollout_main_s4", "rollout_reduced_s1"])
+def test_rollout_parity(lib, name):
+    M.rollout_case(name, lib, "cuda")
+
+
+def test_larger_geometry_vs_oracle(lib):
+    """breakout-reduced hyper-parameters at 64x64, T=5 (BASELINE configs[0] geometry, shortened) vs the CPU oracle."""
+    M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=5, H=64, W=64, gt=3, tau=0.85))
+
+
+def test_non_square_frames(lib):
+    """state resolution 26x20 -> 13x10 (Breakout 208x160, SURVEY hard part 7)."""
+    M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=3, H=208, W=160, gt=1, tau=0.6))
