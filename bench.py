@@ -30,6 +30,14 @@ HBM_PEAK_GBS = 8000.0
 ALGO = {"bair256_t16_b8": dict(gflop_clip_fwd=336.08, act_gb_clip_fwd=2.2374, w_gb_fwd=0.5159)}
 
 
+T_START = time.time()
+
+
+def log(msg):
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench +{time.time() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def make_noise(B, T, K, Da, dev, gen):
     n = T - 1
     return {"eps_states": torch.randn(B * T, Da, device=dev, generator=gen), "eps_dirs": torch.randn(B * n, Da, device=dev, generator=gen),
@@ -44,7 +52,7 @@ def cpu_baseline(wl):
     d = O.Dims(variant=wl["variant"], actions=wl["actions"], action_dim=wl["action_dim"], hidden=wl["hidden"], stacking=wl["stacking"],
                state_res=(wl["height"] // 8, wl["width"] // 8))
     P = {k: v.clone().requires_grad_(O.is_trainable(k)) for k, v in O.make_params(d, seed=0).items()}
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # oneDNN degrades badly beyond ~32 threads on the 256-core GPU host (measured: >25 min at 256)
     torch.set_num_threads(cores)
     obs = torch.rand(1, wl["seq_len"], 3 * wl["stacking"], wl["height"], wl["width"]) * 2 - 1
     w = dict(O.DEFAULT_LOSS_WEIGHTS)
@@ -89,7 +97,9 @@ def main():
     wl = configs.WORKLOADS[a.workload]
     B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
     eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev)
+    log(f"engine created: workspace {eng.ws_bytes / 2**30:.1f} GiB, {eng.n_train} trainable floats")
     init_parameters(eng, seed=0)                            # identical replicas on every rank
+    log("parameters initialised")
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1     # each rank owns its shard of the global batch
     step_no = [0]
@@ -108,8 +118,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         losses = step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done, loss {losses['total']:.5f}")
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -121,6 +133,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     ms_step = dt / a.steps * 1e3
+    log(f"timed region done: {ms_step:.1f} ms/step")
     clips_s = world * B * a.steps / dt
 
     # live per-kernel timing (HIP events on the launch stream) of extra, untimed-for-throughput steps
@@ -153,7 +166,9 @@ def main():
                           "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
                "loss": losses["total"], "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle, 1 clip) ...")
             res["cpu_baseline"] = cpu_baseline(wl)
+            log("cpu baseline done")
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

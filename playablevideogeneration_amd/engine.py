@@ -68,7 +68,7 @@ class CaddyError(Exception):
 class Engine:
     def __init__(self, *, variant: str, batch: int, seq_len: int, height: int, width: int, stacking: int, actions: int,
                  action_dim: int, hidden: int, use_gumbel=True, hard_gumbel=False, use_variations=True, centroid_alpha=0.1,
-                 device="cuda", lib=None):
+                 device="cuda", lib=None, params=None, grads=None):
         self.lib = _bind(lib if lib is not None else _lib.load())
         self.device = torch.device(device)
         self.cfg = CaddyConfig(0 if variant == "main" else 1, batch, seq_len, height, width, stacking, actions, action_dim, hidden,
@@ -78,8 +78,11 @@ class Engine:
         if n <= 0:
             raise CaddyError(self._err())
         self.n_floats, self.n_train = n, self.lib.caddy_trainable_floats(C.byref(self.cfg))
-        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.device)
+        # flat buffers may be supplied by the caller (Model shares one parameter buffer across engines of different B/T)
+        self.params = params if params is not None else torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = grads if grads is not None else torch.zeros(self.n_train, dtype=torch.float32, device=self.device)
+        assert self.params.numel() == n and self.grads.numel() == self.n_train and self.params.is_contiguous() and self.grads.is_contiguous()
+        assert self.params.device == self.grads.device and self.params.device.type == self.device.type
         self.table = []
         info = ParamInfo()
         for i in range(self.lib.caddy_param_count(C.byref(self.cfg))):

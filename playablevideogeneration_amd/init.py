@@ -7,6 +7,7 @@ import torch
 
 
 def init_parameters(engine, seed: int = 0):
+    """`engine`: anything with `.table` [(name, offset, shape, kind)] and `.view(entry)` (Engine or Model)."""
     g = torch.Generator().manual_seed(seed)
     fan = {}
     for name, off, shape, kind in engine.table:

@@ -1,0 +1,239 @@
+"""Drop-in for the reference's model plugin: `config["model"]["architecture"] = "playablevideogeneration_amd.model"`
+(main) or `"playablevideogeneration_amd.reduced_model"`; the factory `model(config)` returns an nn.Module with the surface the
+reference callers use (model/main_model/model.py:57-82, 561-607):
+
+    model(batch_tuple, ground_truth_observations_init, gumbel_temperature=...) -> 20-tuple
+    model.module.centroid_estimator.get_estimated_centroids(), state_dict()/load_state_dict() with the reference's keys,
+    parameters() (views of ONE flat fp32 buffer), train()/eval(), cuda(), start_inference(), generate_next(obs, action).
+
+All arithmetic runs in libcaddy_hip.so (HIP, gfx950) through `Engine`; there is no torch/CPU fallback.  Noise is drawn from
+torch's global CPU generator with the reference's calls in the reference's order, so `torch.manual_seed(s)` reproduces the
+reference's action samples bit-for-bit.
+"""
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import CaddyConfig, Engine, ParamInfo, _bind
+from .init import init_parameters
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state_dict names."""
+
+
+class _CentroidView:
+    def __init__(self, model):
+        self._m = model
+
+    def get_estimated_centroids(self) -> torch.Tensor:     # centroid_estimator.py:31-36
+        return self._m._param_views["centroid_estimator.estimated_centroids"]
+
+    @property
+    def estimated_centroids(self):
+        return self.get_estimated_centroids()
+
+
+class Model(nn.Module):
+    VARIANT = "main"
+
+    def __init__(self, config, lib=None):
+        super().__init__()
+        self.config = config
+        an = config["model"]["action_network"]
+        if config["training"].get("use_ground_truth_actions", False):
+            self._forbid_gt_actions = True
+        else:
+            self._forbid_gt_actions = False
+        self._pretraining_detach = config["training"].get("pretraining_detach", False)
+        sr = config["model"]["representation_network"]["state_resolution"]
+        self.dims = dict(variant=self.VARIANT, height=int(sr[0]) * 8, width=int(sr[1]) * 8,
+                         stacking=config["training"]["batching"]["observation_stacking"], actions=config["data"]["actions_count"],
+                         action_dim=an["action_space_dimension"], hidden=config["model"]["dynamics_network"]["hidden_state_size"],
+                         use_gumbel=bool(an["use_gumbel"]), hard_gumbel=bool(an["hard_gumbel"]), use_variations=bool(an.get("use_variations", True)),
+                         centroid_alpha=config["model"]["centroid_estimator"]["alpha"])
+        self.random_noise_size = config["model"]["dynamics_network"]["random_noise_size"]
+        self.current_temperature = an["gumbel_temperature"]      # GumbelSoftmax.current_temperature (gumbel_softmax.py:21)
+        self._lib = _bind(lib if lib is not None else _lib.load())
+        d = self.dims
+        cc = CaddyConfig(0 if d["variant"] == "main" else 1, 1, 2, d["height"], d["width"], d["stacking"], d["actions"], d["action_dim"], d["hidden"],
+                         int(d["use_gumbel"]), int(d["hard_gumbel"]), int(d["use_variations"]), d["centroid_alpha"])
+        n = self._lib.caddy_param_floats(C.byref(cc))
+        if n <= 0:
+            raise Exception(self._lib.caddy_last_error().decode())
+        self.n_floats, self.n_train = n, self._lib.caddy_trainable_floats(C.byref(cc))
+        info = ParamInfo()
+        self.table = []
+        for i in range(self._lib.caddy_param_count(C.byref(cc))):
+            self._lib.caddy_param_info_get(C.byref(cc), i, C.byref(info))
+            self.table.append((info.name.decode(), info.offset, tuple(info.shape[:info.ndim]), info.kind))
+        self._flat = torch.zeros(n, dtype=torch.float32)
+        self._flat_grad = torch.zeros(self.n_train, dtype=torch.float32)
+        self._param_views: Dict[str, torch.Tensor] = {}
+        self._bn_counters: Dict[str, torch.Tensor] = {}
+        self._register_tree()
+        init_parameters(self, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        self._engines: Dict[Tuple[int, int], Engine] = {}
+        self._infer: Optional[Engine] = None
+        self._bn_seen: Dict[Tuple[int, int], Dict[str, int]] = {}
+        self.last_engine: Optional[Engine] = None
+        self.centroid_estimator_view = _CentroidView(self)
+        self._rebind()          # Parameter.grad = views of the flat gradient buffer
+
+    # ---- parameter plumbing ---------------------------------------------------------------------------------------
+    def view(self, entry) -> torch.Tensor:
+        name, off, shape, kind = entry
+        k = 1
+        for s in shape:
+            k *= s
+        return self._flat[off:off + k].view(shape)
+
+    def _register_tree(self):
+        for e in self.table:
+            name, off, shape, kind = e
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            v = self.view(e)
+            if kind == 1:
+                node.register_buffer(parts[-1], v)
+                if parts[-1] == "running_var":
+                    cnt = torch.zeros((), dtype=torch.int64)
+                    node.register_buffer("num_batches_tracked", cnt)
+                    self._bn_counters[".".join(parts[:-1])] = cnt
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(v, requires_grad=(kind == 0)))
+            self._param_views[name] = v
+
+    def _rebind(self):
+        """Re-point every Parameter / buffer at the (moved) flat buffers; gradients are views of the flat gradient buffer."""
+        for e in self.table:
+            name, off, shape, kind = e
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                node = node._modules[p]
+            v = self.view(e)
+            self._param_views[name] = v
+            if kind == 1:
+                node._buffers[parts[-1]] = v
+            else:
+                prm = node._parameters[parts[-1]]
+                prm.data = v
+                if kind == 0:
+                    k = v.numel()
+                    prm.grad = self._flat_grad[off:off + k].view(shape)
+        for pre, cnt in list(self._bn_counters.items()):
+            node = self
+            for p in pre.split("."):
+                node = node._modules[p]
+            self._bn_counters[pre] = node._buffers["num_batches_tracked"]
+
+    def _apply(self, fn, recurse=True):
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise Exception("the HIP path computes in fp32; dtype conversion of the model is not supported")
+        self._flat = new_flat.contiguous()
+        self._flat_grad = fn(self._flat_grad).contiguous()
+        for pre in list(self._bn_counters):
+            node = self
+            for p in pre.split("."):
+                node = node._modules[p]
+            node._buffers["num_batches_tracked"] = fn(node._buffers["num_batches_tracked"])
+        self._rebind()
+        self._engines.clear()
+        self._infer = None
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        self._flat_grad.zero_()
+
+    @property
+    def module(self):            # reference callers unwrap nn.DataParallel via `.module` (training/trainer.py:434)
+        return self
+
+    @property
+    def centroid_estimator(self):
+        return self.centroid_estimator_view
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        sd.pop("centroid_estimator_view", None)
+        return sd
+
+    # ---- engines ------------------------------------------------------------------------------------------------------
+    def engine(self, B: int, T: int) -> Engine:
+        key = (B, T)
+        if key not in self._engines:
+            d = self.dims
+            if self._flat.device.type != "cuda" and not getattr(self._lib, "_caddy_emulated", False):
+                raise Exception("playablevideogeneration_amd runs on the MI355X only: call model.cuda() first (no CPU fallback)")
+            self._engines[key] = Engine(batch=B, seq_len=T, device=self._flat.device, lib=self._lib, params=self._flat, grads=self._flat_grad, **d)
+            self._bn_seen[key] = {}
+        return self._engines[key]
+
+    def _sync_bn_counters(self, eng: Engine, key):
+        seen = self._bn_seen.setdefault(key, {})
+        for name, calls in eng.bn_calls().items():
+            delta = calls - seen.get(name, 0)
+            if delta:
+                self._bn_counters[name] += delta
+                seen[name] = calls
+
+    # ---- Model.forward (model/main_model/model.py:57-82) -----------------------------------------------------------------
+    def forward(self, batch_tuple, ground_truth_observations_init=0, pretraining=False, gumbel_temperature=None,
+                action_sampler=None, action_variation_sampler=None, fetch_outputs=True):
+        if pretraining:
+            if self._pretraining_detach:
+                raise Exception("Pretraining detach is not supported by the current model")
+            raise NotImplementedError("forward_pretraining (model.py:290-468) is not part of this round's HIP path; see DESIGN.md")
+        if ground_truth_observations_init <= 0:
+            raise Exception("To forward the full model specify a number of ground truth observations > 0")
+        if self._forbid_gt_actions:
+            raise Exception("The use of ground truth actions during training is not supported by the selected model")
+        if action_sampler is not None or action_variation_sampler is not None:
+            raise NotImplementedError("evaluation action samplers (evaluation/action_sampler.py) are a 'next' row (SURVEY 8f-3)")
+        observations = batch_tuple[0]
+        B, T = observations.shape[:2]
+        eng = self.engine(B, T)
+        if gumbel_temperature is not None:
+            self.current_temperature = gumbel_temperature
+        d = self.dims
+        Da, K, n = d["action_dim"], d["actions"], T - 1
+        # RNG draws in the reference's order; all independent of data, so they can be drawn up front
+        noise = {"eps_states": torch.randn((B * T, Da), dtype=torch.float32), "eps_dirs": torch.randn((B, n, Da), dtype=torch.float32).reshape(B * n, Da)}
+        noise["gumbel_uniform"] = torch.rand((B * n, K)) if d["use_gumbel"] else torch.zeros((B * n, K))
+        for _ in range(n):
+            torch.randn((B, self.random_noise_size))        # model.py:220/496: drawn, never consumed by R
+        noise["eps_states_rec"] = torch.randn((B * T, Da), dtype=torch.float32)
+        noise["eps_dirs_rec"] = torch.randn((B, n, Da), dtype=torch.float32).reshape(B * n, Da)
+        out = eng.forward_full(observations, int(ground_truth_observations_init), float(self.current_temperature), noise,
+                               training=self.training, fetch_outputs=fetch_outputs)
+        if self.training:
+            self._sync_bn_counters(eng, (B, T))
+        self.last_engine = eng
+        return tuple(out) if out is not None else None
+
+    # ---- play.py path (model.py:561-607) ---------------------------------------------------------------------------------
+    def start_inference(self):
+        if self._infer is None:
+            d = self.dims
+            self._infer = Engine(batch=1, seq_len=2, device=self._flat.device, lib=self._lib, params=self._flat, grads=self._flat_grad, **d)
+        self._infer.start_inference()
+
+    def generate_next(self, observation: torch.Tensor, action: int, noise=False):
+        if self._infer is None:
+            raise Exception("start_inference() must be called before generate_next()")
+        variation = torch.randn((1, self.dims["action_dim"]), dtype=torch.float32)[0] if noise else None
+        torch.randn((1, self.random_noise_size))             # generate_noise(batch_size=1), unused by R (model.py:596)
+        return self._infer.generate_next(observation, action, variation)
+
+
+def model(config):
+    return Model(config)

@@ -1,0 +1,141 @@
+"""Counterpart of training/trainer.py for the HIP path: `config["training"]["trainer"] = "playablevideogeneration_amd.trainer"`.
+
+Same schedules (trainer.py:124-165), same loss weighting (:494-500, perceptual term excluded -- no pretrained VGG19 offline),
+same optimiser (Adam lr / weight_decay, MultiStepLR; :36-37,584-587) and checkpoint keys (:100), but losses + backward +
+Adam run fused inside libcaddy_hip.so and only one small buffer of loss scalars crosses to the host per step.
+"""
+import math
+import os
+from typing import Dict
+
+import torch
+
+
+class Trainer:
+    SMOOTH_MI = False
+
+    def __init__(self, config, model, dataset, logger):
+        self.config, self.dataset, self.logger = config, dataset, logger
+        tr = config["training"]
+        self.lr, self.weight_decay = tr["learning_rate"], tr["weight_decay"]
+        self.lr_schedule, self.lr_gamma = list(tr["lr_schedule"]), tr["lr_gamma"]
+        self.global_step = 0
+        self.action_mutual_infromation_entropy_lambda = tr.get("action_mutual_information_entropy_lambda", 1.0)   # configuration.py:79-80
+        b = tr["batching"]
+        self.observations_count_start, self.observations_count_end, self.observations_count_steps = b["observations_count_start"], b["observations_count"], b["observations_count_steps"]
+        self.real_observations_start, self.real_observations_end, self.real_observations_steps = tr["ground_truth_observations_start"], tr["ground_truth_observations_end"], tr["ground_truth_observations_steps"]
+        self.gumbel_temperature_start, self.gumbel_temperature_end, self.gumbel_temperature_steps = tr["gumbel_temperature_start"], tr["gumbel_temperature_end"], tr["gumbel_temperature_steps"]
+        self.mi_alpha = tr.get("mutual_information_estimation_alpha", 0.2)
+        self.adam_m = self.adam_v = None
+        self.mi_ema = None
+        self.opt_steps = 0
+
+    # ---- schedules: training/trainer.py:124-165 ----
+    def get_ground_truth_observations_count(self) -> int:
+        v = self.real_observations_start - (self.real_observations_start - self.real_observations_end) * self.global_step / self.real_observations_steps
+        return max(self.real_observations_end, math.ceil(v))
+
+    def get_gumbel_temperature(self) -> float:
+        v = self.gumbel_temperature_start - (self.gumbel_temperature_start - self.gumbel_temperature_end) * self.global_step / self.gumbel_temperature_steps
+        return max(self.gumbel_temperature_end, v)
+
+    def get_observations_count(self) -> int:
+        v = self.observations_count_start + (self.observations_count_end - self.observations_count_start) * self.global_step / self.observations_count_steps
+        return min(self.observations_count_end, math.floor(v))
+
+    def _get_current_lr(self) -> float:
+        return self.lr * self.lr_gamma ** sum(1 for m in self.lr_schedule if self.opt_steps >= m)     # MultiStepLR
+
+    def loss_weights(self) -> Dict[str, float]:
+        lw = self.config["training"]["loss_weights"]
+        return dict(rec=lw["reconstruction_loss_lambda"], states=lw["states_rec_lambda"], entropy=lw["entropy_lambda"],
+                    dir_kl=lw["action_directions_kl_lambda"], mi=lw["action_mutual_information_lambda"],
+                    state_kl=lw["action_state_distribution_kl_lambda"], mi_entropy=self.action_mutual_infromation_entropy_lambda)
+
+    # ---- Trainer.compute_losses (trainer.py:400-550): forward + fused losses + backward ----
+    def compute_losses(self, model, batch, observations_count: int):
+        gt = self.get_ground_truth_observations_count()
+        if gt >= observations_count:
+            gt = observations_count - 1
+        tau = self.get_gumbel_temperature()
+        batch_tuple = batch.to_tuple() if hasattr(batch, "to_tuple") else batch
+        model(batch_tuple, gt, gumbel_temperature=tau, fetch_outputs=False)
+        eng = model.module.last_engine
+        if self.SMOOTH_MI and self.mi_ema is not None:
+            eng.mi_ema = self.mi_ema
+        li = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha)
+        if self.SMOOTH_MI:
+            self.mi_ema = eng.mi_ema
+        w = self.loss_weights()
+        loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
+                     "loss_component_entropy": w["entropy"] * li["entropy"], "loss_component_action_directions_kl_divergence": w["dir_kl"] * li["dir_kl"],
+                     "loss_component_action_mutual_information": w["mi"] * li["mi"], "loss_component_action_state_distribution_kl": w["state_kl"] * li["state_kl"],
+                     "avg_observations_rec_loss": li["rec"], "states_rec_loss": li["states"], "entropy_loss": li["entropy"],
+                     "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
+                     "observations_rec_loss_r0": li["l1_r0"], "observations_rec_loss_r1": li["l1_r1"], "observations_rec_loss_r2": li["l1_r2"],
+                     "ground_truth_observations": gt, "gumbel_temperature": tau, "observations_count": observations_count}
+        return li["total"], loss_info, {}
+
+    def optimizer_step(self, model, world_size: int = 1):
+        """optimizer.zero_grad(); loss.backward(); optimizer.step(); lr_scheduler.step() (trainer.py:584-587): backward already
+        ran inside compute_losses; gradients of all ranks are summed by the caller (one flat all-reduce) before this."""
+        eng = model.module.last_engine
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(eng.grads), torch.zeros_like(eng.grads)
+        eng.adam_m, eng.adam_v = self.adam_m, self.adam_v
+        self.opt_steps += 1
+        eng.adam_step(self.opt_steps, lr=self._get_current_lr(), weight_decay=self.weight_decay, grad_scale=1.0 / world_size)
+
+    def train_epoch(self, model, dataloader=None):
+        """training/trainer.py:552-609 without the wandb plumbing; `dataloader` yields Batch objects / batch tuples."""
+        observations_count = self.get_observations_count()
+        if hasattr(self.dataset, "set_observations_count"):
+            self.dataset.set_observations_count(observations_count)
+        performed = 0
+        for batch in (dataloader if dataloader is not None else self.dataset):
+            if performed > self.config["training"].get("max_steps_per_epoch", 10000):
+                break
+            self.global_step += 1
+            performed += 1
+            if self.get_observations_count() != observations_count:
+                break
+            if self.global_step <= self.config["training"].get("pretraining_steps", 0):
+                raise NotImplementedError("pretraining steps (compute_losses_pretraining) are not part of this round's HIP path")
+            loss, loss_info, _ = self.compute_losses(model, batch, observations_count)
+            self.optimizer_step(model)
+            loss_info["loss"] = loss
+            if self.logger is not None:
+                self.logger.print(f"step: {self.global_step} " + " ".join(f"{k}:{v:.3f}" for k, v in loss_info.items()) + f" lr: {self._get_current_lr():.4f}")
+        return performed
+
+    # ---- checkpoints: same top-level keys as training/trainer.py:100 / smooth_mi_trainer.py:43-45 ----
+    def save_checkpoint(self, model, name=None):
+        root = self.config["logging"]["save_root_directory"]
+        filename = os.path.join(root, "latest.pth.tar" if name is None else f"{name}_.pth.tar")
+        sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
+        state = {"model": sd, "optimizer": {"fused_adam": True, "steps": self.opt_steps, "exp_avg": None if self.adam_m is None else self.adam_m.cpu(),
+                                            "exp_avg_sq": None if self.adam_v is None else self.adam_v.cpu()},
+                 "lr_scheduler": {"milestones": self.lr_schedule, "gamma": self.lr_gamma, "last_epoch": self.opt_steps}, "step": self.global_step}
+        if self.SMOOTH_MI:
+            state["mi_estimator"] = {"matrix_estimator.estimated_matrix": None if self.mi_ema is None else self.mi_ema.cpu()}
+        torch.save(state, filename)
+
+    def load_checkpoint(self, model, name=None):
+        root = self.config["logging"]["save_root_directory"]
+        filename = os.path.join(root, "latest.pth.tar" if name is None else f"{name}.pth.tar")
+        if not os.path.isfile(filename):
+            raise Exception(f"Cannot load model: no checkpoint found at '{filename}'")
+        st = torch.load(filename, map_location="cpu")
+        model.module.load_state_dict(st["model"])
+        opt = st.get("optimizer", {})
+        if opt.get("fused_adam") and opt.get("exp_avg") is not None:
+            dev = model.module._flat.device
+            self.adam_m, self.adam_v, self.opt_steps = opt["exp_avg"].to(dev), opt["exp_avg_sq"].to(dev), opt["steps"]
+        mi = st.get("mi_estimator", {}).get("matrix_estimator.estimated_matrix")
+        if mi is not None:
+            self.mi_ema = mi.to(model.module._flat.device)
+        self.global_step = st["step"]
+
+
+def trainer(config, model, dataset, logger):
+    return Trainer(config, model, dataset, logger)

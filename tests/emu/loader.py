@@ -7,7 +7,9 @@ _emu = None
 
 
 def load_emu():
+    """Simulator build; flagged so Model() accepts CPU tensors in tests."""
     global _emu
     if _emu is None:
         _emu = C.CDLL(B.build_emu())
+        _emu._caddy_emulated = True
     return _emu

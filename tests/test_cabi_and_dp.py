@@ -1,0 +1,86 @@
+"""CPU-side checks: the gfx950 library builds, loads and exports every symbol include/caddy_hip.h declares; host-only entry
+points (parameter table, workspace sizing, argument validation) behave; data-parallel step over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    from playablevideogeneration_amd.csrc import build as B
+    return C.CDLL(B.build())
+
+
+def test_every_declared_symbol_is_exported(hiplib):
+    hdr = open(os.path.join(ROOT, "include", "caddy_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(caddy_\w+)\s*\(", hdr))
+    assert len(names) > 25
+    missing = [n for n in sorted(names) if not hasattr(hiplib, n)]
+    assert not missing, missing
+
+
+def test_host_only_entry_points(hiplib):
+    from playablevideogeneration_amd.engine import CaddyConfig, ParamInfo, _bind
+    from oracle import caddy_oracle as O
+    lib = _bind(hiplib)
+    cfg = CaddyConfig(0, 8, 16, 256, 256, 1, 7, 2, 128, 1, 0, 1, 0.1)
+    assert lib.caddy_trainable_floats(C.byref(cfg)) >= 9856353          # trainable scalars of BAIR-main (+ 16-byte padding)
+    d = O.Dims(variant="main", actions=7, action_dim=2, hidden=128, stacking=1, state_res=(32, 32))
+    ref = {n: tuple(s) for n, s in O.param_table(d) if not n.endswith("num_batches_tracked")}
+    info, got = ParamInfo(), {}
+    for i in range(lib.caddy_param_count(C.byref(cfg))):
+        assert lib.caddy_param_info_get(C.byref(cfg), i, C.byref(info)) == 0
+        got[info.name.decode()] = tuple(info.shape[:info.ndim])
+    assert got == ref                                                     # reference state_dict names and shapes
+    assert 30 * 2 ** 30 < lib.caddy_workspace_bytes(C.byref(cfg)) < 64 * 2 ** 30
+    bad = CaddyConfig(0, 8, 16, 250, 256, 1, 7, 2, 128, 1, 0, 1, 0.1)    # height not a multiple of 16
+    assert lib.caddy_workspace_bytes(C.byref(bad)) == 0 and b"invalid" in lib.caddy_last_error()
+    assert not lib.caddy_ctx_create(C.byref(cfg), None, None, None, 0)   # null buffers are rejected, nothing is launched
+
+
+def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
+    from playablevideogeneration_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from tests.emu.loader import load_emu
+    from playablevideogeneration_amd.engine import Engine
+    from oracle import caddy_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = O.Dims(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1, state_res=(2, 2))
+    P = O.make_params(d, seed=3)
+    eng = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device="cpu", lib=load_emu())
+    eng.load_state_dict(P)
+    g = torch.Generator().manual_seed(100 + rank)
+    obs = torch.rand(1, 3, 3, 16, 16, generator=g) * 2 - 1
+    noise = {"eps_states": torch.randn(3, 1, generator=g), "eps_dirs": torch.randn(2, 1, generator=g), "gumbel_uniform": torch.rand(2, 3, generator=g),
+             "eps_states_rec": torch.randn(3, 1, generator=g), "eps_dirs_rec": torch.randn(2, 1, generator=g)}
+    eng.forward_full(obs, 1, 0.8, noise, training=True, fetch_outputs=False)
+    eng.loss_backward(dict(O.DEFAULT_LOSS_WEIGHTS))
+    local = eng.grads.clone()
+    dist.all_reduce(eng.grads)                      # the N>1 path of bench.py: one flat all-reduce, then Adam with 1/world
+    eng.adam_step(1, grad_scale=1.0 / world)
+    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params[:eng.n_train].clone()}, os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.allclose(r0["reduced"], r0["local"] + r1["local"], atol=1e-6)       # sum over ranks
+    assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["params"], r1["params"])   # trainable replicas stay identical (BN running stats are rank-local, as under nn.DataParallel)
+    assert not torch.equal(r0["local"], r1["local"])                                 # shards really differed
