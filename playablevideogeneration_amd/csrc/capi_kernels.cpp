@@ -20,7 +20,8 @@ int caddy_k_pool2(const TV* in, const TV* out, void* s) { return pw_pool2(*in, *
 int caddy_k_pool2_bwd(const TV* dout, const TV* din, void* s) { return pw_pool2_bwd(*dout, *din, ST(s)); }
 int caddy_k_up2(const TV* in, const TV* out, void* s) { return pw_up2(*in, *out, ST(s)); }
 int caddy_k_up2_bwd(const TV* dout, const TV* din, void* s) { return pw_up2_bwd(*dout, *din, ST(s)); }
-int caddy_k_stats(const TV* x, double* sums, void* s) { return pw_stats(*x, sums, ST(s)); }
+int caddy_k_stats(const TV* x, double* sums, void* s) { return pw_stats(*x, sums, nullptr, ST(s)); }
+int caddy_k_stats_partials(const TV* x, double* sums, double* scratch, void* s) { return pw_stats(*x, sums, scratch, ST(s)); }
 int caddy_k_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
                         float* mean, float* invstd, float* scale, float* shift, void* s) {
     return pw_bn_finalize(sums, count, gamma, beta, rmean, rvar, C, training, mean, invstd, scale, shift, ST(s));
@@ -29,7 +30,7 @@ int caddy_k_bn_apply(const TV* x, const float* scale, const float* shift, const 
     return pw_bn_apply(*x, scale, shift, x2, scale2, shift2, act, *out, ST(s));
 }
 int caddy_k_bn_bwd_reduce(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, double* sums, void* s) {
-    return pw_bn_bwd_reduce(*dout, outm, *x, mean, invstd, sums, ST(s));
+    return pw_bn_bwd_reduce(*dout, outm, *x, mean, invstd, sums, nullptr, ST(s));
 }
 int caddy_k_bn_bwd_apply(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const double* sums,
                          const TV* dx, float* dgamma, float* dbeta, void* s) {

@@ -50,6 +50,7 @@ struct ConvArgs {
     long out_sn;
     int out_ld;
     int accumulate;     // out += result
+    int splitk;         // set by the launcher: K range split across blockIdx.z (atomic accumulation; accumulate mode only)
 };
 
 // wgrad: dwp[tap][o][k] += sum_p dY[p][o] * A[p+tap][k]   (A = concatenation of the forward sources)
@@ -69,4 +70,6 @@ struct WgradArgs {
 
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
-int conv_pick_bn(int cout);   // N-tile (32/64/128) the launcher will use for this Cout
+int conv_pick_bn(int cout);
+int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
+int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st);   // N-tile (32/64/128) the launcher will use for this Cout

@@ -49,14 +49,40 @@ __device__ __forceinline__ float4 load_src4(const SegRef& sg, int kq, bool valid
     return load4_masked(q, c, sg.C);
 }
 
+template <int A_PER, int B_PER>
+struct TileRegs { float4 a[A_PER]; float4 b[B_PER]; };
+
+// global -> registers for K-iteration `it` (tap, 16-channel chunk); returned by value so the tile stays in VGPRs
+template <int A_PER, int B_PER, int BN>
+__device__ __forceinline__ TileRegs<A_PER, B_PER> conv_gload(const ConvArgs& a, int it, int nchunks, int R, int n0, int tid, int kq,
+                                                             const int* pn, const int* py, const int* px, const bool* pv) {
+    TileRegs<A_PER, B_PER> t;
+    int tap = it / nchunks, ch = it - tap * nchunks;
+    int dy = tap / a.KS - R, dx = tap % a.KS - R;
+    SegRef sg = find_seg(a.src, a.nsrc, ch * BK);
+#pragma unroll
+    for (int i = 0; i < A_PER; i++) {
+        int yy = py[i] + dy, xx = px[i] + dx;
+        bool ok = pv[i] && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        t.a[i] = load_src4(sg, kq, ok, pn[i], yy, xx, a.W);
+    }
+    const float* wt = a.wp + ((long)tap * a.Cout_pad + n0) * a.Ktot + ch * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < B_PER; i++) {
+        int r = (tid >> 2) + 64 * i;
+        t.b[i] = (r < BN) ? *reinterpret_cast<const float4*>(wt + (long)r * a.Ktot) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return t;
+}
+
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int A_PER = BM * 4 / 256;
+    constexpr int A_PER = (BM * 4 + 255) / 256;
     constexpr int B_PER = (BN * 4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ float As[BM * LDSK];
-    __shared__ float Bs[BN * LDSK];
+    __shared__ float As[2][BM * LDSK];
+    __shared__ float Bs[2][BN * LDSK];
     __shared__ long rowoff[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,8 +98,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     bool pv[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; i++) {
-        long p = p0 + (tid >> 2) + 64 * i;
-        pv[i] = p < P;
+        int r = (tid >> 2) + 64 * i;
+        long p = p0 + r;
+        pv[i] = (r < BM) && p < P;
         long pp = pv[i] ? p : 0;
         pn[i] = (int)(pp / HW);
         int rem = (int)(pp - (long)pn[i] * HW);
@@ -87,27 +114,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
         rowoff[tid] = off;
     }
 
+    // split-K: blockIdx.z owns a contiguous range of the (tap, chunk) iterations; partial sums are combined with atomics
     const int nchunks = a.Ktot / BK;
-    const int niter = a.KS * a.KS * nchunks;
-    float4 ra[A_PER], rb[B_PER];
-
-    auto gload = [&](int it) {
-        int tap = it / nchunks, ch = it - tap * nchunks;
-        int dy = tap / a.KS - R, dx = tap % a.KS - R;
-        SegRef sg = find_seg(a.src, a.nsrc, ch * BK);
-#pragma unroll
-        for (int i = 0; i < A_PER; i++) {
-            int yy = py[i] + dy, xx = px[i] + dx;
-            bool ok = pv[i] && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            ra[i] = load_src4(sg, kq, ok, pn[i], yy, xx, a.W);
-        }
-        const float* wt = a.wp + ((long)tap * a.Cout_pad + n0) * a.Ktot + ch * BK + kq * 4;
-#pragma unroll
-        for (int i = 0; i < B_PER; i++) {
-            int r = (tid >> 2) + 64 * i;
-            if (r < BN) rb[i] = *reinterpret_cast<const float4*>(wt + (long)r * a.Ktot);
-        }
-    };
+    const int niter_all = a.KS * a.KS * nchunks;
+    const int per = (niter_all + a.splitk - 1) / a.splitk;
+    const int it0 = blockIdx.z * per;
+    const int it1 = (it0 + per < niter_all) ? it0 + per : niter_all;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -117,26 +129,33 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    gload(0);
-    for (int it = 0; it < niter; it++) {
+    TileRegs<A_PER, B_PER> t;
+    if (it0 < it1) t = conv_gload<A_PER, B_PER, BN>(a, it0, nchunks, R, n0, tid, kq, pn, py, px, pv);
+    int buf = 0;
+    for (int it = it0; it < it1; it++, buf ^= 1) {
+        // LDS double buffer: tile `it` goes to buffer `buf`; the single barrier below also orders the previous iteration's
+        // fragment reads of buffer `buf^1` against the NEXT iteration's stores into it
 #pragma unroll
-        for (int i = 0; i < A_PER; i++) *reinterpret_cast<float4*>(&As[((tid >> 2) + 64 * i) * LDSK + kq * 4]) = ra[i];
+        for (int i = 0; i < A_PER; i++) {
+            int r = (tid >> 2) + 64 * i;
+            if (r < BM) *reinterpret_cast<float4*>(&As[buf][r * LDSK + kq * 4]) = t.a[i];
+        }
 #pragma unroll
         for (int i = 0; i < B_PER; i++) {
             int r = (tid >> 2) + 64 * i;
-            if (r < BN) *reinterpret_cast<float4*>(&Bs[r * LDSK + kq * 4]) = rb[i];
+            if (r < BN) *reinterpret_cast<float4*>(&Bs[buf][r * LDSK + kq * 4]) = t.b[i];
         }
         __syncthreads();
-        if (it + 1 < niter) gload(it + 1);
+        if (it + 1 < it1) t = conv_gload<A_PER, B_PER, BN>(a, it + 1, nchunks, R, n0, tid, kq, pn, py, px, pv);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; i++)
-                fa[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -147,8 +166,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
     }
+    __syncthreads();   // rowoff visibility when the K range is empty
 
     // epilogue: D fragment map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -166,8 +185,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
                 float v = acc[i][j][r] + bv;
                 if (a.act == 1) v = tanhf(v);
                 float* o = a.out + off + col;
-                if (a.accumulate) v += *o;
-                *o = v;
+                if (a.splitk > 1) atomicAdd(o, v);
+                else { if (a.accumulate) v += *o; *o = v; }
             }
         }
     }
@@ -307,7 +326,8 @@ int conv_pick_bn(int cout) {
     return best;
 }
 
-int conv_fwd_launch(const ConvArgs& a, hipStream_t st) {
+int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
     if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC || (a.KS != 1 && a.KS != 3 && a.KS != 7)) return -1;
     int kt = 0;
     for (int s = 0; s < a.nsrc; s++) {
@@ -317,8 +337,29 @@ int conv_fwd_launch(const ConvArgs& a, hipStream_t st) {
     if (kt != a.Ktot || (a.out_ld < a.Cout)) return -1;
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
+    a.splitk = 1;
+    if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
     long P = (long)a.N * a.H * a.W;
-    dim3 grid(cdiv(P, 128), a.Cout_pad / bn);
+    // tile choice: 128-row tiles when they fill the chip (256 CUs x ~3 resident workgroups), otherwise 64x64 tiles; the
+    // remaining deficit of accumulating launches (dgrad) is covered by splitting K across blockIdx.z (fp32 atomics).
+    long blocks128 = (long)cdiv(P, 128) * (a.Cout_pad / bn);
+    bool small = (bn >= 64) && blocks128 < 512;
+    int niter = a.KS * a.KS * (a.Ktot / BK);
+    a.splitk = 1;
+    long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
+    if (a.accumulate && a.act == 0 && a.bias == nullptr && blocks < 384 && niter >= 16) {
+        int want = (int)((512 + blocks - 1) / blocks);
+        int maxs = niter / 8;
+        a.splitk = want < maxs ? want : maxs;
+        if (a.splitk > 8) a.splitk = 8;
+        if (a.splitk < 1) a.splitk = 1;
+    }
+    if (small) {
+        dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
+        hipLaunchKernelGGL((k_conv_fwd<1, 1, 2, 2>), grid, dim3(256), 0, st, a);
+        return 0;
+    }
+    dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_fwd<2, 1, 2, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1>), grid, dim3(256), 0, st, a);
@@ -330,6 +371,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC) return -1;
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
+    if (conv_thin_wgrad_try(a, st) == 1) return 0;
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
     int ktiles = cdiv(a.Ktot, 128);

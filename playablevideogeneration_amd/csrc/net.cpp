@@ -194,6 +194,7 @@ void build_layers(caddy_ctx* c) {
     }
     c->centroids = PP(c, "centroid_estimator.estimated_centroids");
     c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
+    c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
 }
 }  // namespace
 
@@ -307,7 +308,7 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     bool dry = c->dry;
     if (c->training) {
         if (!dry) hipMemsetAsync(s.sums, 0, sizeof(double) * 2 * bn.C, c->stream);
-        if (!dry) c->ck(pw_stats(dv(x), s.sums, c->stream), "pw_stats");
+        if (!dry) c->ck(pw_stats(dv(x), s.sums, c->red_scratch, c->stream), "pw_stats");
         if (!dry) bn.calls++;
     }
     if (!dry) c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, c->training ? 1 : 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
@@ -326,11 +327,11 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             TV om = dv(out);
             const TV* omp = actf ? &om : nullptr;
             if (!dry) hipMemsetAsync(s1.sums, 0, sizeof(double) * 2 * b1->C, stream);
-            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, stream));
+            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, stream));
             RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), b1->dgamma, b1->dbeta, stream));
             if (has2 && b2) {
                 if (!dry) hipMemsetAsync(s2.sums, 0, sizeof(double) * 2 * b2->C, stream);
-                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, stream));
+                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, stream));
                 RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), b2->dgamma, b2->dbeta, stream));
             } else if (has2) {
                 if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream));

@@ -269,6 +269,7 @@ struct FNhwcToNchw {
 // MODE 3: outf[c] += sum x                                           (bias gradient)
 struct RedArgs {
     TV x, dout, outm; const float *mean, *invstd; double* sums; float* outf; long out_sn; float scale; int act; int pix_per_block;
+    double* partials;   // MODE 0/1: when set, block b writes its sums to partials[b][2C] (no atomics); k_sum_partials folds them
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
@@ -312,11 +313,22 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
         int c = j * 4;
         for (int e = 0; e < 4; e++) {
             if (c + e >= C) break;
-            if (MODE <= 1) { atomicAdd(&a.sums[2 * (c + e)], s[e]); atomicAdd(&a.sums[2 * (c + e) + 1], s[4 + e]); }
+            if (MODE <= 1) {
+                if (a.partials) { double* pp = a.partials + (long)blockIdx.x * 2 * C; pp[2 * (c + e)] = s[e]; pp[2 * (c + e) + 1] = s[4 + e]; }
+                else { atomicAdd(&a.sums[2 * (c + e)], s[e]); atomicAdd(&a.sums[2 * (c + e) + 1], s[4 + e]); }
+            }
             else if (MODE == 2) atomicAdd(&a.outf[(long)blockIdx.y * a.out_sn + c + e], (float)(s[e] * a.scale));
             else atomicAdd(&a.outf[c + e], (float)s[e]);
         }
     }
+}
+
+__global__ void k_sum_partials(const double* partials, int nb, int n2c, double* sums) {   // sums[i] += sum_b partials[b][i]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2c) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; b++) s += partials[(long)b * n2c + i];
+    sums[i] += s;
 }
 
 template <int MODE>
@@ -329,10 +341,13 @@ int run_reduce(RedArgs a, hipStream_t st) {
         a.pix_per_block = ppb;
         hipLaunchKernelGGL((k_reduce<MODE>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
     } else {
-        long ppb = (P + 1023) / 1024;
+        long maxb = (MODE <= 1 && a.partials) ? RED_MAX_BLOCKS : 1024;
+        long ppb = (P + maxb - 1) / maxb;
         if (ppb < 64) ppb = 64;
         a.pix_per_block = (int)ppb;
-        hipLaunchKernelGGL((k_reduce<MODE>), dim3(cdiv(P, ppb)), dim3(256), 0, st, a);
+        int nb = cdiv(P, ppb);
+        hipLaunchKernelGGL((k_reduce<MODE>), dim3(nb), dim3(256), 0, st, a);
+        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 128)), dim3(128), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums);
     }
     return 0;
 }
@@ -385,7 +400,7 @@ int pw_pool2(const TV& in, const TV& out, hipStream_t st) { return run_map((long
 int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din}, st); }
 int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
 int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
-int pw_stats(const TV& x, double* sums, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; return run_reduce<0>(a, st); }
+int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch; return run_reduce<0>(a, st); }
 int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
                    float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
     hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, (double)count, gamma, beta, rmean, rvar, C, training, 0.1f, 1e-5f, mean, invstd, scale, shift);
@@ -395,8 +410,8 @@ int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x
     FBnApply f{x, x2 ? *x2 : x, out, scale, shift, scale2, shift2, x.H * x.W, x2 ? 1 : 0, act};
     return run_map((long)x.N * x.H * x.W, x.C, f, st);
 }
-int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, hipStream_t st) {
-    RedArgs a{}; a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, hipStream_t st) {
+    RedArgs a{}; a.partials = scratch; a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
     return run_reduce<1>(a, st);
 }
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,

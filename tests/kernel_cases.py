@@ -213,8 +213,11 @@ def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed
     def run_bn(xt, gm, bt, rmean, rvar):
         xb = nhwc(xt.detach(), dev=dev)
         sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
-        if training:
+        if training and seed % 2 == 0:
             assert lib.caddy_k_stats(C.byref(tv(xb, Cc)), P(sums), st) == 0
+        elif training:                          # atomics-free variant: per-block partials + second-stage sum
+            scratch = torch.zeros(512 * 2 * Cc, dtype=torch.float64, device=dev)
+            assert lib.caddy_k_stats_partials(C.byref(tv(xb, Cc)), P(sums), P(scratch), st) == 0
         o = [torch.zeros(Cc, device=dev) for _ in range(4)]
         gmd, btd, rmd, rvd = gm.detach().to(dev), bt.detach().to(dev), rmean.to(dev), rvar.to(dev)
         assert lib.caddy_k_bn_finalize(P(sums), C.c_long(M), P(gmd), P(btd), P(rmd), P(rvd), Cc, training, *[P(t) for t in o], st) == 0

@@ -13,6 +13,11 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=4, W=4, segs=[(20, 0), (9, 1), (24, 0)], Cout=64, KS=3, nw=4, bias=True),
     dict(N=3, H=8, W=8, segs=[(32, 0)], Cout=65, KS=1),
     dict(N=2, H=12, W=12, segs=[(8, 0), (4, 1)], Cout=136, KS=3),
+    dict(N=2, H=10, W=36, segs=[(3, 0)], Cout=16, KS=3),                       # E stem (thin-in), tile overhang in x and y
+    dict(N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3),                       # stem with observation_stacking = 4
+    dict(N=2, H=8, W=40, segs=[(64, 0)], Cout=3, KS=3, bias=True, act=1),      # FinalBlock k3 (thin-out)
+    dict(N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1),     # FinalBlock k7
+    dict(N=2, H=8, W=8, segs=[(48, 0)], Cout=9, KS=3),                         # shape of the broadcast-input dgrad (OUT = K + Da)
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)
@@ -25,6 +30,7 @@ def test_pool_upsample():
 @pytest.mark.parametrize("second,act,training", [("bn", 1, 1), ("plain", 1, 1), (None, 0, 1), (None, 1, 0), ("plain", 0, 1)])
 def test_batchnorm(second, act, training):
     K.bn_case(load_emu(), "cpu", second=second, act=act, training=training)
+    K.bn_case(load_emu(), "cpu", second=second, act=act, training=training, seed=1, N=2, H=9, W=8)
 
 
 def test_lstm_gates():

@@ -23,6 +23,12 @@ def lib():
     dict(N=4, H=32, W=32, segs=[(64, 0), (9, 1), (128, 0)], Cout=512, KS=3, nw=4, bias=True, tol=5e-5),   # BAIR LSTM0 shape
     dict(N=2, H=64, W=64, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, tol=5e-5),
     dict(N=2, H=48, W=40, segs=[(64, 0)], Cout=32, KS=3, tol=5e-5),
+    dict(N=2, H=10, W=36, segs=[(3, 0)], Cout=16, KS=3),
+    dict(N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3),
+    dict(N=2, H=8, W=40, segs=[(64, 0)], Cout=3, KS=3, bias=True, act=1),
+    dict(N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1),
+    dict(N=2, H=8, W=8, segs=[(48, 0)], Cout=9, KS=3),
+    dict(N=4, H=64, W=64, segs=[(3, 0)], Cout=16, KS=3, tol=5e-5),
 ])
 def test_conv(lib, kw):
     K.conv_case(lib, "cuda", **kw)

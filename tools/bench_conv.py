@@ -8,7 +8,9 @@ from playablevideogeneration_amd._lib import ConvArgs, ConvSrc, WgradArgs, round
 
 lib = _lib.load()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-SHAPES = [  # name, N, H, W, Cin, Cout, KS
+SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run the forward kernel in accumulate mode)
+    ("dgrad lstm1-h 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("dgrad lstm0-h 512->128 @32", 8, 32, 32, 512, 128, 3),
+    ("same0 144->256 @32", 8, 32, 32, 144, 256, 3), ("up 272->128 @16", 8, 16, 16, 272, 128, 3),
     ("lstm0 201->512 @32", 8, 32, 32, 208, 512, 3), ("lstm1 521->1024 @16", 8, 16, 16, 528, 1024, 3),
     ("dec 128->128 @64", 8, 64, 64, 128, 128, 3), ("dec 128->64 @128", 8, 128, 128, 128, 64, 3),
     ("dec 64->64 @128", 8, 128, 128, 64, 64, 3), ("dec 64->32 @256", 8, 256, 256, 64, 32, 3),
@@ -24,6 +26,7 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     a.src[0] = ConvSrc(x.data_ptr(), H * W * Cin, Cin, Cin, Cin, 0)
     a.nsrc, a.N, a.H, a.W, a.KS, a.wp, a.Ktot, a.Cout, a.Cout_pad = 1, N, H, W, KS, wp.data_ptr(), Cin, Cout, cp
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out.shape[3], out.shape[3]
+    a.accumulate = 1 if name.startswith('dgrad') else 0
     dy = torch.randn(N, H, W, round_up(Cout, 4), device="cuda")
     dwp = torch.zeros_like(wp)
     wa = WgradArgs()
