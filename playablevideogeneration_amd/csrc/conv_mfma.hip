@@ -14,6 +14,7 @@
 // fp32 MFMA keeps the result bitwise a k-ordered fmaf chain, which is what holds the 1e-5 frame-MSE parity bound over
 // 15 recurrent steps (hard part 1); roofline for this kernel = 157.3 TFLOP/s fp32 matrix peak.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BNk == 128, "loader assumes a 128-wide k tile");
     constexpr int Y_PER = (BP * BMo / 4 + 255) / 256;
-    __shared__ float Ys[BP * BMo];
-    __shared__ float Xs[BP * BNk];
+    __shared__ float Ys[2][BP * BMo];
+    __shared__ float Xs[2][BP * BNk];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -270,14 +271,15 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
     };
 
     if (ps < pe) gload(ps);
-    for (long pb = ps; pb < pe; pb += BP) {
+    int buf = 0;
+    for (long pb = ps; pb < pe; pb += BP, buf ^= 1) {   // LDS double buffer: one barrier per 16-pixel step
 #pragma unroll
-        for (int i = 0; i < 2; i++) *reinterpret_cast<float4*>(&Xs[xp * BNk + (wave + 4 * i) * BK + xq * 4]) = rx[i];
+        for (int i = 0; i < 2; i++) *reinterpret_cast<float4*>(&Xs[buf][xp * BNk + (wave + 4 * i) * BK + xq * 4]) = rx[i];
 #pragma unroll
         for (int i = 0; i < Y_PER; i++) {
             int idx = tid + 256 * i;
             int pr = idx / (BMo / 4), q = idx - pr * (BMo / 4);
-            if (pr < BP) *reinterpret_cast<float4*>(&Ys[pr * BMo + q * 4]) = ry[i];
+            if (pr < BP) *reinterpret_cast<float4*>(&Ys[buf][pr * BMo + q * 4]) = ry[i];
         }
         __syncthreads();
         if (pb + BP < pe) gload(pb + BP);
@@ -286,15 +288,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
             float fa[TM], fb[TN];
             int prow = 2 * s + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < TM; i++) fa[i] = Ys[prow * BMo + wm * 32 * TM + i * 32 + (lane & 31)];
+            for (int i = 0; i < TM; i++) fa[i] = Ys[buf][prow * BMo + wm * 32 * TM + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < TN; j++) fb[j] = Xs[prow * BNk + wn * 32 * TN + j * 32 + (lane & 31)];
+            for (int j = 0; j < TN; j++) fb[j] = Xs[buf][prow * BNk + wn * 32 * TN + j * 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
 
 #pragma unroll
@@ -310,6 +311,83 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
                 float* d = a.dwp + ((long)tap * a.Cout_pad + o) * a.Ktot + k;
                 if (a.slabs > 1) atomicAdd(d, acc[i][j][r]);
                 else *d += acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad for narrow layers (Cout <= 32 and K <= 64: E's 16/32-channel blocks, D's last UpBlock).  The generic kernel's
+// 128-wide k tile would be mostly padding there.  Here a workgroup owns a 8x32 pixel tile: dY and the X halo tile are
+// staged in LDS ONCE and reused by all taps; each wave owns the taps {w, w+4, w+8} and keeps one 32(o) x 32*KT(k)
+// accumulator per tap in registers across many tiles (grid-stride), then flushes with atomics.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int STW = 32, STH = 8;
+template <int KT>
+__global__ __launch_bounds__(256) void k_conv_wgrad_small(WgradArgs a, int tiles_x, int tiles_y) {
+    constexpr int KC = 32 * KT;                       // channels staged per pixel
+    __shared__ float Xh[(STH + 2) * (STW + 2) * KC];  // halo tile [pixel][KC]   (3x3 or 1x1 only)
+    __shared__ float Yt[STH * STW * 32];              // dY tile   [pixel][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = a.KS * a.KS, R = a.KS >> 1, HWD = STW + 2 * R, HHT = STH + 2 * R;
+    const ConvSrc s = a.src[0];
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+    f32x16 acc[3][KT];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int j = 0; j < KT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][j][r] = 0.f;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int y0 = (rem / tiles_x) * STH, x0 = (rem % tiles_x) * STW;
+        for (int idx = tid; idx < HHT * HWD * (KC / 4); idx += 256) {
+            int q = idx % (KC / 4), pix = idx / (KC / 4);
+            int hy = pix / HWD, hx = pix - hy * HWD;
+            int y = y0 - R + hy, x = x0 - R + hx, c = q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W && c < s.C) v = load4_masked(s.p + (long)n * s.sn + ((long)y * a.W + x) * s.ld + c, c, s.C);
+            *reinterpret_cast<float4*>(&Xh[pix * KC + c]) = v;
+        }
+        for (int idx = tid; idx < STH * STW * 8; idx += 256) {
+            int q = idx & 7, pix = idx >> 3;
+            int y = y0 + pix / STW, x = x0 + pix % STW, c = q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < a.H && x < a.W && c < a.Cout) v = load4_masked(a.dy + (long)n * a.dy_sn + ((long)y * a.W + x) * a.dy_ld + c, c, a.Cout);
+            *reinterpret_cast<float4*>(&Yt[pix * 32 + c]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            int tap = wave + 4 * t;
+            if (tap < taps) {
+                int dy = tap / a.KS, dx = tap - dy * a.KS;
+                for (int p = 0; p < STH * STW; p += 2) {
+                    int pp = p + (lane >> 5);                 // MFMA k index = pixel
+                    int py = pp / STW, px = pp - py * STW;
+                    float fa = Yt[pp * 32 + (lane & 31)];     // A[row = o][k = pixel]
+                    const float* xr = &Xh[((py + dy) * HWD + px + dx) * KC + (lane & 31)];
+#pragma unroll
+                    for (int j = 0; j < KT; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, xr[32 * j], acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        int tap = wave + 4 * t;
+        if (tap >= taps) continue;
+#pragma unroll
+        for (int j = 0; j < KT; j++) {
+            int k = j * 32 + (lane & 31);
+            if (k >= a.Ktot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (o < a.Cout) atomicAdd(a.dwp + ((long)tap * a.Cout_pad + o) * a.Ktot + k, acc[t][j][r]);
             }
         }
     }
@@ -344,6 +422,10 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     // remaining deficit of accumulating launches (dgrad) is covered by splitting K across blockIdx.z (fp32 atomics).
     long blocks128 = (long)cdiv(P, 128) * (a.Cout_pad / bn);
     bool small = (bn >= 64) && blocks128 < 512;
+    static const int force_tile = getenv("CADDY_FORCE_TILE") ? atoi(getenv("CADDY_FORCE_TILE")) : 0;   // tuning aid: 1 = 128-row tiles, 2 = 64x64
+    if (force_tile == 1) small = false;
+    if (force_tile == 2 && bn >= 64) small = true;
+    static const int force_splitk = getenv("CADDY_FORCE_SPLITK") ? atoi(getenv("CADDY_FORCE_SPLITK")) : 0;
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
@@ -354,6 +436,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         if (a.splitk > 8) a.splitk = 8;
         if (a.splitk < 1) a.splitk = 1;
     }
+    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr) a.splitk = force_splitk;
     if (small) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
         hipLaunchKernelGGL((k_conv_fwd<1, 1, 2, 2>), grid, dim3(256), 0, st, a);
@@ -374,6 +457,14 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (conv_thin_wgrad_try(a, st) == 1) return 0;
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
+    if (a.nsrc == 1 && !a.src[0].bcast && a.Cout <= 32 && a.Ktot <= 64 && a.KS <= 3 && P >= 4096) {   // narrow layers
+        int tx = cdiv(a.W, STW), ty = cdiv(a.H, STH);
+        long ntiles = (long)a.N * tx * ty;
+        int grid = (int)(ntiles < 512 ? ntiles : 512);
+        if (a.Ktot <= 32) hipLaunchKernelGGL((k_conv_wgrad_small<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+        else hipLaunchKernelGGL((k_conv_wgrad_small<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+        return 0;
+    }
     int ktiles = cdiv(a.Ktot, 128);
     int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
     if (a.Cout_pad % bmo) bmo = 32;

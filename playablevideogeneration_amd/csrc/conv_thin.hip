@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(ThinWgradArgs a) {
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     if (a.nsrc != 1 || a.src[0].bcast || a.splitk > 1) return 0;
     dim3 grid(cdiv(a.W, TW), cdiv(a.H, TH), a.N);
-    if (a.Cout <= 12 && a.src[0].C >= 16) {
+    // OUT<=4: FinalBlock heads; OUT<=12 only with a narrow input (dgrad of the stem).  The 9-channel broadcast-input dgrad of R
+    // (IN up to 1024 channels on 16x16 maps) stays on the MFMA kernel: one thread per pixel would leave the chip empty.
+    if ((a.Cout <= 4 && a.src[0].C >= 16) || (a.Cout <= 12 && a.src[0].C >= 16 && a.src[0].C <= 32)) {
         if (a.Cout <= 4) hipLaunchKernelGGL((k_conv_thin_out<4>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_thin_out<12>), grid, dim3(256), 0, st, a);
         return 1;
@@ -218,7 +220,7 @@ int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st) {
     ThinWgradArgs a{};
     a.N = w.N; a.H = w.H; a.W = w.W; a.KS = w.KS; a.Cout_pad = w.Cout_pad; a.Ktot = w.Ktot; a.dwp = w.dwp;
     a.tiles_x = cdiv(w.W, TW); a.tiles_y = cdiv(w.H, TH);
-    if (w.Cout <= 12 && w.src[0].C >= 16) {          // thin = dY, wide = X
+    if ((w.Cout <= 4 && w.src[0].C >= 16) || (w.Cout <= 12 && w.src[0].C >= 16 && w.src[0].C <= 32)) {          // thin = dY, wide = X
         a.swap = 0; a.thin = w.dy; a.thin_sn = w.dy_sn; a.thin_ld = w.dy_ld; a.TC = w.Cout;
         a.wide = w.src[0].p; a.wide_sn = w.src[0].sn; a.wide_ld = w.src[0].ld; a.WC = w.src[0].C;
     } else if (w.src[0].C <= 12) {                    // thin = X, wide = dY

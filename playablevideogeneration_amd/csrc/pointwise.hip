@@ -323,12 +323,13 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
     }
 }
 
-__global__ void k_sum_partials(const double* partials, int nb, int n2c, double* sums) {   // sums[i] += sum_b partials[b][i]
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2c) return;
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums) {
+    // sums[i] += sum_b partials[b][i]; one wave per output index (4 per workgroup), lanes stride over the blocks
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int b = 0; b < nb; b++) s += partials[(long)b * n2c + i];
-    sums[i] += s;
+    if (i < n2c) for (int b = lane; b < nb; b += 64) s += partials[(long)b * n2c + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (i < n2c && lane == 0) sums[i] += s;
 }
 
 template <int MODE>
@@ -347,7 +348,7 @@ int run_reduce(RedArgs a, hipStream_t st) {
         a.pix_per_block = (int)ppb;
         int nb = cdiv(P, ppb);
         hipLaunchKernelGGL((k_reduce<MODE>), dim3(nb), dim3(256), 0, st, a);
-        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 128)), dim3(128), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums);
+        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums);
     }
     return 0;
 }

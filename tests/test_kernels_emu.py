@@ -18,6 +18,9 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=8, W=40, segs=[(64, 0)], Cout=3, KS=3, bias=True, act=1),      # FinalBlock k3 (thin-out)
     dict(N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1),     # FinalBlock k7
     dict(N=2, H=8, W=8, segs=[(48, 0)], Cout=9, KS=3),                         # shape of the broadcast-input dgrad (OUT = K + Da)
+    dict(N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3),                      # narrow-layer wgrad kernel (K<=32), tile overhang
+    dict(N=2, H=33, W=64, segs=[(64, 0)], Cout=32, KS=3),                      # narrow-layer wgrad kernel, KT=2
+    dict(N=2, H=48, W=48, segs=[(16, 0)], Cout=32, KS=1),                      # 1x1 down-sample conv
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)

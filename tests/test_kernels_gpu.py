@@ -29,6 +29,9 @@ def lib():
     dict(N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1),
     dict(N=2, H=8, W=8, segs=[(48, 0)], Cout=9, KS=3),
     dict(N=4, H=64, W=64, segs=[(3, 0)], Cout=16, KS=3, tol=5e-5),
+    dict(N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3),
+    dict(N=2, H=33, W=64, segs=[(64, 0)], Cout=32, KS=3, tol=5e-5),
+    dict(N=2, H=48, W=48, segs=[(16, 0)], Cout=32, KS=1),
 ])
 def test_conv(lib, kw):
     K.conv_case(lib, "cuda", **kw)

@@ -8,6 +8,9 @@ from playablevideogeneration_amd._lib import ConvArgs, ConvSrc, WgradArgs, round
 
 lib = _lib.load()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+import os
+print("CADDY_FORCE_TILE =", os.environ.get("CADDY_FORCE_TILE"), "CADDY_FORCE_SPLITK =", os.environ.get("CADDY_FORCE_SPLITK"))
+ONLY = os.environ.get("BENCH_ONLY")
 SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run the forward kernel in accumulate mode)
     ("dgrad lstm1-h 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("dgrad lstm0-h 512->128 @32", 8, 32, 32, 512, 128, 3),
     ("same0 144->256 @32", 8, 32, 32, 144, 256, 3), ("up 272->128 @16", 8, 16, 16, 272, 128, 3),
@@ -16,7 +19,11 @@ SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run th
     ("dec 64->64 @128", 8, 128, 128, 64, 64, 3), ("dec 64->32 @256", 8, 256, 256, 64, 32, 3),
     ("final 32->3 k7 @256", 8, 256, 256, 32, 3, 7), ("enc 16->16 @128", 128, 128, 128, 16, 16, 3),
 ]
+SHAPES += [("dgrad lstm0-x 512->64 @32", 8, 32, 32, 512, 64, 3), ("dgrad lstm1-x 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("same2 144->128 @32", 8, 32, 32, 144, 128, 3),
+           ("A res0 64->128 @32x128f", 128, 32, 32, 64, 128, 3), ("A res1 128->128 @16x128f", 128, 16, 16, 128, 128, 3), ("E 32->64 @64x128f", 128, 64, 64, 32, 64, 3)]
 for name, N, H, W, Cin, Cout, KS in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(N, H, W, Cin, device="cuda")
     bn = lib.caddy_k_conv_pick_bn(Cout)
     cp = round_up(Cout, bn)
