@@ -21,11 +21,13 @@ __device__ __forceinline__ float4 ldmask(const float* q, int c, int C) {
     return v;
 }
 
-// stage channels [c0, c0+16) of the (TH+2R)x(TW+2R) halo tile of `src` (zero padded) into lds[pix][PITCH]
+// stage channels [c0, c0+4*Q4) of the (TH+2R)x(TW+2R) halo tile of `src` (zero padded) into lds[pix][4*Q4+4]
+template <int Q4 = 4>
 __device__ __forceinline__ void stage_halo(float* lds, const float* base, int ld, int C, int c0, int H, int W, int y0, int x0, int R, int tid) {
+    constexpr int PITCH = 4 * Q4 + 4;
     const int HWD = TW + 2 * R, HHT = TH + 2 * R;
-    for (int idx = tid; idx < HHT * HWD * 4; idx += 256) {
-        int q = idx & 3, pix = idx >> 2;
+    for (int idx = tid; idx < HHT * HWD * Q4; idx += 256) {
+        int q = idx % Q4, pix = idx / Q4;
         int hy = pix / HWD, hx = pix - hy * HWD;
         int y = y0 - R + hy, x = x0 - R + hx;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void k_conv_thin_out(ConvArgs a) {
 #pragma unroll
     for (int o = 0; o < CO; o++) acc[o] = 0.f;
     for (int c0 = 0; c0 < s.C; c0 += CK) {
-        stage_halo(lds, base, s.ld, s.C, c0, a.H, a.W, y0, x0, R, tid);
+        stage_halo<4>(lds, base, s.ld, s.C, c0, a.H, a.W, y0, x0, R, tid);
         __syncthreads();
         for (int tap = 0; tap < a.KS * a.KS; tap++) {
             int dy = tap / a.KS, dx = tap - dy * a.KS;
@@ -78,16 +80,19 @@ __global__ __launch_bounds__(256) void k_conv_thin_out(ConvArgs a) {
     }
 }
 
-// IN <= 12 channels (K = 16): each thread computes one pixel x 16 output channels; blockIdx.z = n * groups + output group
+// Narrow input (IN <= 4*Q4 channels, K = Ktot <= 32): each thread computes one pixel x 16 output channels on the VALUs with no
+// channel padding; blockIdx.z = n * groups + output group.  Q4 = 4 (pitch 20) also serves 7x7 heads' dgrad; Q4 = 8 (pitch 36) is 3x3/1x1 only.
+template <int Q4, int MAXR>
 __global__ __launch_bounds__(256) void k_conv_thin_in(ConvArgs a, int groups) {
-    __shared__ float lds[(TH + 6) * (TW + 6) * PITCH];
+    constexpr int PITCH = 4 * Q4 + 4;
+    __shared__ float lds[(TH + 2 * MAXR) * (TW + 2 * MAXR) * PITCH];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     const int n = blockIdx.z / groups, og = blockIdx.z - n * groups;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
     const int R = a.KS >> 1, HWD = TW + 2 * R;
     const ConvSrc s = a.src[0];
     const int IC4 = (s.C + 3) >> 2;
-    stage_halo(lds, s.p + (long)n * s.sn, s.ld, s.C, 0, a.H, a.W, y0, x0, R, tid);
+    stage_halo<Q4>(lds, s.p + (long)n * s.sn, s.ld, s.C, 0, a.H, a.W, y0, x0, R, tid);
     __syncthreads();
     float acc[16];
 #pragma unroll
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(ThinWgradArgs a) {
         int n = (int)(tile / (a.tiles_y * a.tiles_x));
         int rem = (int)(tile - (long)n * a.tiles_y * a.tiles_x);
         int y0 = (rem / a.tiles_x) * TH, x0 = (rem % a.tiles_x) * TW;
-        stage_halo(wl, a.wide + (long)n * a.wide_sn, a.wide_ld, a.WC, chunk * CK, a.H, a.W, y0, x0, R, tid);
+        stage_halo<4>(wl, a.wide + (long)n * a.wide_sn, a.wide_ld, a.WC, chunk * CK, a.H, a.W, y0, x0, R, tid);
         for (int idx = tid; idx < TH * TW; idx += 256) {
             int yy = y0 + idx / TW, xx = x0 + idx % TW;
             const float* tp = a.thin + (long)n * a.thin_sn + ((long)yy * a.W + xx) * a.thin_ld;
@@ -178,18 +183,24 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(ThinWgradArgs a) {
         }
         __syncthreads();
     }
+    // fold the pixel-splits of this workgroup in LDS (ds_add_f32), then ONE global atomic per (tap, t, w) and workgroup
+    float* red = wl;                                  // reuse the halo tile storage: IT * TCP * 4 floats
+    for (int i = tid; i < IT * TCP * 4; i += 256) red[i] = 0.f;
+    __syncthreads();
     if (active) {
 #pragma unroll
-        for (int t = 0; t < TCP; t++) {
-            if (t >= a.TC) break;
-            for (int e = 0; e < 4; e++) {
-                int w = chunk * CK + wq * 4 + e;
-                if (w >= a.WC) break;
-                float* d = a.swap ? a.dwp + ((long)(taps - 1 - tap) * a.Cout_pad + w) * a.Ktot + t
-                                  : a.dwp + ((long)tap * a.Cout_pad + t) * a.Ktot + w;
-                atomicAdd(d, acc[t][e]);
-            }
-        }
+        for (int t = 0; t < TCP; t++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd(&red[(item * TCP + t) * 4 + e], acc[t][e]);
+    }
+    __syncthreads();
+    for (int i = tid; i < IT * TCP * 4; i += 256) {
+        int e = i & 3, t = (i >> 2) % TCP, it = (i >> 2) / TCP;
+        int tp = it >> 2, w = chunk * CK + (it & 3) * 4 + e;
+        if (t >= a.TC || w >= a.WC) continue;
+        float* d = a.swap ? a.dwp + ((long)(taps - 1 - tp) * a.Cout_pad + w) * a.Ktot + t
+                          : a.dwp + ((long)tp * a.Cout_pad + t) * a.Ktot + w;
+        atomicAdd(d, red[i]);
     }
 }
 }  // namespace
@@ -205,11 +216,12 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_thin_out<12>), grid, dim3(256), 0, st, a);
         return 1;
     }
-    if (a.src[0].C <= 12 && a.Ktot == 16 && a.act == 0) {
+    if (a.src[0].C <= 32 && a.Ktot <= 32 && a.act == 0 && (a.KS <= 3 || a.Ktot == 16)) {     // narrow input: no channel padding on the VALUs
         int groups = cdiv(a.Cout, 16);
-        if (groups * 16 > a.Cout_pad) return 0;
+        if (groups * 16 > a.Cout_pad || (long)a.N * groups > 65535) return 0;
         grid.z = a.N * groups;
-        hipLaunchKernelGGL(k_conv_thin_in, grid, dim3(256), 0, st, a, groups);
+        if (a.Ktot == 16) hipLaunchKernelGGL((k_conv_thin_in<4, 3>), grid, dim3(256), 0, st, a, groups);
+        else hipLaunchKernelGGL((k_conv_thin_in<8, 1>), grid, dim3(256), 0, st, a, groups);
         return 1;
     }
     return 0;
@@ -229,7 +241,7 @@ int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st) {
     } else return 0;
     a.chunks = cdiv(a.WC, CK);
     long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
-    long gx = 1024 / a.chunks; if (gx < 64) gx = 64; if (gx > ntiles) gx = ntiles;
+    long gx = 512 / a.chunks; if (gx < 32) gx = 32; if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, a.chunks);
     if (a.TC <= 4) hipLaunchKernelGGL((k_wgrad_thin<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_thin<12>), grid, dim3(256), 0, st, a);

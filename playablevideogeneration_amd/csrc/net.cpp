@@ -4,6 +4,7 @@
 // conv_mfma.hip / pointwise.hip / head.hip / pack.hip on one HIP stream; nothing here allocates device memory.
 #include "net.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -231,7 +232,15 @@ int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     prof_recs.push_back(r);
     return rc;
 }
+hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the main stream
+    if (!use_side || !side) return stream;
+    hipEvent_t e = sev();
+    hipEventRecord(e, stream);
+    hipStreamWaitEvent(side, e, 0);
+    return side;
+}
 int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
+    hipStream_t stream = wgrad_stream();
     if (!prof) return conv_wgrad_launch(a, stream);
     int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
     if (a.Cout_pad % bmo) bmo = 32;
@@ -557,6 +566,11 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         for (int i = 0; i < 3; i++) { hipMemsetAsync(c->lstm[i].ih.g, 0, c->lstm[i].ih.sn * 4, st); hipMemsetAsync(c->lstm[i].ic.g, 0, c->lstm[i].ic.sn * 4, st); }
         hipMemsetAsync(c->loss_acc, 0, sizeof(double) * LOSS_SLOTS, st);
     }
+    if (c->use_side && !c->side && !dry) {
+        static const bool off = getenv("CADDY_SIDE_STREAM") && atoi(getenv("CADDY_SIDE_STREAM")) == 0;
+        if (off) c->use_side = false; else hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    }
+    c->sev_used = 0;
     LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda};
     double nr[3];
     for (int r = 0; r < 3; r++) {
@@ -579,6 +593,11 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     if (!dry) c->ck(loss_small(a, st), "loss_small");
     if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, 0.0, st), "loss_finalize");
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
+    if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
+        hipEvent_t e = c->sev();
+        hipEventRecord(e, c->side);
+        hipStreamWaitEvent(st, e, 0);
+    }
     c->unpack_all();
     if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
     return finish(c);
@@ -731,7 +750,10 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (c->fail) { delete c; return nullptr; }
     return c;
 }
-void caddy_ctx_destroy(caddy_ctx* c) { delete c; }
+void caddy_ctx_destroy(caddy_ctx* c) {
+    if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    delete c;
+}
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training, const float* samples_in, const float* variations_in) {
     c->fail = false;

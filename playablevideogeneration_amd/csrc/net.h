@@ -91,6 +91,11 @@ struct caddy_ctx {
     hipEvent_t ev() { if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); } return ev_pool[ev_used++]; }
     int timed_conv_fwd(const ConvArgs& a, double flops);
     int timed_conv_wgrad(const WgradArgs& a, double flops);
+    // weight gradients run on a side stream, off the BPTT critical path (dgrad chain); joined before unpack_all()
+    hipStream_t side = nullptr; bool use_side = true; bool side_ready = false;
+    std::vector<hipEvent_t> sev_pool; size_t sev_used = 0;
+    hipEvent_t sev() { if (sev_used == sev_pool.size()) { hipEvent_t e; hipEventCreate(&e); sev_pool.push_back(e); } return sev_pool[sev_used++]; }
+    hipStream_t wgrad_stream();
 
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);

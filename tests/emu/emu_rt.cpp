@@ -216,6 +216,9 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { *st = nullptr; return 0; }
+hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 hipError_t hipDeviceSynchronize() { return 0; }
 hipError_t hipGetLastError() { return 0; }
 hipError_t hipPeekAtLastError() { return 0; }

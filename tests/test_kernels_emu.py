@@ -21,6 +21,8 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3),                      # narrow-layer wgrad kernel (K<=32), tile overhang
     dict(N=2, H=33, W=64, segs=[(64, 0)], Cout=32, KS=3),                      # narrow-layer wgrad kernel, KT=2
     dict(N=2, H=48, W=48, segs=[(16, 0)], Cout=32, KS=1),                      # 1x1 down-sample conv
+    dict(N=2, H=20, W=36, segs=[(32, 0)], Cout=64, KS=3),                      # narrow-input VALU conv, 4 output groups
+    dict(N=2, H=9, W=40, segs=[(24, 0)], Cout=16, KS=3, bias=True),
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)

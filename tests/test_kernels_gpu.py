@@ -32,6 +32,8 @@ def lib():
     dict(N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3),
     dict(N=2, H=33, W=64, segs=[(64, 0)], Cout=32, KS=3, tol=5e-5),
     dict(N=2, H=48, W=48, segs=[(16, 0)], Cout=32, KS=1),
+    dict(N=2, H=20, W=36, segs=[(32, 0)], Cout=64, KS=3),
+    dict(N=2, H=9, W=40, segs=[(24, 0)], Cout=16, KS=3, bias=True),
 ])
 def test_conv(lib, kw):
     K.conv_case(lib, "cuda", **kw)

@@ -20,18 +20,21 @@ SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run th
     ("final 32->3 k7 @256", 8, 256, 256, 32, 3, 7), ("enc 16->16 @128", 128, 128, 128, 16, 16, 3),
 ]
 SHAPES += [("dgrad lstm0-x 512->64 @32", 8, 32, 32, 512, 64, 3), ("dgrad lstm1-x 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("same2 144->128 @32", 8, 32, 32, 144, 128, 3),
+           ("stem 3->16 @256x128f", 128, 256, 256, 3, 16, 3), ("stem 3->16 @256x8f", 8, 256, 256, 3, 16, 3), ("final 64->3 k3 @128", 8, 128, 128, 64, 3, 3),
            ("A res0 64->128 @32x128f", 128, 32, 32, 64, 128, 3), ("A res1 128->128 @16x128f", 128, 16, 16, 128, 128, 3), ("E 32->64 @64x128f", 128, 64, 64, 32, 64, 3)]
 for name, N, H, W, Cin, Cout, KS in SHAPES:
     if ONLY and ONLY not in name:
         continue
-    x = torch.randn(N, H, W, Cin, device="cuda")
+    ldx = round_up(Cin, 4)
+    x = torch.randn(N, H, W, ldx, device="cuda")
     bn = lib.caddy_k_conv_pick_bn(Cout)
     cp = round_up(Cout, bn)
-    wp = torch.randn(KS * KS * cp * Cin, device="cuda") * 0.01
+    Kt = round_up(Cin, 16)
+    wp = torch.randn(KS * KS * cp * Kt, device="cuda") * 0.01
     out = torch.empty(N, H, W, round_up(Cout, 4), device="cuda")
     a = ConvArgs()
-    a.src[0] = ConvSrc(x.data_ptr(), H * W * Cin, Cin, Cin, Cin, 0)
-    a.nsrc, a.N, a.H, a.W, a.KS, a.wp, a.Ktot, a.Cout, a.Cout_pad = 1, N, H, W, KS, wp.data_ptr(), Cin, Cout, cp
+    a.src[0] = ConvSrc(x.data_ptr(), H * W * ldx, ldx, Cin, Kt, 0)
+    a.nsrc, a.N, a.H, a.W, a.KS, a.wp, a.Ktot, a.Cout, a.Cout_pad = 1, N, H, W, KS, wp.data_ptr(), Kt, Cout, cp
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out.shape[3], out.shape[3]
     a.accumulate = 1 if name.startswith('dgrad') else 0
     dy = torch.randn(N, H, W, round_up(Cout, 4), device="cuda")
@@ -39,7 +42,7 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     wa = WgradArgs()
     wa.src[0] = a.src[0]
     wa.nsrc, wa.N, wa.H, wa.W, wa.KS = 1, N, H, W, KS
-    wa.dy, wa.dy_sn, wa.dy_ld, wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs = dy.data_ptr(), H * W * dy.shape[3], dy.shape[3], Cout, cp, Cin, dwp.data_ptr(), 0
+    wa.dy, wa.dy_sn, wa.dy_ld, wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs = dy.data_ptr(), H * W * dy.shape[3], dy.shape[3], Cout, cp, Kt, dwp.data_ptr(), 0
     flops = 2.0 * N * H * W * KS * KS * Cin * Cout
     for label, fn in (("fwd", lambda: lib.caddy_k_conv_fwd(C.byref(a), st)), ("wgrad", lambda: lib.caddy_k_conv_wgrad(C.byref(wa), st))):
         for _ in range(3):
