@@ -109,6 +109,9 @@ int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, co
  *             x {launches, algorithmic FLOPs (SURVEY 8d definition), total milliseconds} --- */
 int caddy_profile_begin(caddy_ctx* ctx);
 int caddy_profile_end(caddy_ctx* ctx, double* out18);
+/* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each
+ * {kind 0 fwd / 1 dgrad / 2 wgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
+int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);
 
 /* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last
  *     forward, converted to (N,C,H,W) --- */

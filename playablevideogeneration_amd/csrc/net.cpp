@@ -225,7 +225,7 @@ static void fill_srcs(ConvSrc* dst, const Seg* segs, int nseg) {
 int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     if (!prof) return conv_fwd_launch(a, stream);
     int bn = conv_pick_bn(a.Cout);
-    ProfRec r{ev(), ev(), bn == 128 ? 0 : (bn == 64 ? 1 : 2), flops};
+    ProfRec r{ev(), ev(), bn == 128 ? 0 : (bn == 64 ? 1 : 2), flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, a.accumulate ? 1 : 0};
     hipEventRecord(r.a, stream);
     int rc = conv_fwd_launch(a, stream);
     hipEventRecord(r.b, stream);
@@ -244,7 +244,7 @@ int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
     if (!prof) return conv_wgrad_launch(a, stream);
     int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
     if (a.Cout_pad % bmo) bmo = 32;
-    ProfRec r{ev(), ev(), bmo == 128 ? 3 : (bmo == 64 ? 4 : 5), flops};
+    ProfRec r{ev(), ev(), bmo == 128 ? 3 : (bmo == 64 ? 4 : 5), flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, 2};
     hipEventRecord(r.a, stream);
     int rc = conv_wgrad_launch(a, stream);
     hipEventRecord(r.b, stream);
@@ -265,7 +265,10 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     if (recording) {
         T4 dz{}; if (actf == 1) dz = alloc(N, H, W, L.pd.Cout);
         Seg sg[CONV_MAX_SRC]; T4 tmp[CONV_MAX_SRC];
-        for (int s = 0; s < nseg; s++) { sg[s] = segs[s]; if (segs[s].bcast && segs[s].need_grad) tmp[s] = alloc(N, H, W, segs[s].t.C); }
+        for (int s = 0; s < nseg; s++) {   // broadcast inputs: scratch for the border-aware sums S[N][Cout][9] (3x3) or a dgrad temp otherwise
+            sg[s] = segs[s];
+            if (segs[s].bcast && segs[s].need_grad) tmp[s] = L.pd.KS == 3 ? alloc(N, 1, 1, L.pd.Cout * 9) : alloc(N, H, W, segs[s].t.C);
+        }
         ConvL* Lp = &L;
         tape.push_back([=]() {
             TV dzv = gv(out);
@@ -278,6 +281,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             if (Lp->dbias) RUN(pw_colsum(dzv, Lp->dbias, stream));
             for (int s = 0; s < nseg; s++) {
                 if (!sg[s].need_grad) continue;
+                if (sg[s].bcast && Lp->pd.KS == 3) { RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, stream)); continue; }
                 ConvArgs d{};
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
@@ -774,8 +778,22 @@ int caddy_generate_next(caddy_ctx* c, const float* observation, int action, cons
     return generate_next(c, observation, action, variation, frame_out, obs_out);
 }
 int caddy_profile_begin(caddy_ctx* c) { c->prof = true; c->prof_recs.clear(); c->ev_used = 0; return 0; }
+int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per launch: {kind, P, K, Cout, KS, flops, ms}; returns count
+    hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
+    int n = 0;
+    for (auto& r : c->prof_recs) {
+        if (n >= max_records) break;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        double* o = out + 7 * n++;
+        o[0] = r.kind; o[1] = r.P; o[2] = r.K; o[3] = r.Cout; o[4] = r.KS; o[5] = r.flops; o[6] = ms;
+    }
+    return n;
+}
 int caddy_profile_end(caddy_ctx* c, double* out18) {   // 6 kernel families x (launches, algorithmic FLOPs, milliseconds)
     hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
     for (int i = 0; i < 18; i++) out18[i] = 0.0;
     for (auto& r : c->prof_recs) {
         float ms = 0.f;

@@ -84,7 +84,7 @@ struct caddy_ctx {
     int hs, ws;   // state resolution
 
     // ---- optional per-launch timing of the conv kernels (HIP events on the launch stream; bench.py roofline) ----
-    struct ProfRec { hipEvent_t a, b; int fam; double flops; };
+    struct ProfRec { hipEvent_t a, b; int fam; double flops; int P, K, Cout, KS, kind; };   // kind: 0 fwd, 1 dgrad (accumulate), 2 wgrad
     bool prof = false;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

@@ -5,6 +5,7 @@
 // Roofline for everything in this file: HBM (8 TB/s).
 #include "common.h"
 #include "pointwise.h"
+#include "pack.h"
 
 namespace {
 
@@ -389,7 +390,71 @@ __global__ void k_batch_sum(const float* src, long sn, long n_el, int N, float* 
     dst[i] += s;
 }
 
+// ---- gradient of a spatially-broadcast conv input (the action / variation vectors of R, conv_dynamics_network.py:77-109) ----
+// forward: y[p,o] += sum_tap W[o,c,tap] * a[c] * [p+off(tap) in bounds]   =>   da[c] = sum_{o,tap} W[o,c,tap] * S[o][tap],
+// S[o][tap] = sum over the pixels whose tap stays in bounds = total - excluded border row/column + doubly excluded corner.
+__global__ __launch_bounds__(256) void k_border_sums(TV dz, float* S) {   // S[n][c][9]; grid (N, ceil(C4/64))
+    __shared__ float4 sh[9][256];
+    const int cq = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int n = blockIdx.x, c = (blockIdx.y * 64 + cq) * 4;
+    const int H = dz.H, W = dz.W, HW = H * W;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 T = z, R0 = z, RL = z, C0 = z, CL = z, K00 = z, K0L = z, KL0 = z, KLL = z;
+    if (c < dz.C) {
+        for (int p = pg; p < HW; p += 4) {
+            int y = p / W, x = p - y * W;
+            float4 v = ld4(dz.p + (long)n * dz.sn + (long)p * dz.ld + c, c, dz.C);
+            T = T + v;
+            if (y == 0) { R0 = R0 + v; if (x == 0) K00 = K00 + v; if (x == W - 1) K0L = K0L + v; }
+            if (y == H - 1) { RL = RL + v; if (x == 0) KL0 = KL0 + v; if (x == W - 1) KLL = KLL + v; }
+            if (x == 0) C0 = C0 + v;
+            if (x == W - 1) CL = CL + v;
+        }
+    }
+    sh[0][threadIdx.x] = T; sh[1][threadIdx.x] = R0; sh[2][threadIdx.x] = RL; sh[3][threadIdx.x] = C0; sh[4][threadIdx.x] = CL;
+    sh[5][threadIdx.x] = K00; sh[6][threadIdx.x] = K0L; sh[7][threadIdx.x] = KL0; sh[8][threadIdx.x] = KLL;
+    __syncthreads();
+    if (pg == 0 && c < dz.C) {
+        float4 v[9];
+        for (int k = 0; k < 9; k++) v[k] = sh[k][cq] + sh[k][cq + 64] + sh[k][cq + 128] + sh[k][cq + 192];
+        for (int ty = 0; ty < 3; ty++)
+            for (int tx = 0; tx < 3; tx++) {
+                float4 r = v[0];
+                if (ty == 0) r = r - v[1];
+                if (ty == 2) r = r - v[2];
+                if (tx == 0) r = r - v[3];
+                if (tx == 2) r = r - v[4];
+                if (ty == 0 && tx == 0) r = r + v[5];
+                if (ty == 0 && tx == 2) r = r + v[6];
+                if (ty == 2 && tx == 0) r = r + v[7];
+                if (ty == 2 && tx == 2) r = r + v[8];
+                float rr[4] = {r.x, r.y, r.z, r.w};
+                for (int e = 0; e < 4 && c + e < dz.C; e++) S[((long)n * dz.C + c + e) * 9 + ty * 3 + tx] = rr[e];
+            }
+    }
+}
+__global__ __launch_bounds__(256) void k_bcast_grad(PackDesc d, int seg, const float* S, float* g, long g_sn) {   // grid (N, seg_C)
+    __shared__ float sh[256];
+    const int n = blockIdx.x, c = blockIdx.y;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < d.Cout * 9; i += 256) {
+        int o = i / 9, tap = i - o * 9;
+        acc += d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + d.seg_off[seg] + c) * 9 + tap] * S[((long)n * d.Cout + o) * 9 + tap];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2]; __syncthreads(); }
+    if (threadIdx.x == 0) g[n * g_sn + c] += sh[0];
+}
+
 }  // namespace
+
+int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S, float* g, long g_sn, hipStream_t st) {
+    if (d.KS != 3 || dz.C != d.Cout) return -1;
+    hipLaunchKernelGGL(k_border_sums, dim3(dz.N, cdiv((dz.C + 3) / 4, 64)), dim3(256), 0, st, dz, S);
+    hipLaunchKernelGGL(k_bcast_grad, dim3(dz.N, d.seg_C[seg]), dim3(256), 0, st, d, seg, (const float*)S, g, g_sn);
+    return 0;
+}
 
 int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) {
     bool aligned = !(((uintptr_t)s.p | (uintptr_t)d.p) & 15) && !((s.ld | d.ld) & 3) && !((s.sn | d.sn) & 3);

@@ -227,6 +227,11 @@ class Engine:
     def profile_begin(self):
         self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))
 
+    def profile_records(self, max_records=20000):
+        buf = (C.c_double * (7 * max_records))()
+        n = self.lib.caddy_profile_records(C.c_void_p(self.ctx), buf, max_records)
+        return [tuple(buf[7 * i + j] for j in range(7)) for i in range(n)]
+
     def profile_end(self):
         """-> {kernel family: (launches, algorithmic FLOPs, milliseconds)} measured with HIP events on the launch stream."""
         out = (C.c_double * 18)()

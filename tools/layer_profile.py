@@ -1,0 +1,31 @@
+"""In-situ per-layer conv timing of one BAIR training step (HIP events around every conv launch): python tools/layer_profile.py"""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from playablevideogeneration_amd import configs
+from playablevideogeneration_amd.engine import Engine
+from playablevideogeneration_amd.init import init_parameters
+
+wl = configs.WORKLOADS["bair256_t16_b8"]
+B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
+dev = torch.device("cuda")
+eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev)
+init_parameters(eng, 0)
+gen = torch.Generator(device=dev).manual_seed(1)
+obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1
+def step():
+    eng.forward_full(obs, wl["gt_init"], wl["tau"], bench.make_noise(B, T, K, Da, dev, gen), training=True, fetch_outputs=False)
+    eng.loss_backward(configs.LOSS_WEIGHTS)
+step(); step()
+eng.profile_begin(); step()
+recs = eng.profile_records(); eng.profile_end()
+agg = collections.OrderedDict()
+for kind, P, Kc, Cout, KS, fl, ms in recs:
+    k = (int(kind), int(P), int(Kc), int(Cout), int(KS))
+    a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += ms
+tot = sum(a[2] for a in agg.values())
+print(f"total conv ms (sum of launches, side stream overlaps not subtracted): {tot:.1f}")
+names = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
+    print(f"{names[k[0]]:5s} P={k[1]:8d} K={k[2]:5d} Cout={k[3]:5d} k{k[4]}  n={a[0]:4d}  {a[2]:7.2f} ms  {a[2]/a[0]*1e3:8.1f} us/launch  {a[1]/a[2]/1e9 if a[2] else 0:6.1f} TF")
