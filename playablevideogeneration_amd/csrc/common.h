@@ -11,6 +11,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct TV {
     float* p;
@@ -50,6 +52,7 @@ struct ConvArgs {
     long out_sn;
     int out_ld;
     int accumulate;     // out += result
+    int precision;      // 0: exact fp32 MFMA; 3: 3-way split bf16 (hi/mid/lo planes, 6 products, ~fp32 accuracy); 2: 2-way split (3 products)
     int splitk;         // set by the launcher: K range split across blockIdx.z (atomic accumulation; accumulate mode only)
 };
 

@@ -53,37 +53,101 @@ __device__ __forceinline__ float4 load_src4(const SegRef& sg, int kq, bool valid
 template <int A_PER, int B_PER>
 struct TileRegs { float4 a[A_PER]; float4 b[B_PER]; };
 
-// global -> registers for K-iteration `it` (tap, 16-channel chunk); returned by value so the tile stays in VGPRs
+// Incremental K iterator of the implicit GEMM: tap (outer) -> input segment -> 16-channel chunk (inner).  Everything that
+// depends on the tap (shifted pixel, zero-padding validity) or on the segment (base pointer, pitch, channel count) is
+// recomputed only when that level changes; the common step is "pointers += 16".  This keeps the per-K-step instruction
+// count low -- the loop is issue-bound, not MFMA-bound, when a launch has only 1-4 waves per SIMD (R's small feature maps).
+template <int A_PER, int B_PER>
+struct ConvIter {
+    const float* ap[A_PER];   // current A pointers (row i, channel c0 + kq*4 of the current segment)
+    const float* bp[B_PER];   // current weight pointers
+    bool aok[A_PER];          // shifted pixel inside the image (and row valid)
+    int pixoff[A_PER];        // (y+dy)*W + (x+dx)
+    int tap, seg, c0, segC, segCpad;
+};
+
+template <int A_PER, int B_PER>
+__device__ __forceinline__ void iter_set_seg(ConvIter<A_PER, B_PER>& I, const ConvArgs& a, int kq, const int* pn) {
+    const ConvSrc sg = a.src[I.seg];
+    I.segC = sg.C; I.segCpad = sg.Cpad; I.c0 = 0;
+#pragma unroll
+    for (int i = 0; i < A_PER; i++)
+        I.ap[i] = sg.p + (long)pn[i] * sg.sn + (sg.bcast ? 0L : (long)I.pixoff[i] * sg.ld) + kq * 4;
+}
 template <int A_PER, int B_PER, int BN>
-__device__ __forceinline__ TileRegs<A_PER, B_PER> conv_gload(const ConvArgs& a, int it, int nchunks, int R, int n0, int tid, int kq,
-                                                             const int* pn, const int* py, const int* px, const bool* pv) {
-    TileRegs<A_PER, B_PER> t;
-    int tap = it / nchunks, ch = it - tap * nchunks;
+__device__ __forceinline__ void iter_set_tap(ConvIter<A_PER, B_PER>& I, const ConvArgs& a, int tap, int R, int n0, int tid, int kq,
+                                             const int* pn, const int* py, const int* px, const bool* pv) {
+    I.tap = tap; I.seg = 0;
     int dy = tap / a.KS - R, dx = tap % a.KS - R;
-    SegRef sg = find_seg(a.src, a.nsrc, ch * BK);
 #pragma unroll
     for (int i = 0; i < A_PER; i++) {
         int yy = py[i] + dy, xx = px[i] + dx;
-        bool ok = pv[i] && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        t.a[i] = load_src4(sg, kq, ok, pn[i], yy, xx, a.W);
+        I.aok[i] = pv[i] && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        I.pixoff[i] = I.aok[i] ? yy * a.W + xx : 0;
     }
-    const float* wt = a.wp + ((long)tap * a.Cout_pad + n0) * a.Ktot + ch * BK + kq * 4;
 #pragma unroll
     for (int i = 0; i < B_PER; i++) {
         int r = (tid >> 2) + 64 * i;
-        t.b[i] = (r < BN) ? *reinterpret_cast<const float4*>(wt + (long)r * a.Ktot) : make_float4(0.f, 0.f, 0.f, 0.f);
+        I.bp[i] = a.wp + ((long)tap * a.Cout_pad + n0 + (r < BN ? r : 0)) * a.Ktot + kq * 4;
+    }
+    iter_set_seg(I, a, kq, pn);
+}
+// load the current (tap, segment, chunk) tile into registers and advance
+template <int A_PER, int B_PER, int BN>
+__device__ __forceinline__ TileRegs<A_PER, B_PER> iter_load(ConvIter<A_PER, B_PER>& I, const ConvArgs& a, int R, int n0, int tid, int kq,
+                                                            const int* pn, const int* py, const int* px, const bool* pv) {
+    TileRegs<A_PER, B_PER> t;
+    const int c = I.c0 + kq * 4;
+#pragma unroll
+    for (int i = 0; i < A_PER; i++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (I.aok[i] && c < I.segC) {
+            if (c + 4 <= I.segC) v = *reinterpret_cast<const float4*>(I.ap[i]);
+            else v = load4_masked(I.ap[i], c, I.segC);
+        }
+        t.a[i] = v;
+        I.ap[i] += BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; i++) {
+        t.b[i] = *reinterpret_cast<const float4*>(I.bp[i]);
+        I.bp[i] += BK;
+    }
+    I.c0 += BK;
+    if (I.c0 >= I.segCpad) {                      // wave-uniform
+        if (I.seg + 1 < a.nsrc) { I.seg++; iter_set_seg(I, a, kq, pn); }
+        else if (I.tap + 1 < a.KS * a.KS) iter_set_tap<A_PER, B_PER, BN>(I, a, I.tap + 1, R, n0, tid, kq, pn, py, px, pv);
     }
     return t;
 }
 
-template <int TM, int TN, int WM, int WN>
+constexpr int LDSH = 24;
+
+template <int NS>
+__device__ __forceinline__ void split_store(unsigned short* base, int plane_stride, float4 v) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int pl = 0; pl < NS; pl++) {
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { h[e] = (__bf16)x[e]; x[e] -= (float)h[e]; }
+        *reinterpret_cast<bf16x4*>(base + pl * plane_stride) = h;
+    }
+}
+
+// NS = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  NS = 2 / 3: split-bf16 planes (see above).
+// K-loop: tile `it` is staged registers -> LDS buffer (it & 1) -> fragments -> MFMA; the global loads of tile it+2 are issued
+// right after the barrier of tile it (two register sets), so HBM/L2 latency is hidden behind TWO K-steps -- this is what
+// matters for R's small feature maps, where a launch only has 1-2 workgroups per CU and nothing else covers the latency.
+template <int TM, int TN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_PER = (BM * 4 + 255) / 256;
     constexpr int B_PER = (BN * 4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ float As[2][BM * LDSK];
-    __shared__ float Bs[2][BN * LDSK];
+    constexpr int A_BYTES = NS == 0 ? BM * LDSK * 4 : NS * BM * LDSH * 2;     // one buffer
+    constexpr int B_BYTES = NS == 0 ? BN * LDSK * 4 : NS * BN * LDSH * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
     __shared__ long rowoff[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,12 +179,16 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
         rowoff[tid] = off;
     }
 
-    // split-K: blockIdx.z owns a contiguous range of the (tap, chunk) iterations; partial sums are combined with atomics
+    // split-K: blockIdx.z owns a contiguous range of TAPS; partial sums are combined with atomics
     const int nchunks = a.Ktot / BK;
-    const int niter_all = a.KS * a.KS * nchunks;
-    const int per = (niter_all + a.splitk - 1) / a.splitk;
-    const int it0 = blockIdx.z * per;
-    const int it1 = (it0 + per < niter_all) ? it0 + per : niter_all;
+    const int taps = a.KS * a.KS;
+    const int tper = (taps + a.splitk - 1) / a.splitk;
+    const int tap0 = blockIdx.z * tper;
+    const int tap1 = (tap0 + tper < taps) ? tap0 + tper : taps;
+    const int it0 = 0;
+    const int it1 = tap0 < tap1 ? (tap1 - tap0) * nchunks : 0;
+    ConvIter<A_PER, B_PER> I;
+    if (it1 > 0) iter_set_tap<A_PER, B_PER, BN>(I, a, tap0, R, n0, tid, kq, pn, py, px, pv);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -130,42 +198,91 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    TileRegs<A_PER, B_PER> t;
-    if (it0 < it1) t = conv_gload<A_PER, B_PER, BN>(a, it0, nchunks, R, n0, tid, kq, pn, py, px, pv);
-    int buf = 0;
-    for (int it = it0; it < it1; it++, buf ^= 1) {
-        // LDS double buffer: tile `it` goes to buffer `buf`; the single barrier below also orders the previous iteration's
-        // fragment reads of buffer `buf^1` against the NEXT iteration's stores into it
+    TileRegs<A_PER, B_PER> t[2];
 #pragma unroll
-        for (int i = 0; i < A_PER; i++) {
-            int r = (tid >> 2) + 64 * i;
-            if (r < BM) *reinterpret_cast<float4*>(&As[buf][r * LDSK + kq * 4]) = t.a[i];
-        }
+    for (int h = 0; h < 2; h++)
+        if (it0 + h < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
+
+    for (int it = it0; it < it1; it += 2) {
 #pragma unroll
-        for (int i = 0; i < B_PER; i++) {
-            int r = (tid >> 2) + 64 * i;
-            if (r < BN) *reinterpret_cast<float4*>(&Bs[buf][r * LDSK + kq * 4]) = t.b[i];
-        }
-        __syncthreads();
-        if (it + 1 < it1) t = conv_gload<A_PER, B_PER, BN>(a, it + 1, nchunks, R, n0, tid, kq, pn, py, px, pv);
+        for (int h = 0; h < 2; h++) {
+            const int cur = it + h;
+            if (cur < it1) {                                   // block-uniform
+                unsigned char* abuf = smem + h * (A_BYTES + B_BYTES);
+                unsigned char* bbuf = abuf + A_BYTES;
+                // registers -> LDS (buffer h).  One barrier per K-step: it also orders the reads of this buffer two steps ago.
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            float4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-                fa[i] = *reinterpret_cast<const float4*>(&As[buf][(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < A_PER; i++) {
+                    int r = (tid >> 2) + 64 * i;
+                    if (r < BM) {
+                        if (NS == 0) *reinterpret_cast<float4*>(abuf + (r * LDSK + kq * 4) * 4) = t[h].a[i];
+                        else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(abuf) + r * LDSH + kq * 4, BM * LDSH, t[h].a[i]);
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < B_PER; i++) {
+                    int r = (tid >> 2) + 64 * i;
+                    if (r < BN) {
+                        if (NS == 0) *reinterpret_cast<float4*>(bbuf + (r * LDSK + kq * 4) * 4) = t[h].b[i];
+                        else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(bbuf) + r * LDSH + kq * 4, BN * LDSH, t[h].b[i]);
+                    }
+                }
+                __syncthreads();
+                if (cur + 2 < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
+                if (NS == 0) {
+                    const float* As = reinterpret_cast<const float*>(abuf);
+                    const float* Bs = reinterpret_cast<const float*>(bbuf);
+#pragma unroll
+                    for (int kk = 0; kk < 2; kk++) {
+                        float4 fa[TM], fb[TN];
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+                            fa[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+#pragma unroll
+                            for (int j = 0; j < TN; j++) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                            }
+                    }
+                } else {
+                    constexpr int NP = NS == 0 ? 1 : NS;
+                    const unsigned short* Ah = reinterpret_cast<const unsigned short*>(abuf);
+                    const unsigned short* Bh = reinterpret_cast<const unsigned short*>(bbuf);
+                    bf16x8 fa[TM][NP], fb[TN][NP];
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++)
+                            fa[i][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * BM * LDSH + (wm * 32 * TM + i * 32 + (lane & 31)) * LDSH + (lane >> 5) * 8]);
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++)
+                            fb[j][pl] = *reinterpret_cast<const bf16x8*>(&Bh[pl * BN * LDSH + (wn * 32 * TN + j * 32 + (lane & 31)) * LDSH + (lane >> 5) * 8]);
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) {
+                            if (NP == 3) {   // smallest terms first
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP - 1], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP - 1], fb[j][0], acc[i][j], 0, 0, 0);
+                            }
+                            if (NP >= 2) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP >= 2 ? 1 : 0], fb[j][0], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
         }
     }
     __syncthreads();   // rowoff visibility when the K range is empty
@@ -429,23 +546,30 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
-    if (a.accumulate && a.act == 0 && a.bias == nullptr && blocks < 384 && niter >= 16) {
+    if (a.accumulate && a.act == 0 && a.bias == nullptr && blocks < 384 && niter >= 16 && a.KS == 3) {
         int want = (int)((512 + blocks - 1) / blocks);
-        int maxs = niter / 8;
-        a.splitk = want < maxs ? want : maxs;
-        if (a.splitk > 8) a.splitk = 8;
-        if (a.splitk < 1) a.splitk = 1;
+        a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
     }
-    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr) a.splitk = force_splitk;
+    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
+    static const int force_prec = getenv("CADDY_PRECISION") ? atoi(getenv("CADDY_PRECISION")) : -1;   // tuning / A-B aid
+    if (force_prec >= 0) a.precision = force_prec;
+    const int ns = (a.precision == 2 || a.precision == 3) ? a.precision : 0;
+#define LAUNCH_CONV(TM_, TN_, WM_, WN_)                                                                              \
+    do {                                                                                                              \
+        if (ns == 3) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 3>), grid, dim3(256), 0, st, a);              \
+        else if (ns == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 2>), grid, dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0>), grid, dim3(256), 0, st, a);                      \
+    } while (0)
     if (small) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
-        hipLaunchKernelGGL((k_conv_fwd<1, 1, 2, 2>), grid, dim3(256), 0, st, a);
+        LAUNCH_CONV(1, 1, 2, 2);
         return 0;
     }
     dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
-    if (bn == 128) hipLaunchKernelGGL((k_conv_fwd<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_fwd<2, 1, 2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1>), grid, dim3(256), 0, st, a);
+    if (bn == 128) LAUNCH_CONV(2, 2, 2, 2);
+    else if (bn == 64) LAUNCH_CONV(2, 1, 2, 2);
+    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0>), grid, dim3(256), 0, st, a);
+#undef LAUNCH_CONV
     return 0;
 }
 

@@ -216,7 +216,9 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_thin_out<12>), grid, dim3(256), 0, st, a);
         return 1;
     }
-    if (a.src[0].C <= 32 && a.Ktot <= 32 && a.act == 0 && (a.KS <= 3 || a.Ktot == 16)) {     // narrow input: no channel padding on the VALUs
+    // IN <= 12 (stem, FinalBlock dgrad).  Wider inputs stay on the MFMA kernel: scalar v_fma_f32 peaks at half the packed/MFMA
+    // fp32 rate, so the VALU path only wins when it avoids > 2x channel padding (measured: 32->64 @64x64: 482 us here vs 221 us on MFMA).
+    if (a.src[0].C <= 12 && a.Ktot == 16 && a.act == 0) {
         int groups = cdiv(a.Cout, 16);
         if (groups * 16 > a.Cout_pad || (long)a.N * groups > 65535) return 0;
         grid.z = a.N * groups;

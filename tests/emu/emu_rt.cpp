@@ -42,7 +42,7 @@ thread_local dim3 t_bdim, t_gdim;
 static constexpr size_t STACK = 256 * 1024;
 static constexpr int MAXT = 1024;
 
-struct WaveState { uint64_t slot[64]; float A[64], B[64]; int arrived; unsigned gen; int nlanes; };
+struct WaveState { uint64_t slot[64]; float A[64], B[64]; float big[64 * 16]; int arrived; unsigned gen; int nlanes; };
 struct BlockState { int nthreads; int arrived; unsigned gen; WaveState waves[MAXT / 64]; };
 static thread_local BlockState t_blk;
 static thread_local void* t_sched_sp;
@@ -89,6 +89,29 @@ void wave_gather2(float a, float b, float* A64, float* B64) {
     wave_sync();
     memcpy(A64, w.A, sizeof(float) * 64); memcpy(B64, w.B, sizeof(float) * 64);
     wave_sync();
+}
+
+void wave_gather_n(const float* mine, int n, float* all) {
+    WaveState& w = t_blk.waves[t_cur->lin >> 6];
+    int l = t_cur->lin & 63;
+    for (int i = 0; i < n; i++) w.big[l * n + i] = mine[i];
+    wave_sync();
+    memcpy(all, w.big, sizeof(float) * 64 * n);
+    wave_sync();
+}
+//  32x32x16 bf16: A[i=l&31][k=(l>>5)*8+j], B[k=(l>>5)*8+j][j'=l&31], j<8; D as 32x32x2 (cdna_hip_programming.md section 3)
+f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+    float mine[16], all[64 * 16];
+    for (int j = 0; j < 8; j++) { mine[j] = (float)a[j]; mine[8 + j] = (float)b[j]; }
+    wave_gather_n(mine, 16, all);
+    int l = t_cur->lin & 63, col = l & 31;
+    for (int r = 0; r < 16; r++) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; k++) acc = fmaf(all[(row + 32 * (k >> 3)) * 16 + (k & 7)], all[(col + 32 * (k >> 3)) * 16 + 8 + (k & 7)], acc);
+        c[r] = acc;
+    }
+    return c;
 }
 
 // Fragment maps per /opt/skills/guides/cdna_hip_programming.md section 3:

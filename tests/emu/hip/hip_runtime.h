@@ -69,6 +69,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 f32x16 mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int);
 f32x4 mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int);
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int);
+void wave_gather_n(const float* mine, int n, float* all);   // all[lane*n + i]
 
 template <typename... KArgs, typename... Args>
 inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t, hipStream_t, Args&&... args) {
@@ -86,6 +89,7 @@ inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t, hipStream_t, Arg
 #define hipLaunchKernelGGL(k, g, b, sh, st, ...) emu::launch(k, g, b, sh, st, __VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu::mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 
 static inline void __syncthreads() { emu::syncthreads(); }
 

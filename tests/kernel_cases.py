@@ -59,7 +59,7 @@ def make_pack(ws, segs, KS, lib):
     return d
 
 
-def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5):
+def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0):
     """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd."""
     g = torch.Generator().manual_seed(seed)
     Cin = sum(c for c, _ in segs)
@@ -104,6 +104,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     b_d = b.to(dev) if bias else None
     a.bias = b_d.data_ptr() if bias else None
     a.act = act
+    a.precision = precision
     out_ld = round_up(Cout, 4) + 4
     out = torch.full((N, H, W, out_ld), 9.0, device=dev)
     a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0
@@ -143,6 +144,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         da.src[0] = ConvSrc(dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3], Cout, kd, 0)
         da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, KS
         da.wp, da.Ktot, da.Cout, da.Cout_pad, da.bias, da.act = wpd.data_ptr(), kd, c, cd_pad, None, 0
+        da.precision = precision
         gx = torch.ones((N, H, W, round_up(c, 4)), device=dev)      # accumulate on top of ones
         da.out, da.out_sn, da.out_ld, da.accumulate = gx.data_ptr(), H * W * gx.shape[3], gx.shape[3], 1
         assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0

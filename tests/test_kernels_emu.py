@@ -28,6 +28,13 @@ def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)
 
 
+@pytest.mark.parametrize("precision,tol", [(3, 3e-5), (2, 2e-3)])
+def test_conv_split_bf16(precision, tol):
+    """3-way split bf16 MFMA path must be fp32-class accurate; the 2-way split is ~2^-16."""
+    K.conv_case(load_emu(), "cpu", N=2, H=8, W=9, segs=[(40, 0), (9, 1), (24, 0)], Cout=128, KS=3, nw=4, bias=True, precision=precision, tol=tol)
+    K.conv_case(load_emu(), "cpu", N=1, H=12, W=12, segs=[(64, 0)], Cout=64, KS=3, precision=precision, tol=tol)
+
+
 def test_pool_upsample():
     K.pool_up_case(load_emu(), "cpu")
 
