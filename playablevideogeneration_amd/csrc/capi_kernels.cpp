@@ -30,7 +30,7 @@ int caddy_k_bn_apply(const TV* x, const float* scale, const float* shift, const 
     return pw_bn_apply(*x, scale, shift, x2, scale2, shift2, act, *out, ST(s));
 }
 int caddy_k_bn_bwd_reduce(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, double* sums, void* s) {
-    return pw_bn_bwd_reduce(*dout, outm, *x, mean, invstd, sums, nullptr, ST(s));
+    return pw_bn_bwd_reduce(*dout, outm, *x, mean, invstd, sums, nullptr, nullptr, nullptr, ST(s));
 }
 int caddy_k_bn_bwd_apply(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const double* sums,
                          const TV* dx, float* dgamma, float* dbeta, void* s) {

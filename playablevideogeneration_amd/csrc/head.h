@@ -24,7 +24,7 @@ struct HeadBufs {
     float *ysoft, *samples, *variations, *aux, *cen_used;
     long long* selected;        // (B*(T-1)) int64 arg-max
     // gradients
-    float *d_feat, *d_logits, *d_ddist, *d_sdist, *d_aux, *g_dmu, *g_dvar;
+    float *d_feat, *d_logits, *d_ddist, *d_sdist, *d_aux, *g_dmu, *g_dvar, *g_mu, *g_raw;
 };
 struct SampleCfg {
     int mode;                   // 0: softmax probabilities, 1: Gumbel-softmax, 2: externally supplied samples

@@ -175,16 +175,22 @@ __global__ void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
         gr[d] = gvar * (raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f));
         atomicAdd(&p.dbm[d], gm[d]); atomicAdd(&p.dbv[d], gr[d]);
     }
-    const float* f = h.feat + (long)n * p.F;
     float* df = h.d_feat + (long)n * p.F;
+    for (int d = 0; d < Da; d++) { h.g_mu[n * Da + d] = gm[d]; h.g_raw[n * Da + d] = gr[d]; }
     for (int k = 0; k < p.F; k++) {
         float acc = 0.f;
-        for (int d = 0; d < Da; d++) {
-            acc += p.Wm[d * p.F + k] * gm[d] + p.Wv[d * p.F + k] * gr[d];
-            atomicAdd(&p.dWm[d * p.F + k], gm[d] * f[k]); atomicAdd(&p.dWv[d * p.F + k], gr[d] * f[k]);
-        }
+        for (int d = 0; d < Da; d++) acc += p.Wm[d * p.F + k] * gm[d] + p.Wv[d * p.F + k] * gr[d];
         df[k] = acc;
     }
+}
+// FC weight gradients: one thread per (d, k) loops over the samples (no atomics)
+__global__ void k_head_bwd3(HeadBufs h, HeadParams p, int NBT) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.Da * p.F) return;
+    int d = i / p.F, k = i - d * p.F;
+    float am = 0.f, av = 0.f;
+    for (int n = 0; n < NBT; n++) { float f = h.feat[(long)n * p.F + k]; am += h.g_mu[n * p.Da + d] * f; av += h.g_raw[n * p.Da + d] * f; }
+    p.dWm[i] += am; p.dWv[i] += av;
 }
 
 // ---- losses ------------------------------------------------------------------------------------------------------------
@@ -374,6 +380,7 @@ int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int 
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {
     hipLaunchKernelGGL(k_head_bwd1, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, c, B * (T - 1), first_call);
     hipLaunchKernelGGL(k_head_bwd2, dim3(cdiv((long)B * T, 64)), dim3(64), 0, st, h, p, B, T);
+    hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 64)), dim3(64), 0, st, h, p, B * T);
     return 0;
 }
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st) {

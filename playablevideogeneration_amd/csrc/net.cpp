@@ -320,7 +320,6 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     s.mean = f; s.invstd = f + cp; s.scale = f + 2 * cp; s.shift = f + 3 * cp; s.sums = c->dalloc(2 * (size_t)bn.C);
     bool dry = c->dry;
     if (c->training) {
-        if (!dry) hipMemsetAsync(s.sums, 0, sizeof(double) * 2 * bn.C, c->stream);
         if (!dry) c->ck(pw_stats(dv(x), s.sums, c->red_scratch, c->stream), "pw_stats");
         if (!dry) bn.calls++;
     }
@@ -339,13 +338,11 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
         tape.push_back([=]() {
             TV om = dv(out);
             const TV* omp = actf ? &om : nullptr;
-            if (!dry) hipMemsetAsync(s1.sums, 0, sizeof(double) * 2 * b1->C, stream);
-            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, stream));
-            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), b1->dgamma, b1->dbeta, stream));
+            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream));   // sums assigned; param grads fused
+            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, stream));
             if (has2 && b2) {
-                if (!dry) hipMemsetAsync(s2.sums, 0, sizeof(double) * 2 * b2->C, stream);
-                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, stream));
-                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), b2->dgamma, b2->dbeta, stream));
+                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, b2->dgamma, b2->dbeta, stream));
+                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, stream));
             } else if (has2) {
                 if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream));
                 else RUN(pw_copy(gv(out), gv(x2c), 1, stream));
@@ -474,6 +471,7 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     b.aux = falloc((size_t)NS * AUX_LD); b.cen_used = falloc(16 * 8);
     b.selected = (long long*)act.alloc(sizeof(long long) * NS);
     b.g_dmu = falloc((size_t)NS * Da); b.g_dvar = falloc((size_t)NS * Da);
+    b.g_mu = falloc((size_t)NT * Da); b.g_raw = falloc((size_t)NT * Da);
     b.d_logits = tw(this, b.logits); b.d_ddist = tw(this, b.ddist); b.d_sdist = tw(this, b.sdist); b.d_aux = tw(this, b.aux);
     RUN(head_forward(b, hp, B, T, stream));
     SampleCfg& sc = H.sc;

@@ -270,6 +270,7 @@ struct FNhwcToNchw {
 // MODE 3: outf[c] += sum x                                           (bias gradient)
 struct RedArgs {
     TV x, dout, outm; const float *mean, *invstd; double* sums; float* outf; long out_sn; float scale; int act; int pix_per_block;
+    float *dgamma, *dbeta;   // MODE 1 + partials: fused parameter gradients
     double* partials;   // MODE 0/1: when set, block b writes its sums to partials[b][2C] (no atomics); k_sum_partials folds them
 };
 template <int MODE>
@@ -324,13 +325,17 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums) {
-    // sums[i] += sum_b partials[b][i]; one wave per output index (4 per workgroup), lanes stride over the blocks
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums, float* dgamma, float* dbeta) {
+    // sums[i] = sum_b partials[b][i] (assign: no memset needed); one wave per output index (4 per workgroup), lanes stride over blocks.
+    // Optionally fused BatchNorm parameter gradients: dbeta[c] += sums[2c], dgamma[c] += sums[2c+1].
     int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     double s = 0.0;
     if (i < n2c) for (int b = lane; b < nb; b += 64) s += partials[(long)b * n2c + i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (i < n2c && lane == 0) sums[i] += s;
+    if (i < n2c && lane == 0) {
+        sums[i] = s;
+        if (dgamma) { if (i & 1) dgamma[i >> 1] += (float)s; else dbeta[i >> 1] += (float)s; }
+    }
 }
 
 template <int MODE>
@@ -345,11 +350,13 @@ int run_reduce(RedArgs a, hipStream_t st) {
     } else {
         long maxb = (MODE <= 1 && a.partials) ? RED_MAX_BLOCKS : 1024;
         long ppb = (P + maxb - 1) / maxb;
-        if (ppb < 64) ppb = 64;
+        int C4r = (a.x.C + 3) / 4; int ptr = 256 / (C4r < 256 ? C4r : 256);      // pixel rows handled in parallel by one block
+        long minp = ptr * 4 > 16 ? ptr * 4 : 16;                                 // >= 4 pixels per thread
+        if (ppb < minp) ppb = minp;
         a.pix_per_block = (int)ppb;
         int nb = cdiv(P, ppb);
         hipLaunchKernelGGL((k_reduce<MODE>), dim3(nb), dim3(256), 0, st, a);
-        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums);
+        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums, a.dgamma, a.dbeta);
     }
     return 0;
 }
@@ -393,15 +400,15 @@ __global__ void k_batch_sum(const float* src, long sn, long n_el, int N, float* 
 // ---- gradient of a spatially-broadcast conv input (the action / variation vectors of R, conv_dynamics_network.py:77-109) ----
 // forward: y[p,o] += sum_tap W[o,c,tap] * a[c] * [p+off(tap) in bounds]   =>   da[c] = sum_{o,tap} W[o,c,tap] * S[o][tap],
 // S[o][tap] = sum over the pixels whose tap stays in bounds = total - excluded border row/column + doubly excluded corner.
-__global__ __launch_bounds__(256) void k_border_sums(TV dz, float* S) {   // S[n][c][9]; grid (N, ceil(C4/64))
+__global__ __launch_bounds__(256) void k_border_sums(TV dz, float* S) {   // S[n][c][9]; grid (N, ceil(C4/16)): 16 channel quads x 16 pixel groups
     __shared__ float4 sh[9][256];
-    const int cq = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int n = blockIdx.x, c = (blockIdx.y * 64 + cq) * 4;
+    const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int n = blockIdx.x, c = (blockIdx.y * 16 + cq) * 4;
     const int H = dz.H, W = dz.W, HW = H * W;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 T = z, R0 = z, RL = z, C0 = z, CL = z, K00 = z, K0L = z, KL0 = z, KLL = z;
     if (c < dz.C) {
-        for (int p = pg; p < HW; p += 4) {
+        for (int p = pg; p < HW; p += 16) {
             int y = p / W, x = p - y * W;
             float4 v = ld4(dz.p + (long)n * dz.sn + (long)p * dz.ld + c, c, dz.C);
             T = T + v;
@@ -414,9 +421,16 @@ __global__ __launch_bounds__(256) void k_border_sums(TV dz, float* S) {   // S[n
     sh[0][threadIdx.x] = T; sh[1][threadIdx.x] = R0; sh[2][threadIdx.x] = RL; sh[3][threadIdx.x] = C0; sh[4][threadIdx.x] = CL;
     sh[5][threadIdx.x] = K00; sh[6][threadIdx.x] = K0L; sh[7][threadIdx.x] = KL0; sh[8][threadIdx.x] = KLL;
     __syncthreads();
+    if (threadIdx.x < 16 * 9 && (blockIdx.y * 16 + (threadIdx.x & 15)) * 4 < dz.C) {   // thread = (category k, channel quad)
+        const int k = threadIdx.x >> 4, q = threadIdx.x & 15;
+        float4 v = z;
+        for (int g = 0; g < 16; g++) v = v + sh[k][g * 16 + q];
+        sh[k][q] = v;                                   // slot (k, q) is only read by this thread
+    }
+    __syncthreads();
     if (pg == 0 && c < dz.C) {
         float4 v[9];
-        for (int k = 0; k < 9; k++) v[k] = sh[k][cq] + sh[k][cq + 64] + sh[k][cq + 128] + sh[k][cq + 192];
+        for (int k = 0; k < 9; k++) v[k] = sh[k][cq];
         for (int ty = 0; ty < 3; ty++)
             for (int tx = 0; tx < 3; tx++) {
                 float4 r = v[0];
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void k_bcast_grad(PackDesc d, int seg, const f
 
 int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S, float* g, long g_sn, hipStream_t st) {
     if (d.KS != 3 || dz.C != d.Cout) return -1;
-    hipLaunchKernelGGL(k_border_sums, dim3(dz.N, cdiv((dz.C + 3) / 4, 64)), dim3(256), 0, st, dz, S);
+    hipLaunchKernelGGL(k_border_sums, dim3(dz.N, cdiv((dz.C + 3) / 4, 16)), dim3(256), 0, st, dz, S);
     hipLaunchKernelGGL(k_bcast_grad, dim3(dz.N, d.seg_C[seg]), dim3(256), 0, st, d, seg, (const float*)S, g, g_sn);
     return 0;
 }
@@ -476,8 +490,8 @@ int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x
     FBnApply f{x, x2 ? *x2 : x, out, scale, shift, scale2, shift2, x.H * x.W, x2 ? 1 : 0, act};
     return run_map((long)x.N * x.H * x.W, x.C, f, st);
 }
-int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, hipStream_t st) {
-    RedArgs a{}; a.partials = scratch; a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st) {
+    RedArgs a{}; a.partials = scratch; if (scratch) { a.dgamma = dgamma; a.dbeta = dbeta; } a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
     return run_reduce<1>(a, st);
 }
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
