@@ -71,6 +71,27 @@ def cpu_baseline(wl):
             "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}), oracle forward+losses+backward, 1 warm-up + 1 timed iteration"}
 
 
+def rollout_fps(dev, frames=32):
+    """BASELINE.json configs[3]: Tennis hyper-parameters (main model, S=4, Da=5) at 256x256, play.py path:
+    start_inference + `frames` x generate_next at batch 1, eval mode, actions i mod 7."""
+    c = dict(configs.TENNIS)
+    eng = Engine(variant=c["variant"], batch=1, seq_len=2, height=256, width=256, stacking=c["stacking"], actions=c["actions"],
+                 action_dim=c["action_dim"], hidden=c["hidden"], device=dev)
+    init_parameters(eng, seed=0)
+    obs = torch.rand(3 * c["stacking"], 256, 256, device=dev) * 2 - 1
+    eng.start_inference()
+    for i in range(4):
+        _, obs = eng.generate_next(obs, i % c["actions"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        _, obs = eng.generate_next(obs, i % c["actions"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "rollout frames/sec", "value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / frames * 1e3,
+            "config": {"workload": "tennis256_s4_rollout32", "model": "main", "batch": 1, "frames": frames}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +186,11 @@ def main():
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
                           "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
                "loss": losses["total"], "roofline": roof}
+        if world == 1:
+            del eng
+            torch.cuda.empty_cache()
+            res["rollout"] = rollout_fps(dev)
+            log(f"roll-out: {res['rollout']['value']:.1f} frames/s")
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle, 1 clip) ...")
             res["cpu_baseline"] = cpu_baseline(wl)

@@ -136,17 +136,19 @@ __device__ __forceinline__ void split_store(unsigned short* base, int plane_stri
 }
 
 // NS = 0: exact fp32 (v_mfma_f32_32x32x2_f32).  NS = 2 / 3: split-bf16 planes (see above).
-// K-loop: tile `it` is staged registers -> LDS buffer (it & 1) -> fragments -> MFMA; the global loads of tile it+2 are issued
-// right after the barrier of tile it (two register sets), so HBM/L2 latency is hidden behind TWO K-steps -- this is what
-// matters for R's small feature maps, where a launch only has 1-2 workgroups per CU and nothing else covers the latency.
-template <int TM, int TN, int WM, int WN, int NS>
+// K-loop: one step = CPS consecutive 16-channel chunks (CPS = 2 -> 32 channels per barrier, which amortises the barrier, the LDS
+// round trip and the loop bookkeeping over twice the MFMA work); step `s` is staged registers -> LDS buffer (s & 1) ->
+// fragments -> MFMA while the global loads of step s+1 are in flight (register double buffer).
+template <int TM, int TN, int WM, int WN, int NS, int CPS>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_PER = (BM * 4 + 255) / 256;
     constexpr int B_PER = (BN * 4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int A_BYTES = NS == 0 ? BM * LDSK * 4 : NS * BM * LDSH * 2;     // one buffer
-    constexpr int B_BYTES = NS == 0 ? BN * LDSK * 4 : NS * BN * LDSH * 2;
+    constexpr int PF = CPS * BK + 4;                                           // fp32 LDS row pitch (floats): 20 or 36, both conflict-free for ds_read_b128
+    constexpr int PH = CPS * BK + 8;                                           // bf16 LDS row pitch (elements): 24 or 40
+    constexpr int A_BYTES = NS == 0 ? BM * PF * 4 : NS * BM * PH * 2;          // one buffer
+    constexpr int B_BYTES = NS == 0 ? BN * PF * 4 : NS * BN * PH * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
     __shared__ long rowoff[BM];
 
@@ -198,90 +200,96 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    TileRegs<A_PER, B_PER> t[2];
+    TileRegs<A_PER, B_PER> t[CPS];
+    const int nsteps = (it1 + CPS - 1) / CPS;
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-        if (it0 + h < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
-
-    for (int it = it0; it < it1; it += 2) {
+    for (int h = 0; h < CPS; h++) {
+        if (h < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
+        else t[h] = TileRegs<A_PER, B_PER>{};
+    }
+    for (int st = 0; st < nsteps; st++) {
+        unsigned char* abuf = smem + (st & 1) * (A_BYTES + B_BYTES);
+        unsigned char* bbuf = abuf + A_BYTES;
+        // registers -> LDS.  One barrier per step: it also orders the fragment reads of this buffer two steps ago.
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int cur = it + h;
-            if (cur < it1) {                                   // block-uniform
-                unsigned char* abuf = smem + h * (A_BYTES + B_BYTES);
-                unsigned char* bbuf = abuf + A_BYTES;
-                // registers -> LDS (buffer h).  One barrier per K-step: it also orders the reads of this buffer two steps ago.
+        for (int h = 0; h < CPS; h++) {
 #pragma unroll
-                for (int i = 0; i < A_PER; i++) {
-                    int r = (tid >> 2) + 64 * i;
-                    if (r < BM) {
-                        if (NS == 0) *reinterpret_cast<float4*>(abuf + (r * LDSK + kq * 4) * 4) = t[h].a[i];
-                        else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(abuf) + r * LDSH + kq * 4, BM * LDSH, t[h].a[i]);
-                    }
+            for (int i = 0; i < A_PER; i++) {
+                int r = (tid >> 2) + 64 * i;
+                if (r < BM) {
+                    if (NS == 0) *reinterpret_cast<float4*>(abuf + (r * PF + h * BK + kq * 4) * 4) = t[h].a[i];
+                    else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(abuf) + r * PH + h * BK + kq * 4, BM * PH, t[h].a[i]);
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < B_PER; i++) {
-                    int r = (tid >> 2) + 64 * i;
-                    if (r < BN) {
-                        if (NS == 0) *reinterpret_cast<float4*>(bbuf + (r * LDSK + kq * 4) * 4) = t[h].b[i];
-                        else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(bbuf) + r * LDSH + kq * 4, BN * LDSH, t[h].b[i]);
-                    }
+            for (int i = 0; i < B_PER; i++) {
+                int r = (tid >> 2) + 64 * i;
+                if (r < BN) {
+                    if (NS == 0) *reinterpret_cast<float4*>(bbuf + (r * PF + h * BK + kq * 4) * 4) = t[h].b[i];
+                    else split_store<NS == 0 ? 1 : NS>(reinterpret_cast<unsigned short*>(bbuf) + r * PH + h * BK + kq * 4, BN * PH, t[h].b[i]);
                 }
-                __syncthreads();
-                if (cur + 2 < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
-                if (NS == 0) {
-                    const float* As = reinterpret_cast<const float*>(abuf);
-                    const float* Bs = reinterpret_cast<const float*>(bbuf);
+            }
+        }
+        __syncthreads();
 #pragma unroll
-                    for (int kk = 0; kk < 2; kk++) {
-                        float4 fa[TM], fb[TN];
+        for (int h = 0; h < CPS; h++) {
+            if ((st + 1) * CPS + h < it1) t[h] = iter_load<A_PER, B_PER, BN>(I, a, R, n0, tid, kq, pn, py, px, pv);
+            else t[h] = TileRegs<A_PER, B_PER>{};       // K tail: zero tile
+        }
+        if (NS == 0) {
+            const float* As = reinterpret_cast<const float*>(abuf);
+            const float* Bs = reinterpret_cast<const float*>(bbuf);
 #pragma unroll
-                        for (int i = 0; i < TM; i++)
-                            fa[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 * TM + i * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+            for (int kk = 0; kk < 2 * CPS; kk++) {
+                float4 fa[TM], fb[TN];
 #pragma unroll
-                        for (int j = 0; j < TN; j++)
-                            fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 * TN + j * 32 + (lane & 31)) * LDSK + kk * 8 + (lane >> 5) * 4]);
+                for (int i = 0; i < TM; i++)
+                    fa[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 * TM + i * 32 + (lane & 31)) * PF + kk * 8 + (lane >> 5) * 4]);
 #pragma unroll
-                        for (int i = 0; i < TM; i++)
+                for (int j = 0; j < TN; j++)
+                    fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 * TN + j * 32 + (lane & 31)) * PF + kk * 8 + (lane >> 5) * 4]);
 #pragma unroll
-                            for (int j = 0; j < TN; j++) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                            }
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                     }
-                } else {
-                    constexpr int NP = NS == 0 ? 1 : NS;
-                    const unsigned short* Ah = reinterpret_cast<const unsigned short*>(abuf);
-                    const unsigned short* Bh = reinterpret_cast<const unsigned short*>(bbuf);
-                    bf16x8 fa[TM][NP], fb[TN][NP];
+            }
+        } else {
+            constexpr int NP = NS == 0 ? 1 : NS;
+            const unsigned short* Ah = reinterpret_cast<const unsigned short*>(abuf);
+            const unsigned short* Bh = reinterpret_cast<const unsigned short*>(bbuf);
 #pragma unroll
-                    for (int i = 0; i < TM; i++)
+            for (int h = 0; h < CPS; h++) {
+                bf16x8 fa[TM][NP], fb[TN][NP];
 #pragma unroll
-                        for (int pl = 0; pl < NP; pl++)
-                            fa[i][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * BM * LDSH + (wm * 32 * TM + i * 32 + (lane & 31)) * LDSH + (lane >> 5) * 8]);
+                for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++)
+                    for (int pl = 0; pl < NP; pl++)
+                        fa[i][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * BM * PH + (wm * 32 * TM + i * 32 + (lane & 31)) * PH + h * BK + (lane >> 5) * 8]);
 #pragma unroll
-                        for (int pl = 0; pl < NP; pl++)
-                            fb[j][pl] = *reinterpret_cast<const bf16x8*>(&Bh[pl * BN * LDSH + (wn * 32 * TN + j * 32 + (lane & 31)) * LDSH + (lane >> 5) * 8]);
+                for (int j = 0; j < TN; j++)
 #pragma unroll
-                    for (int i = 0; i < TM; i++)
+                    for (int pl = 0; pl < NP; pl++)
+                        fb[j][pl] = *reinterpret_cast<const bf16x8*>(&Bh[pl * BN * PH + (wn * 32 * TN + j * 32 + (lane & 31)) * PH + h * BK + (lane >> 5) * 8]);
 #pragma unroll
-                        for (int j = 0; j < TN; j++) {
-                            if (NP == 3) {   // smallest terms first
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP - 1], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP - 1], fb[j][0], acc[i][j], 0, 0, 0);
-                            }
-                            if (NP >= 2) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP >= 2 ? 1 : 0], fb[j][0], acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        if (NP == 3) {   // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP - 1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP - 1], fb[j][0], acc[i][j], 0, 0, 0);
                         }
-                }
+                        if (NP >= 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP >= 2 ? 1 : 0], fb[j][0], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
             }
         }
     }
@@ -554,11 +562,14 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     static const int force_prec = getenv("CADDY_PRECISION") ? atoi(getenv("CADDY_PRECISION")) : -1;   // tuning / A-B aid
     if (force_prec >= 0) a.precision = force_prec;
     const int ns = (a.precision == 2 || a.precision == 3) ? a.precision : 0;
+    static const int force_cps = getenv("CADDY_CPS") ? atoi(getenv("CADDY_CPS")) : 0;
+    const int cps = force_cps == 2 ? 2 : 1;    // 32 channels per barrier measured +-3% (not the limiter): kept selectable, default 16
 #define LAUNCH_CONV(TM_, TN_, WM_, WN_)                                                                              \
     do {                                                                                                              \
-        if (ns == 3) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 3>), grid, dim3(256), 0, st, a);              \
-        else if (ns == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 2>), grid, dim3(256), 0, st, a);         \
-        else hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0>), grid, dim3(256), 0, st, a);                      \
+        if (ns == 3) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 3, 1>), grid, dim3(256), 0, st, a);           \
+        else if (ns == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 2, 1>), grid, dim3(256), 0, st, a);      \
+        else if (cps == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0, 2>), grid, dim3(256), 0, st, a);     \
+        else hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0, 1>), grid, dim3(256), 0, st, a);                   \
     } while (0)
     if (small) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
@@ -568,7 +579,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
     if (bn == 128) LAUNCH_CONV(2, 2, 2, 2);
     else if (bn == 64) LAUNCH_CONV(2, 1, 2, 2);
-    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
 #undef LAUNCH_CONV
     return 0;
 }
