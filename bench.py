@@ -164,13 +164,21 @@ def main():
         for _ in range(a.profile_steps):
             step()
         fam = eng.profile_end()
-        name, (n, fl, ms) = max(fam.items(), key=lambda kv: kv[1][2])
+        name, (n, fl, ms, by) = max(fam.items(), key=lambda kv: kv[1][2])
         tot_ms = sum(v[2] for v in fam.values())
+        traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         roof = {"kernel": name, "bound": "mfma", "achieved": fl / ms / 1e9, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "frac": fl / ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                 "launches_per_step": n // a.profile_steps, "avg_launch_us": ms / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
-                "all_conv_families_ms_per_step": tot_ms / a.profile_steps,
-                "families": {k: {"launches": v[0] // a.profile_steps, "tflops": (v[1] / v[2] / 1e9 if v[2] > 0 else 0.0), "ms": v[2] / a.profile_steps} for k, v in fam.items()}}
+                "algorithmic_bytes_per_launch": by / n, "all_conv_kernels_ms_per_step": tot_ms / a.profile_steps,
+                "note": "wgrad kernels run on a side stream concurrently with the main stream, so per-launch durations measured inside the step include that sharing",
+                "kernels": {k: {"launches": v[0] // a.profile_steps, "tflops": (v[1] / v[2] / 1e9 if v[2] > 0 else 0.0), "ms": v[2] / a.profile_steps,
+                                "avg_us": (v[2] / v[0] * 1e3 if v[0] else 0.0)} for k, v in fam.items()}}
         alg = ALGO.get(a.workload)
         if alg:   # whole-step figures on SURVEY 8(d)'s algorithmic work: bytes = 3*(B*act + W), flops = 3*B*fwd
             step_bytes = 3 * (B * alg["act_gb_clip_fwd"] + alg["w_gb_fwd"]) * 1e9

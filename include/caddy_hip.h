@@ -85,6 +85,12 @@ int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
  *     samples_in / variations_in (nullable): outputs of an evaluation action_sampler / action_variation_sampler. --- */
 int caddy_forward_full(caddy_ctx* ctx, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training,
                        const float* samples_in, const float* variations_in);
+/* --- Model.forward(batch_tuple, pretraining=True, ...) -> forward_pretraining (model/main_model/model.py:290-468).
+ *     Afterwards caddy_get_output ids follow THAT function's tuple (4 = reconstructed hidden states (B,T,Ch,h,w),
+ *     5 = hidden states, 6 = selected actions, 7 = logits, 8 = samples, 9 = attention; 10..19 as in full mode; frames have T entries)
+ *     and caddy_loss_backward adds the `hidden` term (HiddenStatesLoss, training/trainer.py:313). --- */
+int caddy_forward_pretraining(caddy_ctx* ctx, const float* obs, float tau, const caddy_noise* noise, int training,
+                              const float* samples_in, const float* variations_in);
 int caddy_get_output(caddy_ctx* ctx, int id, void* dst);      /* copy one output, converted to the reference layout */
 /* d(loss)/d(output) after caddy_loss_backward, same layout (what autograd holds in `.grad` of a retained output);
  * available for ids 0, 100-102, 2, 3, 4, 6, 8, 9, 10, 12, 15, 16, 18. */
@@ -105,10 +111,11 @@ int caddy_start_inference(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.
- *     out18 = 6 kernel families {k_conv_fwd<2,2,2,2>, <2,1,2,2>, <1,1,4,1>, k_conv_wgrad<2,2,2,2>, <1,2,2,2>, <1,1,1,4>}
- *             x {launches, algorithmic FLOPs (SURVEY 8d definition), total milliseconds} --- */
+ *     out33 = 11 kernels {k_conv_fwd<2,2,2,2,*>, k_conv_fwd<2,1,2,2,*>, k_conv_fwd<1,1,2,2,*>, k_conv_fwd<1,1,4,1,*>, k_conv_thin_out,
+ *             k_conv_thin_in, k_conv_wgrad<2,2,2,2>, k_conv_wgrad<1,2,2,2>, k_conv_wgrad<1,1,1,4>, k_conv_wgrad_small, k_wgrad_thin}
+ *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
 int caddy_profile_begin(caddy_ctx* ctx);
-int caddy_profile_end(caddy_ctx* ctx, double* out18);
+int caddy_profile_end(caddy_ctx* ctx, double* out44);
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each
  * {kind 0 fwd / 1 dgrad / 2 wgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
 int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);

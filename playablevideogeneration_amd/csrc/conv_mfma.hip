@@ -520,6 +520,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_small(WgradArgs a, int tiles
 
 }  // namespace
 
+thread_local int g_last_conv_kernel = -1;
+
 int conv_pick_bn(int cout) {
     int best = 128, bestpad = round_up(cout, 128);
     for (int bn : {64, 32}) {
@@ -574,9 +576,11 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     if (small) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
         LAUNCH_CONV(1, 1, 2, 2);
+        g_last_conv_kernel = CK_FWD_64x64;
         return 0;
     }
     dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
+    g_last_conv_kernel = bn == 128 ? CK_FWD_128x128 : (bn == 64 ? CK_FWD_128x64 : CK_FWD_128x32);
     if (bn == 128) LAUNCH_CONV(2, 2, 2, 2);
     else if (bn == 64) LAUNCH_CONV(2, 1, 2, 2);
     else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
@@ -598,6 +602,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
         int grid = (int)(ntiles < 512 ? ntiles : 512);
         if (a.Ktot <= 32) hipLaunchKernelGGL((k_conv_wgrad_small<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_small<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+        g_last_conv_kernel = CK_WGRAD_SMALL;
         return 0;
     }
     int ktiles = cdiv(a.Ktot, 128);
@@ -611,6 +616,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
         a.slabs = (int)(want < maxs ? want : maxs);
         if (a.slabs < 1) a.slabs = 1;
     }
+    g_last_conv_kernel = bmo == 128 ? CK_WGRAD_128 : (bmo == 64 ? CK_WGRAD_64 : CK_WGRAD_32);
     dim3 grid(ktiles, otiles, taps * a.slabs);
     if (bmo == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
     else if (bmo == 64) hipLaunchKernelGGL((k_conv_wgrad<1, 2, 2, 2>), grid, dim3(256), 0, st, a);

@@ -214,6 +214,7 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     if ((a.Cout <= 4 && a.src[0].C >= 16) || (a.Cout <= 12 && a.src[0].C >= 16 && a.src[0].C <= 32)) {
         if (a.Cout <= 4) hipLaunchKernelGGL((k_conv_thin_out<4>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_thin_out<12>), grid, dim3(256), 0, st, a);
+        g_last_conv_kernel = CK_THIN_OUT;
         return 1;
     }
     // IN <= 12 (stem, FinalBlock dgrad).  Wider inputs stay on the MFMA kernel: scalar v_fma_f32 peaks at half the packed/MFMA
@@ -224,6 +225,7 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
         grid.z = a.N * groups;
         if (a.Ktot == 16) hipLaunchKernelGGL((k_conv_thin_in<4, 3>), grid, dim3(256), 0, st, a, groups);
         else hipLaunchKernelGGL((k_conv_thin_in<8, 1>), grid, dim3(256), 0, st, a, groups);
+        g_last_conv_kernel = CK_THIN_IN;
         return 1;
     }
     return 0;
@@ -247,5 +249,6 @@ int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st) {
     dim3 grid((unsigned)gx, a.chunks);
     if (a.TC <= 4) hipLaunchKernelGGL((k_wgrad_thin<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_thin<12>), grid, dim3(256), 0, st, a);
+    g_last_conv_kernel = CK_WGRAD_THIN;
     return 1;
 }

@@ -224,11 +224,13 @@ static void fill_srcs(ConvSrc* dst, const Seg* segs, int nseg) {
 
 int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     if (!prof) return conv_fwd_launch(a, stream);
-    int bn = conv_pick_bn(a.Cout);
-    ProfRec r{ev(), ev(), bn == 128 ? 0 : (bn == 64 ? 1 : 2), flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, a.accumulate ? 1 : 0};
+    int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
+    const double px = (double)a.N * a.H * a.W;   // algorithmic bytes: 4 * (|in| + |out| + |W|)
+    ProfRec r{ev(), ev(), 0, flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, a.accumulate ? 1 : 0, 4.0 * (px * cin + px * a.Cout + (double)a.KS * a.KS * a.Ktot * a.Cout)};
     hipEventRecord(r.a, stream);
     int rc = conv_fwd_launch(a, stream);
     hipEventRecord(r.b, stream);
+    r.fam = g_last_conv_kernel;
     prof_recs.push_back(r);
     return rc;
 }
@@ -242,12 +244,13 @@ hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everyth
 int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
     hipStream_t stream = wgrad_stream();
     if (!prof) return conv_wgrad_launch(a, stream);
-    int bmo = a.Cout_pad >= 128 ? 128 : (a.Cout_pad >= 64 ? 64 : 32);
-    if (a.Cout_pad % bmo) bmo = 32;
-    ProfRec r{ev(), ev(), bmo == 128 ? 3 : (bmo == 64 ? 4 : 5), flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, 2};
+    int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
+    const double px = (double)a.N * a.H * a.W;
+    ProfRec r{ev(), ev(), 0, flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, 2, 4.0 * (px * cin + px * a.Cout + (double)a.KS * a.KS * a.Ktot * a.Cout)};
     hipEventRecord(r.a, stream);
     int rc = conv_wgrad_launch(a, stream);
     hipEventRecord(r.b, stream);
+    r.fam = g_last_conv_kernel;
     prof_recs.push_back(r);
     return rc;
 }
@@ -510,7 +513,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     c->act.reset(); c->tape.clear(); c->dbg.clear();
-    c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau;
+    c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
     c->pack_all();
     caddy_noise z{}; if (nz) z = *nz;
@@ -555,6 +558,64 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     return finish(c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward_pretraining (model/main_model/model.py:290-468): D decodes conv3x3(states) for all T frames in one batch, R is
+// unrolled on the GROUND-TRUTH states, E re-encodes the (re-stacked) reconstructions in one batch, A runs on both.
+// ---------------------------------------------------------------------------------------------------------------------
+static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const caddy_noise* nz, int training,
+                               const float* samples_in, const float* variations_in) {
+    const caddy_config& g = c->cfg;
+    const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
+    bool dry = c->dry;
+    c->act.reset(); c->tape.clear(); c->dbg.clear();
+    c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
+    for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
+    c->pack_all();
+    caddy_noise z{}; if (nz) z = *nz;
+    c->obs = c->alloc(B * T, H, W, 3 * S);
+    if (!dry) c->ck(pw_nchw_to_nhwc(obs, (long)3 * S * H * W, dv(c->obs), c->stream), "obs layout");
+    c->x65_gt = c->encode(c->obs, false, nullptr);
+    c->action_net(c->x65_gt, c->head1, z.eps_states, z.eps_dirs, z.gumbel_uniform, true, samples_in, variations_in);
+    // state_to_hidden_state_layer (model.py:41-43,413) then D on all B*T frames at once
+    Seg ss{chan(c->x65_gt, 0, 64), 0, true};
+    c->rec_hidden = c->conv(c->s2h, &ss, 1, 0, nullptr);
+    for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(B * T, H >> r, W >> r, 3);
+    c->render(c->rec_hidden, 0, 1);
+    // R on ground-truth states
+    c->hidden = c->alloc(B * (T - 1), c->hs, c->ws, g.hidden);
+    T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
+    for (int t = 0; t < T - 1; t++) {
+        T4 hslot = tslice(c->hidden, B, T - 1, t);
+        c->dynamics(chan(tslice(c->x65_gt, B, T, t), 0, 64), tslice(aux_all, B, T - 1, t), &hslot);
+    }
+    // compute_stacked_observations (model.py:470-486): channel group k of time t = reconstruction max(t-k, 0)
+    T4 stacked;
+    if (S == 1) stacked = c->frames[0];
+    else {
+        stacked = c->alloc(B * T, H, W, 3 * S);
+        const T4& f = c->frames[0];
+        for (int k = 0; k < S; k++) {
+            int n = T - k;   // times k..T-1 <- reconstructions 0..T-1-k (one tall "image" of n frames per clip)
+            if (n > 0) {
+                T4 src{f.d, f.g, B, n * H, W, 3, (long)T * f.sn, f.ld};
+                T4 dst{stacked.d + (long)k * stacked.sn + 3 * k, stacked.g + (long)k * stacked.sn + 3 * k, B, n * H, W, 3, (long)T * stacked.sn, stacked.ld};
+                c->copy_op(src, dst);
+            }
+            for (int t = 0; t < k && t < T; t++) {   // repeated first reconstruction
+                T4 src{f.d, f.g, B, H, W, 3, (long)T * f.sn, f.ld};
+                T4 dst{stacked.d + (long)t * stacked.sn + 3 * k, stacked.g + (long)t * stacked.sn + 3 * k, B, H, W, 3, (long)T * stacked.sn, stacked.ld};
+                c->copy_op(src, dst);
+            }
+        }
+    }
+    c->rec_x65 = c->alloc(B * T, c->hs, c->ws, 65, 68);
+    c->encode(stacked, true, &c->rec_x65);
+    c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
+    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions);
+    c->have_forward = true;
+    return finish(c);
+}
+
 static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_host) {
     if (!c->have_forward || !c->recording) { set_error("caddy_loss_backward needs a preceding training-mode caddy_forward_full"); return -2; }
     const caddy_config& g = c->cfg;
@@ -578,11 +639,21 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     for (int r = 0; r < 3; r++) {
         const T4& f = c->frames[r];
         nr[r] = (double)f.N * 3 * f.H * f.W;
-        if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, 1, T, T - 1, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, st), "loss_l1");
+        const int Trec = c->pretraining ? T : T - 1;      // pretraining reconstructs all T frames (losses.py:83-87)
+        if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, c->pretraining ? 0 : 1, T, Trec, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, st), "loss_l1");
     }
     T4 sa = chan(c->x65_gt, 0, 64), sb = chan(c->rec_x65, 0, 64);
     double nst = (double)sa.N * 64 * sa.H * sa.W;
     if (!dry) c->ck(loss_mse(dv(sa), dv(sb), gv(sb), (float)(w.states / nst), c->loss_acc + LOSS_STATES, st), "loss_mse");
+    double nhid = 0.0;
+    if (c->pretraining && w.hidden != 0.0) {   // HiddenStatesLoss(hidden, rec_hidden[:, 1:].detach()) (trainer.py:313, losses.py:30-53)
+        const T4& rh = c->rec_hidden; const T4& hd = c->hidden;
+        TV a{rh.d + rh.sn, B, (T - 1) * rh.H, rh.W, rh.C, (long)T * rh.sn, rh.ld};
+        TV b{hd.d, B, (T - 1) * hd.H, hd.W, hd.C, (long)(T - 1) * hd.sn, hd.ld};
+        TV db{hd.g, B, (T - 1) * hd.H, hd.W, hd.C, (long)(T - 1) * hd.sn, hd.ld};
+        nhid = (double)B * (T - 1) * hd.H * hd.W * hd.C;
+        if (!dry) c->ck(loss_mse(a, b, db, (float)(w.hidden / nhid), c->loss_acc + LOSS_HIDDEN, st), "hidden loss");
+    }
     if (!dry) c->ck(head_softmax(c->head2.b.logits, c->q_prob, nullptr, B * (T - 1), K, st), "softmax");
     SmallLossArgs a{};
     a.K = K; a.Da = Da; a.NS = B * (T - 1); a.NT = B * T;
@@ -593,7 +664,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     a.mi_lamb = (float)w.mi_entropy_lambda; a.w_mi = (float)w.mi; a.w_entropy = (float)w.entropy; a.w_dirkl = (float)w.dir_kl; a.w_statekl = (float)w.state_kl;
     a.acc = c->loss_acc;
     if (!dry) c->ck(loss_small(a, st), "loss_small");
-    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, 0.0, st), "loss_finalize");
+    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, st), "loss_finalize");
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
         hipEvent_t e = c->sev();
@@ -659,6 +730,10 @@ static int get_output(caddy_ctx* c, int id, void* dst, bool grad) {
     if (grad && (id == 5 || id == 7 || id == 11 || id == 13 || id == 14 || id == 17 || id == 19)) { set_error("no gradient is kept for this output"); return -2; }
     const HeadBufs& a = c->head1.b; const HeadBufs& r = c->head2.b;
     const size_t NS = (size_t)B * (T - 1), NT = (size_t)B * T;
+    if (c->pretraining) {   // tuple order of forward_pretraining (model.py:463-468): 4 = rec. hidden states, 5.. = full-model 4..8 shifted by one
+        if (id == 4) return nchw(c->rec_hidden);
+        if (id >= 5 && id <= 9) id -= 1;
+    }
     switch (id) {
         case 0: case 100: return nchw(c->frames[0]);
         case 101: return nchw(c->frames[1]);
@@ -733,6 +808,7 @@ long caddy_trainable_floats(const caddy_config* cfg) { if (!check_cfg(cfg)) retu
 static void dry_sizes(const caddy_config* cfg, size_t* persist, size_t* act) {
     caddy_ctx* c = make_ctx(cfg, nullptr, nullptr, nullptr, (size_t)1 << 50);
     forward_full(c, nullptr, 1, 1.f, nullptr, 1, nullptr, nullptr);
+    forward_pretraining(c, nullptr, 1.f, nullptr, 1, nullptr, nullptr);     // Arena::high keeps the maximum of both graphs
     *persist = (c->persist.high + 4095) & ~(size_t)4095;
     *act = (c->act.high + 4095) & ~(size_t)4095;
     delete c;
@@ -762,6 +838,11 @@ int caddy_forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, c
     if (!obs || !noise) { set_error("null input"); return -2; }
     return forward_full(c, obs, gt_init, tau, noise, training, samples_in, variations_in);
 }
+int caddy_forward_pretraining(caddy_ctx* c, const float* obs, float tau, const caddy_noise* noise, int training, const float* samples_in, const float* variations_in) {
+    c->fail = false;
+    if (!obs || !noise) { set_error("null input"); return -2; }
+    return forward_pretraining(c, obs, tau, noise, training, samples_in, variations_in);
+}
 int caddy_get_output(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, false); }
 int caddy_get_output_grad(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, true); }
 int caddy_loss_backward(caddy_ctx* c, const caddy_loss_cfg* cfg, double* losses_host) { c->fail = false; return loss_backward(c, cfg, losses_host); }
@@ -789,14 +870,15 @@ int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per
     }
     return n;
 }
-int caddy_profile_end(caddy_ctx* c, double* out18) {   // 6 kernel families x (launches, algorithmic FLOPs, milliseconds)
+int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (11) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 44 doubles
     hipStreamSynchronize(c->stream);
     if (c->side) hipStreamSynchronize(c->side);
-    for (int i = 0; i < 18; i++) out18[i] = 0.0;
+    for (int i = 0; i < 4 * CK_COUNT; i++) out18[i] = 0.0;
     for (auto& r : c->prof_recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
-        out18[r.fam * 3] += 1.0; out18[r.fam * 3 + 1] += r.flops; out18[r.fam * 3 + 2] += ms;
+        if (r.fam < 0 || r.fam >= CK_COUNT) continue;
+        out18[r.fam * 4] += 1.0; out18[r.fam * 4 + 1] += r.flops; out18[r.fam * 4 + 2] += ms; out18[r.fam * 4 + 3] += r.bytes;
     }
     c->prof = false; c->prof_recs.clear();
     return 0;

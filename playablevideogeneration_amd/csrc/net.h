@@ -75,7 +75,8 @@ struct caddy_ctx {
     float* centroids = nullptr;
     // per-forward state
     int gt_init = 0; float tau = 1.f;
-    T4 obs, x65_gt, rec_x65, hidden, frames[3], attn_gt;
+    T4 obs, x65_gt, rec_x65, hidden, frames[3], attn_gt, rec_hidden;
+    bool pretraining = false;         // last forward was forward_pretraining (model.py:290-468)
     HeadState head1, head2;
     float *q_prob = nullptr;
     double* loss_acc = nullptr;
@@ -84,7 +85,7 @@ struct caddy_ctx {
     int hs, ws;   // state resolution
 
     // ---- optional per-launch timing of the conv kernels (HIP events on the launch stream; bench.py roofline) ----
-    struct ProfRec { hipEvent_t a, b; int fam; double flops; int P, K, Cout, KS, kind; };   // kind: 0 fwd, 1 dgrad (accumulate), 2 wgrad
+    struct ProfRec { hipEvent_t a, b; int fam; double flops; int P, K, Cout, KS, kind; double bytes; };   // kind: 0 fwd, 1 dgrad (accumulate), 2 wgrad
     bool prof = false;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

@@ -48,6 +48,7 @@ def _bind(lib):
     lib.caddy_ctx_destroy.argtypes = [C.c_void_p]
     lib.caddy_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.caddy_forward_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.caddy_forward_pretraining.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.caddy_get_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.caddy_get_output_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.caddy_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -138,10 +139,9 @@ class Engine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {e[0]: self.view(e).detach().clone() for e in self.table}
 
-    # ---- forward (Model.forward, full-model mode) ----
-    def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
-                     samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
-        B, T, S, H, W, K, Da, Ch = self.B, self.T, self.S, self.H, self.W, self.K, self.Da, self.Ch
+    # ---- forward (Model.forward: full-model mode and pretraining mode) ----
+    def _prepare(self, obs, noise, samples_in, variations_in):
+        B, T, S, H, W = self.B, self.T, self.S, self.H, self.W
         assert tuple(obs.shape) == (B, T, 3 * S, H, W), obs.shape
         dev = self.device
         obs = obs.to(dev, torch.float32).contiguous()
@@ -152,31 +152,55 @@ class Engine:
         vi = variations_in.to(dev, torch.float32).contiguous() if variations_in is not None else None
         self._keep = [obs, nz, si, vi]
         self._stream()
-        self._check(self.lib.caddy_forward_full(self.ctx, obs.data_ptr(), gt_init, float(tau), C.byref(cn), int(training),
-                                                si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
-        if not fetch_outputs:      # fused-loss training path: outputs stay in the workspace, only loss scalars leave
-            return None
-        hs, ws = H // 8, W // 8
+        return obs, cn, si, vi
+
+    def _fetch(self, pretraining: bool) -> List:
+        """Outputs in the reference's tuple order: forward_full_model (model.py:280-286) or forward_pretraining (:463-468)."""
+        B, T, S, H, W, K, Da, Ch = self.B, self.T, self.S, self.H, self.W, self.K, self.Da, self.Ch
+        dev, hs, ws = self.device, H // 8, W // 8
         f32 = dict(dtype=torch.float32, device=dev)
-        shapes = {0: (B, T - 1, 3, H, W), 2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, T - 1, Ch, hs, ws), 6: (B, T - 1, K),
-                  7: (B, T - 1, K), 8: (B, T, 1, hs, ws), 9: (B, T - 1, 1, hs, ws), 10: (B, T - 1, 2, Da), 11: (B, T - 1, Da),
-                  12: (B, T, 2, Da), 13: (B, T, Da), 14: (B, T - 1, Da), 15: (B, T - 1, K), 16: (B, T - 1, 2, Da), 17: (B, T - 1, Da),
-                  18: (B, T, 2, Da), 19: (B, T, Da)}
+        n = T - 1
+        Tf = T if pretraining else n                      # reconstructed frames: all T in pretraining mode
+        act = {"logits": (B, n, K), "samples": (B, n, K), "ddist": (B, n, 2, Da), "dirs": (B, n, Da), "sdist": (B, T, 2, Da), "ssamp": (B, T, Da), "var": (B, n, Da)}
+        if pretraining:
+            shapes = {0: (B, Tf, 3, H, W), 2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, T, Ch, hs, ws), 5: (B, n, Ch, hs, ws),
+                      7: act["logits"], 8: act["samples"], 9: (B, T, 1, hs, ws)}
+            sel_id = 6
+        else:
+            shapes = {0: (B, Tf, 3, H, W), 2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, n, Ch, hs, ws),
+                      6: act["logits"], 7: act["samples"], 8: (B, T, 1, hs, ws), 9: (B, n, 1, hs, ws)}
+            sel_id = 5
+        shapes.update({10: act["ddist"], 11: act["dirs"], 12: act["sdist"], 13: act["ssamp"], 14: act["var"], 15: act["logits"],
+                       16: act["ddist"], 17: act["dirs"], 18: act["sdist"], 19: act["ssamp"]})
         out = [None] * 20
         for i, shp in shapes.items():
             t = torch.empty(shp, **f32)
             self._check(self.lib.caddy_get_output(self.ctx, i, t.data_ptr()))
             out[i] = t
-        sel = torch.empty((B, T - 1), dtype=torch.int64, device=dev)
-        self._check(self.lib.caddy_get_output(self.ctx, 5, sel.data_ptr()))
-        out[5] = sel
+        sel = torch.empty((B, n), dtype=torch.int64, device=dev)
+        self._check(self.lib.caddy_get_output(self.ctx, sel_id, sel.data_ptr()))
+        out[sel_id] = sel
         multi = [out[0]]
         for r in (1, 2):
-            t = torch.empty((B, T - 1, 3, H >> r, W >> r), **f32)
+            t = torch.empty((B, Tf, 3, H >> r, W >> r), **f32)
             self._check(self.lib.caddy_get_output(self.ctx, 100 + r, t.data_ptr()))
             multi.append(t)
         out[1] = multi
         return out
+
+    def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
+                     samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
+        obs, cn, si, vi = self._prepare(obs, noise, samples_in, variations_in)
+        self._check(self.lib.caddy_forward_full(self.ctx, obs.data_ptr(), gt_init, float(tau), C.byref(cn), int(training),
+                                                si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
+        return self._fetch(False) if fetch_outputs else None      # fused-loss training: outputs stay in the workspace
+
+    def forward_pretraining(self, obs: torch.Tensor, tau: float, noise: Dict[str, torch.Tensor], training=True,
+                            samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
+        obs, cn, si, vi = self._prepare(obs, noise, samples_in, variations_in)
+        self._check(self.lib.caddy_forward_pretraining(self.ctx, obs.data_ptr(), float(tau), C.byref(cn), int(training),
+                                                       si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
+        return self._fetch(True) if fetch_outputs else None
 
     def output_grad(self, idx: int, like: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(output idx) after loss_backward (debug / autograd bridge)."""
@@ -221,8 +245,9 @@ class Engine:
                                                  frame.data_ptr(), nxt.data_ptr()))
         return frame, nxt
 
-    CONV_FAMILIES = ["k_conv_fwd<2,2,2,2>", "k_conv_fwd<2,1,2,2>", "k_conv_fwd<1,1,4,1>",
-                     "k_conv_wgrad<2,2,2,2>", "k_conv_wgrad<1,2,2,2>", "k_conv_wgrad<1,1,1,4>"]
+    CONV_FAMILIES = ["k_conv_fwd<2, 2, 2, 2, 0, 1>", "k_conv_fwd<2, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 4, 1, 0, 1>",
+                     "k_conv_thin_out", "k_conv_thin_in", "k_conv_wgrad<2, 2, 2, 2>", "k_conv_wgrad<1, 2, 2, 2>", "k_conv_wgrad<1, 1, 1, 4>",
+                     "k_conv_wgrad_small", "k_wgrad_thin"]      # rocprofv3 kernel names (exact-fp32 build of k_conv_fwd)
 
     def profile_begin(self):
         self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))
@@ -233,10 +258,10 @@ class Engine:
         return [tuple(buf[7 * i + j] for j in range(7)) for i in range(n)]
 
     def profile_end(self):
-        """-> {kernel family: (launches, algorithmic FLOPs, milliseconds)} measured with HIP events on the launch stream."""
-        out = (C.c_double * 18)()
+        """-> {kernel: (launches, algorithmic FLOPs, milliseconds, algorithmic bytes)}, HIP events on the launch stream."""
+        out = (C.c_double * 44)()
         self._check(self.lib.caddy_profile_end(C.c_void_p(self.ctx), out))
-        return {n: (int(out[3 * i]), out[3 * i + 1], out[3 * i + 2]) for i, n in enumerate(self.CONV_FAMILIES)}
+        return {n: (int(out[4 * i]), out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]) for i, n in enumerate(self.CONV_FAMILIES)}
 
     def bn_calls(self) -> Dict[str, int]:
         buf = C.create_string_buffer(128)

@@ -189,11 +189,9 @@ class Model(nn.Module):
     # ---- Model.forward (model/main_model/model.py:57-82) -----------------------------------------------------------------
     def forward(self, batch_tuple, ground_truth_observations_init=0, pretraining=False, gumbel_temperature=None,
                 action_sampler=None, action_variation_sampler=None, fetch_outputs=True):
-        if pretraining:
-            if self._pretraining_detach:
-                raise Exception("Pretraining detach is not supported by the current model")
-            raise NotImplementedError("forward_pretraining (model.py:290-468) is not part of this round's HIP path; see DESIGN.md")
-        if ground_truth_observations_init <= 0:
+        if pretraining and self._pretraining_detach:
+            raise Exception("Pretraining detach is not supported by the current model")
+        if not pretraining and ground_truth_observations_init <= 0:
             raise Exception("To forward the full model specify a number of ground truth observations > 0")
         if self._forbid_gt_actions:
             raise Exception("The use of ground truth actions during training is not supported by the selected model")
@@ -213,8 +211,11 @@ class Model(nn.Module):
             torch.randn((B, self.random_noise_size))        # model.py:220/496: drawn, never consumed by R
         noise["eps_states_rec"] = torch.randn((B * T, Da), dtype=torch.float32)
         noise["eps_dirs_rec"] = torch.randn((B, n, Da), dtype=torch.float32).reshape(B * n, Da)
-        out = eng.forward_full(observations, int(ground_truth_observations_init), float(self.current_temperature), noise,
-                               training=self.training, fetch_outputs=fetch_outputs)
+        if pretraining:
+            out = eng.forward_pretraining(observations, float(self.current_temperature), noise, training=self.training, fetch_outputs=fetch_outputs)
+        else:
+            out = eng.forward_full(observations, int(ground_truth_observations_init), float(self.current_temperature), noise,
+                                   training=self.training, fetch_outputs=fetch_outputs)
         if self.training:
             self._sync_bn_counters(eng, (B, T))
         self.last_engine = eng

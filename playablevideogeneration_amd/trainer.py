@@ -46,11 +46,15 @@ class Trainer:
     def _get_current_lr(self) -> float:
         return self.lr * self.lr_gamma ** sum(1 for m in self.lr_schedule if self.opt_steps >= m)     # MultiStepLR
 
-    def loss_weights(self) -> Dict[str, float]:
+    def loss_weights(self, pretraining=False) -> Dict[str, float]:
         lw = self.config["training"]["loss_weights"]
-        return dict(rec=lw["reconstruction_loss_lambda"], states=lw["states_rec_lambda"], entropy=lw["entropy_lambda"],
-                    dir_kl=lw["action_directions_kl_lambda"], mi=lw["action_mutual_information_lambda"],
-                    state_kl=lw["action_state_distribution_kl_lambda"], mi_entropy=self.action_mutual_infromation_entropy_lambda)
+        sfx = "_pretraining" if pretraining else ""          # training/trainer.py:340-347 vs :494-500
+        w = dict(rec=lw["reconstruction_loss_lambda" + sfx], states=lw["states_rec_lambda" + sfx], entropy=lw["entropy_lambda" + sfx],
+                 dir_kl=lw["action_directions_kl_lambda" + sfx], mi=lw["action_mutual_information_lambda" + sfx],
+                 state_kl=lw["action_state_distribution_kl_lambda" + sfx], mi_entropy=self.action_mutual_infromation_entropy_lambda)
+        if pretraining:
+            w["hidden"] = lw["hidden_states_rec_lambda_pretraining"]
+        return w
 
     # ---- Trainer.compute_losses (trainer.py:400-550): forward + fused losses + backward ----
     def compute_losses(self, model, batch, observations_count: int):
@@ -74,6 +78,27 @@ class Trainer:
                      "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
                      "observations_rec_loss_r0": li["l1_r0"], "observations_rec_loss_r1": li["l1_r1"], "observations_rec_loss_r2": li["l1_r2"],
                      "ground_truth_observations": gt, "gumbel_temperature": tau, "observations_count": observations_count}
+        return li["total"], loss_info, {}
+
+    # ---- Trainer.compute_losses_pretraining (trainer.py:241-398) ----
+    def compute_losses_pretraining(self, model, batch, observations_count: int):
+        tau = self.get_gumbel_temperature()
+        batch_tuple = batch.to_tuple() if hasattr(batch, "to_tuple") else batch
+        model(batch_tuple, pretraining=True, gumbel_temperature=tau, fetch_outputs=False)
+        eng = model.module.last_engine
+        if self.SMOOTH_MI and self.mi_ema is not None:
+            eng.mi_ema = self.mi_ema
+        w = self.loss_weights(pretraining=True)
+        li = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha)
+        if self.SMOOTH_MI:
+            self.mi_ema = eng.mi_ema
+        loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
+                     "loss_component_hidden_states_rec": w["hidden"] * li["hidden"], "loss_component_entropy": w["entropy"] * li["entropy"],
+                     "loss_component_action_directions_kl_divergence": w["dir_kl"] * li["dir_kl"],
+                     "loss_component_action_mutual_information": w["mi"] * li["mi"], "loss_component_action_state_distribution_kl": w["state_kl"] * li["state_kl"],
+                     "avg_observations_rec_loss": li["rec"], "states_rec_loss": li["states"], "hidden_states_rec_loss": li["hidden"], "entropy_loss": li["entropy"],
+                     "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
+                     "gumbel_temperature": tau, "observations_count": observations_count}
         return li["total"], loss_info, {}
 
     def optimizer_step(self, model, world_size: int = 1):
@@ -100,8 +125,9 @@ class Trainer:
             if self.get_observations_count() != observations_count:
                 break
             if self.global_step <= self.config["training"].get("pretraining_steps", 0):
-                raise NotImplementedError("pretraining steps (compute_losses_pretraining) are not part of this round's HIP path")
-            loss, loss_info, _ = self.compute_losses(model, batch, observations_count)
+                loss, loss_info, _ = self.compute_losses_pretraining(model, batch, observations_count)
+            else:
+                loss, loss_info, _ = self.compute_losses(model, batch, observations_count)
             self.optimizer_step(model)
             loss_info["loss"] = loss
             if self.logger is not None:

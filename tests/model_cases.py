@@ -154,6 +154,48 @@ def oracle_case(lib, dev, c, fwd_tol=3e-4):
     assert torch.isfinite(eng.grads).all()
 
 
+def pretraining_case(lib, dev, name="pre_main_s4", fwd_tol=2e-4):
+    """forward_pretraining vs the reference's golden vector (S=4 re-stacking included) and the oracle; loss terms incl. the
+    hidden-states loss; gradients vs the fp64 oracle (same robust criterion as full_case)."""
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        oout = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_pretraining(obs, tau=c["tau"], noise=nz)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    out = eng.forward_pretraining(obs, c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+    _cmp(out, list(oout), fwd_tol, name + " vs oracle")
+    _cmp(out, H.golden_outputs(z), fwd_tol, name + " vs reference golden")
+    w = dict(H.LOSS_W, hidden=1.0)
+    losses = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2)
+
+    def orun(dtype):
+        Po = {k: (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in P.items()}
+        for k in Po:
+            if O.is_trainable(k):
+                Po[k].requires_grad_(True)
+        o = O.Oracle(d, Po, training=True).forward_pretraining(obs.to(dtype), tau=c["tau"], noise=O.Noise(replay=[t.to(dtype) for t in nz.record]))
+        total, comp, _ = O.pretraining_loss(o, obs.to(dtype), w, mi_ema=torch.full((d.K, d.K), 1.0 / (d.K * d.K), dtype=dtype), mi_alpha=0.2)
+        total.backward()
+        return Po, total, comp
+    P64, t64, c64 = orun(torch.float64)
+    P32, _, _ = orun(torch.float32)
+    assert abs(losses["total"] - t64.item()) < 1e-4 * max(1.0, abs(t64.item())), (losses["total"], t64.item())
+    assert abs(losses["hidden"] - c64["hidden"].item()) < 1e-4 * max(1.0, abs(c64["hidden"].item()))
+    num_h = num_o = den = 0.0
+    for n, _ in O.param_table(d):
+        if not O.is_trainable(n):
+            continue
+        g64 = P64[n].grad if P64[n].grad is not None else torch.zeros_like(P64[n])
+        g32 = (P32[n].grad if P32[n].grad is not None else torch.zeros_like(P32[n])).double()
+        g = eng.grad_view(n).cpu().double()
+        num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
+    rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+    assert rel_h <= max(5 * rel_o, 3e-2), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+
+
 def rollout_case(name, lib, dev, tol=2e-4):
     c, z = H.load_case(name)
     d, P, obs = H.inputs_of(c)

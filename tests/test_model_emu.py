@@ -29,3 +29,7 @@ def test_full_main_s4_hard_gumbel():
 
 def test_rollout_main_s4():
     M.rollout_case("rollout_main_s4", load_emu(), "cpu")
+
+
+def test_pretraining_main_s4():
+    M.pretraining_case(load_emu(), "cpu")

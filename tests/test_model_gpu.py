@@ -29,6 +29,10 @@ def test_rollout_parity(lib, name):
     M.rollout_case(name, lib, "cuda")
 
 
+def test_pretraining_parity(lib):
+    M.pretraining_case(lib, "cuda")
+
+
 def test_larger_geometry_vs_oracle(lib):
     """breakout-reduced hyper-parameters at 64x64, T=5 (BASELINE configs[0] geometry, shortened) vs the CPU oracle."""
     M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=5, H=64, W=64, gt=3, tau=0.85))
