@@ -121,6 +121,8 @@ def main():
     log(f"engine created: workspace {eng.ws_bytes / 2**30:.1f} GiB, {eng.n_train} trainable floats")
     init_parameters(eng, seed=0)                            # identical replicas on every rank
     log("parameters initialised")
+    if world > 1:
+        eng.enable_data_parallel()                          # global-batch centroid sums + MI joint matrix (tiny all-reduces)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1     # each rank owns its shard of the global batch
     step_no = [0]

@@ -78,6 +78,13 @@ size_t caddy_workspace_bytes(const caddy_config* cfg);
 caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes);
 void caddy_ctx_destroy(caddy_ctx* ctx);
 int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
+/* Data parallelism (one process per GPU): `hook(ptr, n, user)` must sum the n floats at device pointer `ptr` (inside the
+ * workspace) over all ranks, in place, stream-ordered (RCCL all-reduce).  It is called for the centroid-EMA sums
+ * (centroid_estimator.py:61-63) during caddy_forward_* and for the K x K joint matrix of the mutual-information loss
+ * (losses.py:262) during caddy_loss_backward, which gives both the reference's global-batch semantics (the reference
+ * computes them on GPU0 over the gathered batch under nn.DataParallel).  The parameter gradients themselves are reduced by
+ * the caller with ONE all-reduce of the flat gradient buffer after caddy_loss_backward. */
+int caddy_set_allreduce_hook(caddy_ctx* ctx, void (*hook)(float* device_ptr, int count, void* user), void* user, int world_size);
 
 /* --- Model.forward(batch_tuple, ground_truth_observations_init, gumbel_temperature=...) in full-model mode:
  *     model/main_model/model.py:57-82 -> forward_full_model :84-286.  obs: (B,T,3S,H,W) fp32 device, reference layout.

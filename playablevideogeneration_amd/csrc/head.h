@@ -34,8 +34,11 @@ struct SampleCfg {
     const float* samples_in;    // mode 2
     const float* variations_in; // optional external variations (evaluation action_variation_sampler)
 };
+typedef void (*allreduce_hook_t)(float* device_ptr, int count, void* user);   // in-place sum over ranks, enqueued on the caller's stream
+
 struct SmallLossArgs {
     int K, Da, NS, NT;
+    float* Pbuf; float mi_grad_scale;   // joint matrix scratch (K*K), world size
     const float *p, *q, *logp;  // softmax(logits), softmax(reconstructed logits), log_softmax(logits)   (NS, K)
     const float *ddist, *sdist, *sdist_r;
     float *d_logits, *d_logits_r, *d_ddist, *d_sdist_r;
@@ -46,9 +49,9 @@ struct SmallLossArgs {
 
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st);
 int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
-int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, hipStream_t st);
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, hipStream_t st);
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st);
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st);
 int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st);
-int loss_small(const SmallLossArgs& a, hipStream_t st);
+int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStream_t st);
 int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, hipStream_t st);

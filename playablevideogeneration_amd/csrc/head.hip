@@ -51,9 +51,10 @@ __global__ void k_head_dirs(HeadBufs h, HeadParams p, int B, int T) {
         h.logits[n * p.K + k] = l;
     }
 }
-// ---- sampling: softmax / log-softmax, centroid EMA (train), Gumbel sample, variations, arg-max.  Single block. --------
-__global__ void k_head_sample(HeadBufs h, HeadParams p, SampleCfg c, int NS) {
-    __shared__ float cen[16 * 8];
+// ---- sampling, part 1: softmax / log-softmax and the centroid-EMA sums (centroid_estimator.py:61-63).  Single block. ----------
+// cen_sums[k*Da+d] = sum_n p_nk * dmu_nd, cen_sums[K*Da + k] = sum_n p_nk.  Under data parallelism these sums are all-reduced
+// between part 1 and part 2 so that every rank applies the global-batch estimate (collective 3).
+__global__ void k_head_probs(HeadBufs h, HeadParams p, int NS, float* cen_sums) {
     const int K = p.K, Da = p.Da;
     for (int n = threadIdx.x; n < NS; n += blockDim.x) {
         const float* l = h.logits + n * K;
@@ -67,11 +68,25 @@ __global__ void k_head_sample(HeadBufs h, HeadParams p, SampleCfg c, int NS) {
     __syncthreads();
     if (threadIdx.x < K * Da) {
         int k = threadIdx.x / Da, d = threadIdx.x - k * Da;
+        float num = 0.f;
+        for (int n = 0; n < NS; n++) num += h.prob[n * K + k] * h.ddist[(long)n * 2 * Da + d];
+        cen_sums[k * Da + d] = num;
+    } else if (threadIdx.x < K * Da + K) {
+        int k = threadIdx.x - K * Da;
+        float den = 0.f;
+        for (int n = 0; n < NS; n++) den += h.prob[n * K + k];
+        cen_sums[K * Da + k] = den;
+    }
+}
+// ---- sampling, part 2: centroid EMA (train), Gumbel sample, variations, arg-max.  Single block. ---------------------------------
+__global__ void k_head_sample(HeadBufs h, HeadParams p, SampleCfg c, int NS, const float* cen_sums) {
+    __shared__ float cen[16 * 8];
+    const int K = p.K, Da = p.Da;
+    if (threadIdx.x < K * Da) {
+        int k = threadIdx.x / Da, d = threadIdx.x - k * Da;
         float cv = c.centroids[k * Da + d];
         if (c.training) {   // centroid_estimator.py:61-68 (means of the direction distribution, soft assignments)
-            float num = 0.f, den = 0.f;
-            for (int n = 0; n < NS; n++) { float pk = h.prob[n * K + k]; num += pk * h.ddist[(long)n * 2 * Da + d]; den += pk; }
-            cv = cv * (1.f - c.alpha) + (num / den) * c.alpha;
+            cv = cv * (1.f - c.alpha) + (cen_sums[k * Da + d] / cen_sums[K * Da + k]) * c.alpha;
             c.centroids[k * Da + d] = cv;
         }
         cen[k * Da + d] = cv;
@@ -101,8 +116,7 @@ __global__ void k_head_sample(HeadBufs h, HeadParams p, SampleCfg c, int NS) {
         if (c.mode == 1 && c.hard) { for (int k = 0; k < K; k++) y[k] = (k == am) ? 1.f : 0.f; }   // straight-through value
         h.selected[n] = am;
         float* aux = h.aux + (long)n * AUX_LD;
-        float sy = 0.f;
-        for (int k = 0; k < K; k++) { aux[k] = y[k]; h.samples[n * K + k] = y[k]; sy += y[k]; }
+        for (int k = 0; k < K; k++) { aux[k] = y[k]; h.samples[n * K + k] = y[k]; }
         for (int d = 0; d < Da; d++) {
             float v;
             if (c.variations_in) v = c.variations_in[n * Da + d];
@@ -239,6 +253,17 @@ __global__ __launch_bounds__(256) void k_loss_mse(TV a, TV b, TV db, float gscal
     s = block_sum(s, sh);
     if (threadIdx.x == 0) atomicAdd(acc, s);
 }
+// joint matrix P = sum_n p_n q_n^T of the mutual-information loss (losses.py:243-262); all-reduced across ranks under data
+// parallelism BEFORE symmetrise / normalise so the loss equals the reference's global-batch value (collective 2)
+__global__ void k_joint_matrix(SmallLossArgs a) {
+    const int K = a.K;
+    if (threadIdx.x < K * K) {
+        int i = threadIdx.x / K, j = threadIdx.x - i * K;
+        float s = 0.f;
+        for (int n = 0; n < a.NS; n++) s += a.p[n * K + i] * a.q[n * K + j];
+        a.Pbuf[i * K + j] = s;
+    }
+}
 // entropy + KL(dir || N(0,1)) + (smooth) mutual information + KL(general gaussian); single block; writes gradient seeds.
 __global__ void k_loss_small(SmallLossArgs a) {
     __shared__ float Pm[16 * 16], Gm[16 * 16], rowv[16], colv[16];
@@ -246,13 +271,7 @@ __global__ void k_loss_small(SmallLossArgs a) {
     __shared__ float Ssum;
     const int K = a.K, Da = a.Da, NS = a.NS, NT = a.NT;
     const float FEPS = 2.220446049250313e-16f;   // sys.float_info.epsilon (losses.py:270)
-    // joint matrix P = sum_n p_n q_n^T
-    if (threadIdx.x < K * K) {
-        int i = threadIdx.x / K, j = threadIdx.x - i * K;
-        float s = 0.f;
-        for (int n = 0; n < NS; n++) s += a.p[n * K + i] * a.q[n * K + j];
-        Pm[i * 16 + j] = s;
-    }
+    if (threadIdx.x < K * K) { int i = threadIdx.x / K, j = threadIdx.x - i * K; Pm[i * 16 + j] = a.Pbuf[i * K + j]; }   // (globally reduced) joint matrix
     __syncthreads();
     if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < K; i++) for (int j = 0; j < K; j++) s += Pm[i * 16 + j]; Ssum = s; }
     __syncthreads();
@@ -283,7 +302,7 @@ __global__ void k_loss_small(SmallLossArgs a) {
         if (mp >= FEPS) g += -(logf(Mc) - a.mi_lamb * logf(Rc) - a.mi_lamb * logf(Cc)) - 1.f;
         if (rowv[mi] >= FEPS) { float s = 0.f; for (int k = 0; k < K; k++) s += Pm[mi * 16 + k]; g += a.mi_lamb * s / Rc; }
         if (colv[mj] >= FEPS) { float s = 0.f; for (int k = 0; k < K; k++) s += Pm[k * 16 + mj]; g += a.mi_lamb * s / Cc; }
-        Gm[mi * 16 + mj] = g * (a.ema ? a.ema_alpha : 1.f) * a.w_mi;     // d total / d m
+        Gm[mi * 16 + mj] = g * (a.ema ? a.ema_alpha : 1.f) * a.w_mi * a.mi_grad_scale;     // d total / d m (x world size: the gradient all-reduce averages)
     }
     __syncthreads();
     // m = sym / S : g_sym = g_m / S - sum(g_m * sym) / S^2   (sym recomputed from P kept in registers: sym)
@@ -372,9 +391,11 @@ int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream
     hipLaunchKernelGGL(k_head_dirs, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, B, T);
     return 0;
 }
-int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, hipStream_t st) {
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, hipStream_t st) {
     if (p.K > 16 || p.Da > 8 || p.K + p.Da > AUX_LD) return -1;
-    hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c, NS);
+    hipLaunchKernelGGL(k_head_probs, dim3(1), dim3(256), 0, st, h, p, NS, cen_sums);
+    if (hook && c.training) hook(cen_sums, p.K * p.Da + p.K, user);
+    hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c, NS, (const float*)cen_sums);
     return 0;
 }
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {
@@ -395,8 +416,10 @@ int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, 
     hipLaunchKernelGGL(k_loss_mse, dim3((unsigned)blocks), dim3(256), 0, st, a, b, db, gscale, acc);
     return 0;
 }
-int loss_small(const SmallLossArgs& a, hipStream_t st) {
+int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStream_t st) {
     if (a.K > 16 || a.Da > 8) return -1;
+    hipLaunchKernelGGL(k_joint_matrix, dim3(1), dim3(256), 0, st, a);
+    if (hook) hook(a.Pbuf, a.K * a.K, user);
     hipLaunchKernelGGL(k_loss_small, dim3(1), dim3(256), 0, st, a);
     return 0;
 }

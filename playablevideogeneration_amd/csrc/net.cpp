@@ -481,7 +481,7 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     sc = SampleCfg{};
     sc.mode = samples_in ? 2 : (cfg.use_gumbel ? 1 : 0); sc.hard = cfg.hard_gumbel; sc.training = training ? 1 : 0; sc.use_variations = cfg.use_variations;
     sc.tau = tau; sc.alpha = cfg.centroid_alpha; sc.centroids = centroids; sc.samples_in = samples_in; sc.variations_in = variations_in;
-    if (first) RUN(head_sample(b, hp, sc, NS, stream));
+    if (first) { float* cs = falloc(16 * 8 + 16); RUN(head_sample(b, hp, sc, NS, cs, hook, hook_user, stream)); }
     if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tape.push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
@@ -553,7 +553,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
         }
     }
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
-    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions);
+    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
     c->have_forward = true;
     return finish(c);
 }
@@ -611,7 +611,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     c->rec_x65 = c->alloc(B * T, c->hs, c->ws, 65, 68);
     c->encode(stacked, true, &c->rec_x65);
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
-    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions);
+    c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
     c->have_forward = true;
     return finish(c);
 }
@@ -663,7 +663,9 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     a.ema = lc->mi_ema; a.ema_alpha = lc->mi_ema_alpha; a.update_ema = lc->update_mi_ema;
     a.mi_lamb = (float)w.mi_entropy_lambda; a.w_mi = (float)w.mi; a.w_entropy = (float)w.entropy; a.w_dirkl = (float)w.dir_kl; a.w_statekl = (float)w.state_kl;
     a.acc = c->loss_acc;
-    if (!dry) c->ck(loss_small(a, st), "loss_small");
+    a.Pbuf = c->q_prob + (size_t)B * (T - 1) * K;      // K*K floats allocated behind q_prob
+    a.mi_grad_scale = (float)(c->hook ? c->world : 1);
+    if (!dry) c->ck(loss_small(a, c->hook, c->hook_user, st), "loss_small");
     if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, st), "loss_finalize");
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
@@ -833,6 +835,10 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+int caddy_set_allreduce_hook(caddy_ctx* c, void (*hook)(float*, int, void*), void* user, int world_size) {
+    c->hook = world_size > 1 ? hook : nullptr; c->hook_user = user; c->world = world_size > 1 ? world_size : 1;
+    return 0;
+}
 int caddy_forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training, const float* samples_in, const float* variations_in) {
     c->fail = false;
     if (!obs || !noise) { set_error("null input"); return -2; }

@@ -47,6 +47,7 @@ def _bind(lib):
     lib.caddy_ctx_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.caddy_ctx_destroy.argtypes = [C.c_void_p]
     lib.caddy_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_set_allreduce_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.caddy_forward_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.caddy_forward_pretraining.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.caddy_get_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -99,6 +100,20 @@ class Engine:
         self.adam_m = self.adam_v = None
         self.mi_ema = None
         self._keep = []
+
+    def enable_data_parallel(self, process_group=None):
+        """Register the all-reduce hook (torch.distributed: RCCL on the MI355X, gloo in the CPU tests) for the small
+        global-batch reductions (centroid sums, MI joint matrix).  Gradients: call dist.all_reduce(engine.grads) yourself."""
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group)
+        base = self._ws_raw.data_ptr()
+
+        def _hook(ptr, count, _user):
+            off = ptr - base
+            dist.all_reduce(self._ws_raw[off:off + 4 * count].view(torch.float32), group=process_group)
+
+        self._hook_keepalive = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)(_hook)
+        self._check(self.lib.caddy_set_allreduce_hook(self.ctx, C.cast(self._hook_keepalive, C.c_void_p), None, world))
 
     def __del__(self):
         if getattr(self, "ctx", None):

@@ -63,6 +63,7 @@ def _dp_worker(rank, world, port, out):
     P = O.make_params(d, seed=3)
     eng = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device="cpu", lib=load_emu())
     eng.load_state_dict(P)
+    eng.enable_data_parallel()
     g = torch.Generator().manual_seed(100 + rank)
     obs = torch.rand(1, 3, 3, 16, 16, generator=g) * 2 - 1
     noise = {"eps_states": torch.randn(3, 1, generator=g), "eps_dirs": torch.randn(2, 1, generator=g), "gumbel_uniform": torch.rand(2, 3, generator=g),
@@ -72,7 +73,8 @@ def _dp_worker(rank, world, port, out):
     local = eng.grads.clone()
     dist.all_reduce(eng.grads)                      # the N>1 path of bench.py: one flat all-reduce, then Adam with 1/world
     eng.adam_step(1, grad_scale=1.0 / world)
-    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params[:eng.n_train].clone()}, os.path.join(out, f"r{rank}.pt"))
+    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params[:eng.n_train].clone(), "centroids": eng.view("centroid_estimator.estimated_centroids").clone(),
+                "mi_ema": eng.mi_ema.clone()}, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -84,3 +86,5 @@ def test_data_parallel_step_gloo_world2(tmp_path):
     assert torch.allclose(r0["reduced"], r0["local"] + r1["local"], atol=1e-6)       # sum over ranks
     assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["params"], r1["params"])   # trainable replicas stay identical (BN running stats are rank-local, as under nn.DataParallel)
     assert not torch.equal(r0["local"], r1["local"])                                 # shards really differed
+    # global-batch semantics of the small reductions: identical centroids and MI estimator state on every rank
+    assert torch.equal(r0["centroids"], r1["centroids"]) and torch.equal(r0["mi_ema"], r1["mi_ema"])
