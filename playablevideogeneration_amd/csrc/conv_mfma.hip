@@ -442,6 +442,125 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// wgrad, tile-resident (3x3 layers with >= 33 output or > 64 input channels: R's ConvLSTM gates, the 64/128-channel
+// residual blocks of E / A / D).  The one-tap-per-workgroup kernel above re-reads dY and X once per tap (9x) and pads K to
+// 128; here a workgroup owns a 64(o) x 64(k) weight tile for ALL nine taps: a 4x16 pixel tile of dY and the 6x18 halo tile
+// of X are staged in LDS once, every wave keeps nine 32x32 accumulators (one per tap, 144 registers) and walks the pixel
+// pairs {(y,x),(y+2,x)} -- the two MFMA k-lanes -- reading one dY fragment and nine shifted X fragments per step.  Row
+// pitches are padded by 16 floats so the two k-lanes (two rows apart) land in opposite halves of the LDS banks.
+// Workgroups are persistent over spatial tiles (blockIdx.z-strided) with a register prefetch of the next tile, and flush
+// their 9x64x64 partial sums once at the end with fp32 atomics.  OS = 2: 64 output channels (waves 2(o) x 2(k));
+// OS = 1: 32 output channels (waves 2(k) x 2(pixel halves)).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WT_W = 16, WT_H = 4, WT_KC = 64;
+constexpr int WT_HW = WT_W + 2, WT_HH = WT_H + 2;
+constexpr int WT_XROW = WT_HW * WT_KC + 16;
+constexpr int WT_XLOADS = (WT_HH * WT_HW * (WT_KC / 4) + 255) / 256;   // 7 float4 per thread
+
+template <int OS>
+__global__ __launch_bounds__(256) void k_conv_wgrad_tile(WgradArgs a, int tiles_x, int tiles_y) {
+    constexpr int OC = 32 * OS;
+    constexpr int YROW = WT_W * OC + 16;
+    constexpr int YLOADS = WT_H * WT_W * (OC / 4) / 256;               // 4 (OS = 2) or 2 (OS = 1)
+    __shared__ float Xh[WT_HH * WT_XROW];
+    __shared__ float Yt[WT_H * YROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1;
+    const int wm = OS == 2 ? (wave >> 1) : 0;
+    const int wp = OS == 2 ? 0 : (wave >> 1);
+    const int k0 = blockIdx.x * WT_KC, o0 = blockIdx.y * OC;
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+
+    // loader roles: X -- float4 column q (0..15) is fixed per thread, halo pixel = (tid >> 4) + 16 i
+    const int xq = tid & 15;
+    const int kx = k0 + (xq >> 2) * BK;
+    const bool kok = kx < a.Ktot;
+    const SegRef sg = find_seg(a.src, a.nsrc, kok ? kx : 0);
+    int xhy[WT_XLOADS], xhx[WT_XLOADS];
+#pragma unroll
+    for (int i = 0; i < WT_XLOADS; i++) {
+        int pix = (tid >> 4) + 16 * i;
+        xhy[i] = pix / WT_HW; xhx[i] = pix - xhy[i] * WT_HW;
+    }
+    // dY: float4 column yq (0..OC/4-1) fixed per thread
+    const int yq = tid % (OC / 4), ypix0 = tid / (OC / 4);
+    const int yc = o0 + yq * 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    float4 rx[WT_XLOADS], ry[YLOADS];
+    auto gload = [&](long tile) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int ty = rem / tiles_x;
+        int y0 = ty * WT_H, x0 = (rem - ty * tiles_x) * WT_W;
+#pragma unroll
+        for (int i = 0; i < WT_XLOADS; i++) {
+            int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
+            bool ok = kok && xhy[i] < WT_HH && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            rx[i] = load_src4(sg, xq & 3, ok, n, y, x, a.W);
+        }
+#pragma unroll
+        for (int i = 0; i < YLOADS; i++) {
+            int pix = ypix0 + (256 / (OC / 4)) * i;
+            int y = y0 + pix / WT_W, x = x0 + (pix & (WT_W - 1));
+            ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < a.H && x < a.W && yc < a.Cout) ry[i] = load4_masked(a.dy + (long)n * a.dy_sn + ((long)y * a.W + x) * a.dy_ld + yc, yc, a.Cout);
+        }
+    };
+
+    const int half = lane >> 5;
+    const float* ybase = Yt + (2 * half) * YROW + wm * 32 + (lane & 31);
+    const float* xbase = Xh + (2 * half) * WT_XROW + wn * 32 + (lane & 31);
+
+    long tile = blockIdx.z;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += gridDim.z) {
+#pragma unroll
+        for (int i = 0; i < WT_XLOADS; i++)
+            if (xhy[i] < WT_HH) *reinterpret_cast<float4*>(&Xh[xhy[i] * WT_XROW + xhx[i] * WT_KC + xq * 4]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < YLOADS; i++) {
+            int pix = ypix0 + (256 / (OC / 4)) * i;
+            *reinterpret_cast<float4*>(&Yt[(pix / WT_W) * YROW + (pix & (WT_W - 1)) * OC + yq * 4]) = ry[i];
+        }
+        __syncthreads();
+        if (tile + gridDim.z < ntiles) gload(tile + gridDim.z);
+        // 32 steps = (2 row pairs) x (16 columns); OS = 1 splits the steps between the two wave pairs
+        constexpr int NSTEP = OS == 2 ? 32 : 16;
+#pragma unroll 4
+        for (int s0 = 0; s0 < NSTEP; s0++) {
+            const int s = s0 + wp * 16;
+            const int yy = s >> 4, x = s & 15;
+            const float fa = ybase[yy * YROW + x * OC];
+            const float* xr = xbase + yy * WT_XROW + x * WT_KC;
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++)
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, xr[dy * WT_XROW + dx * WT_KC], acc[dy * 3 + dx], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int k = k0 + wn * 32 + (lane & 31);
+    if (k < a.Ktot) {
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // wgrad for narrow layers (Cout <= 32 and K <= 64: E's 16/32-channel blocks, D's last UpBlock).  The generic kernel's
 // 128-wide k tile would be mostly padding there.  Here a workgroup owns a 8x32 pixel tile: dY and the X halo tile are
 // staged in LDS ONCE and reused by all taps; each wave owns the taps {w, w+4, w+8} and keeps one 32(o) x 32*KT(k)
@@ -596,13 +715,31 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (conv_thin_wgrad_try(a, st) == 1) return 0;
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
-    if (a.nsrc == 1 && !a.src[0].bcast && a.Cout <= 32 && a.Ktot <= 64 && a.KS <= 3 && P >= 4096) {   // narrow layers
+    static const int narrow_tile = getenv("CADDY_WGRAD_NARROW_TILE") ? atoi(getenv("CADDY_WGRAD_NARROW_TILE")) : 1;   // A/B aid: K = 64 narrow layers -> tile-resident kernel
+    if (a.nsrc == 1 && !a.src[0].bcast && a.Cout <= 32 && a.Ktot <= 64 && a.KS <= 3 && P >= 4096 && !(narrow_tile && a.Ktot > 32 && a.KS == 3)) {   // narrow layers
         int tx = cdiv(a.W, STW), ty = cdiv(a.H, STH);
         long ntiles = (long)a.N * tx * ty;
         int grid = (int)(ntiles < 512 ? ntiles : 512);
         if (a.Ktot <= 32) hipLaunchKernelGGL((k_conv_wgrad_small<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_small<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         g_last_conv_kernel = CK_WGRAD_SMALL;
+        return 0;
+    }
+    static const int no_tile = getenv("CADDY_WGRAD_TILE") ? !atoi(getenv("CADDY_WGRAD_TILE")) : 0;     // A/B aid: 0 disables the tile-resident kernel
+    if (a.KS == 3 && !no_tile && a.W >= 8 && a.H >= 2) {
+        int tx = cdiv(a.W, WT_W), ty = cdiv(a.H, WT_H);
+        long ntiles = (long)a.N * tx * ty;
+        int kt = cdiv(a.Ktot, WT_KC);
+        bool o32 = a.Cout <= 32;
+        int ot = o32 ? 1 : cdiv(a.Cout, 64);
+        static const int tile_blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;   // one persistent workgroup per CU: measured best inside the training step (the BPTT chain shares the chip)
+        long g = tile_blocks / ((long)kt * ot);
+        if (g < 1) g = 1;
+        if (g > ntiles) g = ntiles;
+        dim3 grid(kt, ot, (unsigned)g);
+        if (o32) hipLaunchKernelGGL((k_conv_wgrad_tile<1>), grid, dim3(256), 0, st, a, tx, ty);
+        else hipLaunchKernelGGL((k_conv_wgrad_tile<2>), grid, dim3(256), 0, st, a, tx, ty);
+        g_last_conv_kernel = CK_WGRAD_TILE;
         return 0;
     }
     int ktiles = cdiv(a.Ktot, 128);

@@ -631,7 +631,16 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     }
     if (c->use_side && !c->side && !dry) {
         static const bool off = getenv("CADDY_SIDE_STREAM") && atoi(getenv("CADDY_SIDE_STREAM")) == 0;
-        if (off) c->use_side = false; else hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        if (off) c->use_side = false;
+        else {
+            // lowest priority: weight-gradient workgroups fill the compute units the BPTT chain leaves idle (R's small feature maps,
+            // point-wise kernels) instead of competing with it
+            static const bool prio = !(getenv("CADDY_SIDE_PRIORITY") && atoi(getenv("CADDY_SIDE_PRIORITY")) == 0);
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (prio) hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
+            else hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        }
     }
     c->sev_used = 0;
     LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda};
@@ -836,7 +845,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_set_allreduce_hook(caddy_ctx* c, void (*hook)(float*, int, void*), void* user, int world_size) {
-    c->hook = world_size > 1 ? hook : nullptr; c->hook_user = user; c->world = world_size > 1 ? world_size : 1;
+    c->hook = hook; c->hook_user = user; c->world = world_size > 1 ? world_size : 1;
     return 0;
 }
 int caddy_forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, const caddy_noise* noise, int training, const float* samples_in, const float* variations_in) {
@@ -876,7 +885,7 @@ int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per
     }
     return n;
 }
-int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (11) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 44 doubles
+int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (12) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 48 doubles
     hipStreamSynchronize(c->stream);
     if (c->side) hipStreamSynchronize(c->side);
     for (int i = 0; i < 4 * CK_COUNT; i++) out18[i] = 0.0;

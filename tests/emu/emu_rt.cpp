@@ -240,6 +240,8 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { *st = nullptr; return 0; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* st, unsigned, int) { *st = nullptr; return 0; }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return 0; }
 hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 hipError_t hipDeviceSynchronize() { return 0; }

@@ -144,6 +144,8 @@ hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamSynchronize(hipStream_t st);
 #define hipStreamNonBlocking 1
 hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t* st, unsigned flags, int priority);
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipDeviceSynchronize();

@@ -45,7 +45,7 @@ def _oracle_run(c, d, P, obs, dtype, record):
     return Po, out
 
 
-def full_case(name, lib, dev, fwd_tol=2e-4):
+def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
     """forward_full_model + losses + backward + BN buffers + centroids + MI-EMA.
 
     Forward / losses / buffers: against the REFERENCE's golden vectors (and the oracle).  Gradients are compared with an
@@ -66,6 +66,8 @@ def full_case(name, lib, dev, fwd_tol=2e-4):
         oout = orc.forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
     eng = make_engine(c, lib, dev)
     eng.load_state_dict(P)
+    if prep is not None:
+        prep(eng)
     out = eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
     _cmp(out, list(oout), fwd_tol, name + " vs oracle")
     _cmp(out, H.golden_outputs(z), fwd_tol, name + " vs reference golden")

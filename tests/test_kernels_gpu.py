@@ -34,6 +34,9 @@ def lib():
     dict(N=2, H=48, W=48, segs=[(16, 0)], Cout=32, KS=1),
     dict(N=2, H=20, W=36, segs=[(32, 0)], Cout=64, KS=3),
     dict(N=2, H=9, W=40, segs=[(24, 0)], Cout=16, KS=3, bias=True),
+    dict(N=2, H=13, W=10, segs=[(64, 0), (9, 1), (40, 0)], Cout=72, KS=3),    # tile-resident wgrad: ragged tiles, 3 segments, 2 k-tiles
+    dict(N=1, H=6, W=21, segs=[(80, 0)], Cout=24, KS=3),                       # tile-resident wgrad, 32-channel output variant
+    dict(N=8, H=32, W=32, segs=[(128, 0), (9, 1), (128, 0)], Cout=512, KS=3, tol=1e-4),   # ConvLSTM gates at R's first resolution (persistent tiles)
 ])
 def test_conv(lib, kw):
     K.conv_case(lib, "cuda", **kw)

@@ -41,3 +41,23 @@ def test_larger_geometry_vs_oracle(lib):
 def test_non_square_frames(lib):
     """state resolution 26x20 -> 13x10 (Breakout 208x160, SURVEY hard part 7)."""
     M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=3, H=208, W=160, gt=1, tau=0.6))
+
+
+def test_allreduce_hook_over_rccl_world1(lib):
+    """The data-parallel hook (centroid sums, MI joint matrix) driven through a real RCCL communicator (world size 1 on this
+    box): stream ordering and the device-pointer -> workspace-view mapping; results must still equal the reference golden."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        calls = []
+
+        def prep(eng):
+            eng.enable_data_parallel(force=True)
+            inner = eng._hook_keepalive
+            calls.append(inner)
+        M.full_case("full_main_s1", lib, "cuda", prep=prep)
+        assert calls
+    finally:
+        dist.destroy_process_group()

@@ -11,6 +11,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 import os
 print("CADDY_FORCE_TILE =", os.environ.get("CADDY_FORCE_TILE"), "CADDY_FORCE_SPLITK =", os.environ.get("CADDY_FORCE_SPLITK"))
 ONLY = os.environ.get("BENCH_ONLY")
+KIND = os.environ.get("BENCH_KIND")
 SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run the forward kernel in accumulate mode)
     ("dgrad lstm1-h 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("dgrad lstm0-h 512->128 @32", 8, 32, 32, 512, 128, 3),
     ("same0 144->256 @32", 8, 32, 32, 144, 256, 3), ("up 272->128 @16", 8, 16, 16, 272, 128, 3),
@@ -45,6 +46,8 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     wa.dy, wa.dy_sn, wa.dy_ld, wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs = dy.data_ptr(), H * W * dy.shape[3], dy.shape[3], Cout, cp, Kt, dwp.data_ptr(), 0
     flops = 2.0 * N * H * W * KS * KS * Cin * Cout
     for label, fn in (("fwd", lambda: lib.caddy_k_conv_fwd(C.byref(a), st)), ("wgrad", lambda: lib.caddy_k_conv_wgrad(C.byref(wa), st))):
+        if KIND and KIND != label:
+            continue
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
