@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--workload", default="bair256_t16_b8", choices=sorted(configs.WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=1)
+    ap.add_argument("--no-rollout", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +200,7 @@ def main():
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
                           "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
                "loss": losses["total"], "roofline": roof}
-        if world == 1:
+        if world == 1 and not a.no_rollout:
             del eng
             torch.cuda.empty_cache()
             res["rollout"] = rollout_fps(dev)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# HBM-traffic counters (separate passes, --kernel-trace only, as the MI355X guide prescribes) -> gpurun_out/pmc_traffic.json
+cd ${GRAFT_REPO_ROOT:-.}
+export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_$c
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o bair -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout > gpurun_out/pmc_$c.log 2>&1
+done
+python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/bair_results.db gpurun_out/pmc_WRITE_SIZE/bair_results.db > gpurun_out/pmc_traffic.json
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+head -c 600 gpurun_out/pmc_traffic.json

@@ -1,0 +1,39 @@
+"""HBM traffic per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only):
+    python tools/pmc_traffic.py <fetch.db> <write.db> > profiles/<round>_pmc_traffic.json
+bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md: on gfx950 the
+counter expression tallies 128-byte read requests of wide coalesced streams at 64 bytes; WRITE_SIZE used as reported)."""
+import collections
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void ", "", n)
+    m = re.match(r"k_map<(\w+)>", n)
+    if m:
+        return "k_map<" + m.group(1) + ">"
+    n = n.split("(")[0]
+    n = re.sub(r"^(k_conv_thin_out|k_conv_thin_in|k_wgrad_thin|k_conv_wgrad_small|k_conv_wgrad_tile)<.*>$", r"\1", n)
+    return n
+
+
+def collect(db, counter):
+    c = sqlite3.connect(db)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for name, val in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        a = agg[short(name)]
+        a[0] += 1
+        a[1] += val
+    return agg
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {"_doc": __doc__.strip().replace("\n", " "), "kernels": {}}
+for k in sorted(fetch):
+    n, f = fetch[k]
+    w = write.get(k, [n, 0.0])[1]
+    out["kernels"][k] = {"launches": n, "fetch_kb_per_launch": f / n, "write_kb_per_launch": w / n, "hbm_bytes_per_launch": (2 * f + w) * 1024 / n}
+print(json.dumps(out, indent=1))
