@@ -54,7 +54,9 @@ struct ConvArgs {
     int accumulate;     // out += result
     int precision;      // 0: exact fp32 MFMA; 3: 3-way split bf16 (hi/mid/lo planes, 6 products, ~fp32 accuracy); 2: 2-way split (3 products)
     int splitk;         // set by the launcher: K range split across blockIdx.z (atomic accumulation; accumulate mode only)
+    float* aux;         // optional device scratch (>= CONV_AUX_BYTES, private to the launching stream): compact weight table of the thin kernels
 };
+constexpr int CONV_AUX_BYTES = 128 * 1024;
 
 // wgrad: dwp[tap][o][k] += sum_p dY[p][o] * A[p+tap][k]   (A = concatenation of the forward sources)
 struct WgradArgs {

@@ -37,12 +37,39 @@ __device__ __forceinline__ void stage_halo(float* lds, const float* base, int ld
     }
 }
 
-template <int CO>
+// Weights are wave-uniform, but reading them with scalar loads thrashes the 16 KB scalar cache (49 taps x CO rows, 4 KB apart in
+// the packed layout): they are staged per 16-channel chunk in LDS as [tap][quad][o] float4 and read back as broadcasts.
+// compact weight tables (built per launch into ConvArgs.aux by k_thin_compact_*): contiguous, so the wave-uniform s_load stream of a
+// workgroup stays inside the scalar cache -- the packed layout's 2-4 KB tap stride maps every row to the same cache set.
+//   thin_out: T[chunk][tap][quad][o < CO]  float4        thin_in: T[group][tap][quad < IC4][o < 16]  float4
+__global__ void k_thin_compact_out(ConvArgs a, int CO, int chunks) {
+    int taps = a.KS * a.KS;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= chunks * taps * 4 * CO) return;
+    int o = idx % CO, tq = idx / CO;
+    int q = tq & 3, ct = tq >> 2;
+    int tap = ct % taps, chunk = ct / taps;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < a.Cout) w = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + o) * a.Ktot + chunk * CK + q * 4);
+    *reinterpret_cast<float4*>(a.aux + (long)idx * 4) = w;
+}
+__global__ void k_thin_compact_in(ConvArgs a, int IC4, int groups) {
+    int taps = a.KS * a.KS;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= groups * taps * IC4 * 16) return;
+    int o = idx & 15, tq = idx >> 4;
+    int q = tq % IC4, gt = tq / IC4;
+    int tap = gt % taps, og = gt / taps;
+    *reinterpret_cast<float4*>(a.aux + (long)idx * 4) = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + og * 16 + o) * a.Ktot + q * 4);
+}
+
+template <int CO, bool WS>
 __global__ __launch_bounds__(256) void k_conv_thin_out(ConvArgs a) {
     __shared__ float lds[(TH + 6) * (TW + 6) * PITCH];
+    __shared__ float wl[WS ? 4 : 49 * 4 * CO * 4];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     const int n = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-    const int R = a.KS >> 1, HWD = TW + 2 * R;
+    const int R = a.KS >> 1, HWD = TW + 2 * R, taps = a.KS * a.KS;
     const ConvSrc s = a.src[0];
     const float* base = s.p + (long)n * s.sn;
     float acc[CO];
@@ -50,18 +77,23 @@ __global__ __launch_bounds__(256) void k_conv_thin_out(ConvArgs a) {
     for (int o = 0; o < CO; o++) acc[o] = 0.f;
     for (int c0 = 0; c0 < s.C; c0 += CK) {
         stage_halo<4>(lds, base, s.ld, s.C, c0, a.H, a.W, y0, x0, R, tid);
+        if (!WS) for (int idx = tid; idx < taps * 4 * CO; idx += 256) {
+            int o = idx % CO, tq = idx / CO;
+            int q = tq & 3, tap = tq >> 2;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < a.Cout) w = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + o) * a.Ktot + c0 + q * 4);
+            *reinterpret_cast<float4*>(&wl[idx * 4]) = w;
+        }
         __syncthreads();
-        for (int tap = 0; tap < a.KS * a.KS; tap++) {
+        for (int tap = 0; tap < taps; tap++) {
             int dy = tap / a.KS, dx = tap - dy * a.KS;
             const float* xp = &lds[((ty + dy) * HWD + tx + dx) * PITCH];
-            const float* wt = a.wp + (long)tap * a.Cout_pad * a.Ktot + c0;
+            const float* __restrict__ wt = WS ? a.aux + ((long)(c0 / CK) * taps + tap) * (4 * CO * 4) : &wl[tap * 4 * CO * 4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float4 x4 = *reinterpret_cast<const float4*>(xp + q * 4);
 #pragma unroll
-                for (int o = 0; o < CO; o++) {
-                    if (o < a.Cout) acc[o] += dot4(x4, *reinterpret_cast<const float4*>(wt + (long)o * a.Ktot + q * 4));
-                }
+                for (int o = 0; o < CO; o++) acc[o] += dot4(x4, *reinterpret_cast<const float4*>(wt + (q * CO + o) * 4));
             }
         }
         __syncthreads();
@@ -82,29 +114,36 @@ __global__ __launch_bounds__(256) void k_conv_thin_out(ConvArgs a) {
 
 // Narrow input (IN <= 4*Q4 channels, K = Ktot <= 32): each thread computes one pixel x 16 output channels on the VALUs with no
 // channel padding; blockIdx.z = n * groups + output group.  Q4 = 4 (pitch 20) also serves 7x7 heads' dgrad; Q4 = 8 (pitch 36) is 3x3/1x1 only.
-template <int Q4, int MAXR>
+template <int Q4, int MAXR, int WQ, bool WS>
 __global__ __launch_bounds__(256) void k_conv_thin_in(ConvArgs a, int groups) {
     constexpr int PITCH = 4 * Q4 + 4;
+    constexpr int MAXT = (2 * MAXR + 1) * (2 * MAXR + 1);
     __shared__ float lds[(TH + 2 * MAXR) * (TW + 2 * MAXR) * PITCH];
+    __shared__ float wl[WS ? 4 : MAXT * WQ * 16 * 4];       // this output group's weights: [tap][quad][o] float4 (LDS broadcasts, see k_conv_thin_out)
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     const int n = blockIdx.z / groups, og = blockIdx.z - n * groups;
     const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-    const int R = a.KS >> 1, HWD = TW + 2 * R;
+    const int R = a.KS >> 1, HWD = TW + 2 * R, taps = a.KS * a.KS;
     const ConvSrc s = a.src[0];
-    const int IC4 = (s.C + 3) >> 2;
+    const int IC4 = (s.C + 3) >> 2;                // <= WQ
     stage_halo<Q4>(lds, s.p + (long)n * s.sn, s.ld, s.C, 0, a.H, a.W, y0, x0, R, tid);
+    if (!WS) for (int idx = tid; idx < taps * IC4 * 16; idx += 256) {
+        int o = idx & 15, tq = idx >> 4;
+        int q = tq % IC4, tap = tq / IC4;
+        *reinterpret_cast<float4*>(&wl[idx * 4]) = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + og * 16 + o) * a.Ktot + q * 4);
+    }
     __syncthreads();
     float acc[16];
 #pragma unroll
     for (int o = 0; o < 16; o++) acc[o] = 0.f;
-    for (int tap = 0; tap < a.KS * a.KS; tap++) {
+    for (int tap = 0; tap < taps; tap++) {
         int dy = tap / a.KS, dx = tap - dy * a.KS;
         const float* xp = &lds[((ty + dy) * HWD + tx + dx) * PITCH];
-        const float* wt = a.wp + ((long)tap * a.Cout_pad + og * 16) * a.Ktot;
+        const float* __restrict__ wt = WS ? a.aux + ((long)og * taps + tap) * (IC4 * 64) : &wl[tap * IC4 * 64];
         for (int q = 0; q < IC4; q++) {
             float4 x4 = *reinterpret_cast<const float4*>(xp + q * 4);
 #pragma unroll
-            for (int o = 0; o < 16; o++) acc[o] += dot4(x4, *reinterpret_cast<const float4*>(wt + (long)o * a.Ktot + q * 4));
+            for (int o = 0; o < 16; o++) acc[o] += dot4(x4, *reinterpret_cast<const float4*>(wt + (q * 16 + o) * 4));
         }
     }
     int y = y0 + ty, x = x0 + tx;
@@ -212,8 +251,16 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     // OUT<=4: FinalBlock heads; OUT<=12 only with a narrow input (dgrad of the stem).  The 9-channel broadcast-input dgrad of R
     // (IN up to 1024 channels on 16x16 maps) stays on the MFMA kernel: one thread per pixel would leave the chip empty.
     if ((a.Cout <= 4 && a.src[0].C >= 16) || (a.Cout <= 12 && a.src[0].C >= 16 && a.src[0].C <= 32)) {
-        if (a.Cout <= 4) hipLaunchKernelGGL((k_conv_thin_out<4>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_conv_thin_out<12>), grid, dim3(256), 0, st, a);
+        const int CO = a.Cout <= 3 ? 3 : (a.Cout <= 4 ? 4 : 12), chunks = cdiv(a.src[0].C, CK);
+        const int n4 = chunks * a.KS * a.KS * 4 * CO;
+        if (a.aux && (long)n4 * 16 <= CONV_AUX_BYTES) {
+            hipLaunchKernelGGL(k_thin_compact_out, dim3(cdiv(n4, 256)), dim3(256), 0, st, a, CO, chunks);
+            if (CO == 3) hipLaunchKernelGGL((k_conv_thin_out<3, true>), grid, dim3(256), 0, st, a);
+            else if (CO == 4) hipLaunchKernelGGL((k_conv_thin_out<4, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_thin_out<12, true>), grid, dim3(256), 0, st, a);
+        } else if (CO == 3) hipLaunchKernelGGL((k_conv_thin_out<3, false>), grid, dim3(256), 0, st, a);
+        else if (CO == 4) hipLaunchKernelGGL((k_conv_thin_out<4, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_thin_out<12, false>), grid, dim3(256), 0, st, a);
         g_last_conv_kernel = CK_THIN_OUT;
         return 1;
     }
@@ -223,8 +270,12 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
         int groups = cdiv(a.Cout, 16);
         if (groups * 16 > a.Cout_pad || (long)a.N * groups > 65535) return 0;
         grid.z = a.N * groups;
-        if (a.Ktot == 16) hipLaunchKernelGGL((k_conv_thin_in<4, 3>), grid, dim3(256), 0, st, a, groups);
-        else hipLaunchKernelGGL((k_conv_thin_in<8, 1>), grid, dim3(256), 0, st, a, groups);
+        const int IC4 = (a.src[0].C + 3) >> 2, n4 = groups * a.KS * a.KS * IC4 * 16;
+        if (a.aux && (long)n4 * 16 <= CONV_AUX_BYTES) {
+            hipLaunchKernelGGL(k_thin_compact_in, dim3(cdiv(n4, 256)), dim3(256), 0, st, a, IC4, groups);
+            hipLaunchKernelGGL((k_conv_thin_in<4, 3, 3, true>), grid, dim3(256), 0, st, a, groups);
+        } else if (a.src[0].C <= 4) hipLaunchKernelGGL((k_conv_thin_in<4, 3, 1, false>), grid, dim3(256), 0, st, a, groups);
+        else hipLaunchKernelGGL((k_conv_thin_in<4, 3, 3, false>), grid, dim3(256), 0, st, a, groups);
         g_last_conv_kernel = CK_THIN_IN;
         return 1;
     }

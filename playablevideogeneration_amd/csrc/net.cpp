@@ -196,6 +196,7 @@ void build_layers(caddy_ctx* c) {
     c->centroids = PP(c, "centroid_estimator.estimated_centroids");
     c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
+    c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
 }
 }  // namespace
 
@@ -262,7 +263,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     ConvArgs a{};
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
-    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0;
+    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux;
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
     if (recording) {
@@ -288,7 +289,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 ConvArgs d{};
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
-                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0;
+                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux;
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
                 if (!sg[s].bcast) { d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = 1; RUN(timed_conv_fwd(d, dfl)); }
                 else {

@@ -59,7 +59,7 @@ def make_pack(ws, segs, KS, lib):
     return d
 
 
-def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0):
+def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True):
     """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd."""
     g = torch.Generator().manual_seed(seed)
     Cin = sum(c for c, _ in segs)
@@ -105,6 +105,8 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     a.bias = b_d.data_ptr() if bias else None
     a.act = act
     a.precision = precision
+    aux = torch.zeros(128 * 1024 // 4, device=dev)     # CONV_AUX_BYTES scratch (compact weight tables of the thin kernels)
+    a.aux = aux.data_ptr() if use_aux else None
     out_ld = round_up(Cout, 4) + 4
     out = torch.full((N, H, W, out_ld), 9.0, device=dev)
     a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0
@@ -145,6 +147,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, KS
         da.wp, da.Ktot, da.Cout, da.Cout_pad, da.bias, da.act = wpd.data_ptr(), kd, c, cd_pad, None, 0
         da.precision = precision
+        da.aux = aux.data_ptr() if use_aux else None
         gx = torch.ones((N, H, W, round_up(c, 4)), device=dev)      # accumulate on top of ones
         da.out, da.out_sn, da.out_ld, da.accumulate = gx.data_ptr(), H * W * gx.shape[3], gx.shape[3], 1
         assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0

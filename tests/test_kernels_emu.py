@@ -30,6 +30,12 @@ def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)
 
 
+def test_thin_conv_without_aux_scratch():
+    """thin kernels fall back to LDS-staged weights when the caller gives no scratch for the compact weight table"""
+    K.conv_case(load_emu(), "cpu", N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3, use_aux=False)
+    K.conv_case(load_emu(), "cpu", N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, use_aux=False)
+
+
 @pytest.mark.parametrize("precision,tol", [(3, 3e-5), (2, 2e-3)])
 def test_conv_split_bf16(precision, tol):
     """3-way split bf16 MFMA path must be fp32-class accurate; the 2-way split is ~2^-16."""

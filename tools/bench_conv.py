@@ -22,6 +22,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run th
 ]
 SHAPES += [("dgrad lstm0-x 512->64 @32", 8, 32, 32, 512, 64, 3), ("dgrad lstm1-x 1024->256 @16", 8, 16, 16, 1024, 256, 3), ("same2 144->128 @32", 8, 32, 32, 144, 128, 3),
            ("stem 3->16 @256x128f", 128, 256, 256, 3, 16, 3), ("stem 3->16 @256x8f", 8, 256, 256, 3, 16, 3), ("final 64->3 k3 @128", 8, 128, 128, 64, 3, 3),
+           ("fdgrad 3->32 k7 @256", 8, 256, 256, 3, 32, 7), ("fdgrad 3->64 k3 @128", 8, 128, 128, 3, 64, 3), ("fdgrad 3->128 k3 @64", 8, 64, 64, 3, 128, 3),
+           ("final 128->3 k3 @64", 8, 64, 64, 128, 3, 3), ("sdgrad 16->3 k7 @256", 8, 256, 256, 16, 3, 7),
            ("A res0 64->128 @32x128f", 128, 32, 32, 64, 128, 3), ("A res1 128->128 @16x128f", 128, 16, 16, 128, 128, 3), ("E 32->64 @64x128f", 128, 64, 64, 32, 64, 3)]
 for name, N, H, W, Cin, Cout, KS in SHAPES:
     if ONLY and ONLY not in name:
@@ -38,6 +40,8 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     a.nsrc, a.N, a.H, a.W, a.KS, a.wp, a.Ktot, a.Cout, a.Cout_pad = 1, N, H, W, KS, wp.data_ptr(), Kt, Cout, cp
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out.shape[3], out.shape[3]
     a.accumulate = 1 if name.startswith('dgrad') else 0
+    aux = torch.zeros(128 * 1024 // 4, device='cuda')
+    a.aux = aux.data_ptr()
     dy = torch.randn(N, H, W, round_up(Cout, 4), device="cuda")
     dwp = torch.zeros_like(wp)
     wa = WgradArgs()
