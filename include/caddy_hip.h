@@ -147,7 +147,7 @@ int caddy_k_pack_fwd(const struct PackDesc* d, float* wp, void* stream);
 int caddy_k_pack_dgrad(const struct PackDesc* d, int seg, float* wpd, int Cd_pad, int Kd, void* stream);
 int caddy_k_unpack_wgrad(const struct PackDesc* d, const float* dwp, void* stream);
 int caddy_k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale, void* stream);
-/* (pointwise kernels: caddy_k_copy, caddy_k_pool2[_bwd], caddy_k_up2[_bwd], caddy_k_stats, caddy_k_bn_finalize, caddy_k_bn_apply,
+/* (pointwise kernels: caddy_k_copy, caddy_k_pool2[_bwd], caddy_k_up2[_bwd], caddy_k_stats, caddy_k_bn_finalize, caddy_k_bn_stats_finalize, caddy_k_bn_apply,
  *  caddy_k_bn_bwd_reduce, caddy_k_bn_bwd_apply, caddy_k_act_bwd_add, caddy_k_lstm_fwd, caddy_k_lstm_bwd, caddy_k_tanh_bwd,
  *  caddy_k_attn_mul[_bwd], caddy_k_gap[_bwd], caddy_k_colsum, caddy_k_spatial_sum, caddy_k_nchw_to_nhwc, caddy_k_nhwc_to_nchw,
  *  caddy_k_batch_sum -- see csrc/capi_kernels.cpp for the exact signatures) */

@@ -26,6 +26,18 @@ int caddy_k_bn_finalize(const double* sums, long count, const float* gamma, cons
                         float* mean, float* invstd, float* scale, float* shift, void* s) {
     return pw_bn_finalize(sums, count, gamma, beta, rmean, rvar, C, training, mean, invstd, scale, shift, ST(s));
 }
+int caddy_k_bn_stats_finalize(const TV* x, double* sums, double* scratch, const float* gamma, const float* beta, float* rmean, float* rvar,
+                              float* mean, float* invstd, float* scale, float* shift, void* s) {
+    return pw_bn_stats_finalize(*x, sums, scratch, gamma, beta, rmean, rvar, mean, invstd, scale, shift, ST(s));
+}
+int caddy_k_bn_small_fwd(const TV* x, const float* gamma, const float* beta, float* rmean, float* rvar, float* mean, float* invstd, float* scale, float* shift,
+                         const TV* x2, int act, const TV* out, void* s) {
+    return pw_bn_small_fwd(*x, gamma, beta, rmean, rvar, mean, invstd, scale, shift, x2, act, *out, ST(s));
+}
+int caddy_k_bn_small_bwd(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const TV* dx,
+                         float* dgamma, float* dbeta, const TV* dres, void* s) {
+    return pw_bn_small_bwd(*dout, outm, *x, mean, invstd, gamma, *dx, dgamma, dbeta, dres, ST(s));
+}
 int caddy_k_bn_apply(const TV* x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV* out, void* s) {
     return pw_bn_apply(*x, scale, shift, x2, scale2, shift2, act, *out, ST(s));
 }

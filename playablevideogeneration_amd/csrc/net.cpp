@@ -235,6 +235,18 @@ int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     prof_recs.push_back(r);
     return rc;
 }
+void caddy_ctx::ensure_side() {
+    if (!use_side || side) return;
+    static const bool off = getenv("CADDY_SIDE_STREAM") && atoi(getenv("CADDY_SIDE_STREAM")) == 0;
+    if (off) { use_side = false; return; }
+    // lowest priority: weight-gradient workgroups fill the compute units the BPTT chain leaves idle (R's small feature maps,
+    // point-wise kernels) instead of competing with it
+    static const bool prio = !(getenv("CADDY_SIDE_PRIORITY") && atoi(getenv("CADDY_SIDE_PRIORITY")) == 0);
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (prio) hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
+    else hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+}
 hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the main stream
     if (!use_side || !side) return stream;
     hipEvent_t e = sev();
@@ -317,31 +329,48 @@ T4 caddy_ctx::up2(const T4& x) {
 }
 
 struct BNStash { float *mean, *invstd, *scale, *shift; double* sums; };
-static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
+static BNStash bn_stash(caddy_ctx* c, BNL& bn) {
     BNStash s; float* f = c->falloc(4 * (size_t)round_up(bn.C, 4));
     int cp = round_up(bn.C, 4);
     c->dbg.push_back(T4{f, f, 1, 1, 1, 4 * cp, 4 * cp, 4 * cp});
     s.mean = f; s.invstd = f + cp; s.scale = f + 2 * cp; s.shift = f + 3 * cp; s.sums = c->dalloc(2 * (size_t)bn.C);
+    return s;
+}
+static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
+    BNStash s = bn_stash(c, bn);
     bool dry = c->dry;
     if (c->training) {
-        if (!dry) c->ck(pw_stats(dv(x), s.sums, c->red_scratch, c->stream), "pw_stats");
+        if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, bn.rmean, bn.rvar, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
         if (!dry) bn.calls++;
-    }
-    if (!dry) c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, c->training ? 1 : 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
+    } else if (!dry) c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
     return s;
 }
 T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into) {
     T4 out = into ? *into : alloc(x.N, x.H, x.W, x.C);
-    BNStash s1 = bn_forward(this, x, bn), s2{};
-    if (x2 && bn2) s2 = bn_forward(this, *x2, *bn2);
+    static const bool no_small = getenv("CADDY_BN_SMALL") && atoi(getenv("CADDY_BN_SMALL")) == 0;      // A/B aid
+    const bool small = training && !bn2 && !no_small && pw_bn_small_pays(dv(x));      // one-launch path for R's small maps
     TV x2v{}; if (x2) x2v = dv(*x2);
-    RUN(pw_bn_apply(dv(x), s1.scale, s1.shift, x2 ? &x2v : nullptr, bn2 ? s2.scale : nullptr, bn2 ? s2.shift : nullptr, actf ? 1 : 0, dv(out), stream));
+    BNStash s1{}, s2{};
+    if (small) {
+        s1 = bn_stash(this, bn);
+        RUN(pw_bn_small_fwd(dv(x), bn.gamma, bn.beta, bn.rmean, bn.rvar, s1.mean, s1.invstd, s1.scale, s1.shift, x2 ? &x2v : nullptr, actf ? 1 : 0, dv(out), stream));
+        if (!dry) bn.calls++;
+    } else {
+        s1 = bn_forward(this, x, bn);
+        if (x2 && bn2) s2 = bn_forward(this, *x2, *bn2);
+        RUN(pw_bn_apply(dv(x), s1.scale, s1.shift, x2 ? &x2v : nullptr, bn2 ? s2.scale : nullptr, bn2 ? s2.shift : nullptr, actf ? 1 : 0, dv(out), stream));
+    }
     if (recording) {
         T4 x2c{}; if (x2) x2c = *x2;
         bool has2 = x2 != nullptr; BNL* b1 = &bn; BNL* b2 = bn2;
         tape.push_back([=]() {
             TV om = dv(out);
             const TV* omp = actf ? &om : nullptr;
+            if (small) {
+                TV dres{}; if (has2) dres = gv(x2c);
+                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, stream));
+                return;
+            }
             RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream));   // sums assigned; param grads fused
             RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, stream));
             if (has2 && b2) {
@@ -624,25 +653,13 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     bool dry = c->dry;
     hipStream_t st = c->stream;
     if (!dry) {
-        hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);
-        hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
+        hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);   // (zero-filling on the side stream during the forward pass was measured: no gain, the step is throughput-bound)
+            hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
         for (ConvL* L : c->convs) hipMemsetAsync(L->dwp, 0, L->wp_floats * 4, st);
         for (int i = 0; i < 3; i++) { hipMemsetAsync(c->lstm[i].ih.g, 0, c->lstm[i].ih.sn * 4, st); hipMemsetAsync(c->lstm[i].ic.g, 0, c->lstm[i].ic.sn * 4, st); }
         hipMemsetAsync(c->loss_acc, 0, sizeof(double) * LOSS_SLOTS, st);
     }
-    if (c->use_side && !c->side && !dry) {
-        static const bool off = getenv("CADDY_SIDE_STREAM") && atoi(getenv("CADDY_SIDE_STREAM")) == 0;
-        if (off) c->use_side = false;
-        else {
-            // lowest priority: weight-gradient workgroups fill the compute units the BPTT chain leaves idle (R's small feature maps,
-            // point-wise kernels) instead of competing with it
-            static const bool prio = !(getenv("CADDY_SIDE_PRIORITY") && atoi(getenv("CADDY_SIDE_PRIORITY")) == 0);
-            int least = 0, greatest = 0;
-            hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (prio) hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
-            else hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-        }
-    }
+    if (!dry) c->ensure_side();
     c->sev_used = 0;
     LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda};
     double nr[3];

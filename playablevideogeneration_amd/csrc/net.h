@@ -99,6 +99,7 @@ struct caddy_ctx {
     std::vector<hipEvent_t> sev_pool; size_t sev_used = 0;
     hipEvent_t sev() { if (sev_used == sev_pool.size()) { hipEvent_t e; hipEventCreate(&e); sev_pool.push_back(e); } return sev_pool[sev_used++]; }
     hipStream_t wgrad_stream();
+    void ensure_side();
 
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);

@@ -12,6 +12,14 @@ int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st);
 int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st);
 int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
                    float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+int pw_bn_stats_finalize(const TV& x, double* sums, double* scratch, const float* gamma, const float* beta, float* rmean, float* rvar,
+                         float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+bool pw_bn_small_ok(const TV& x);
+bool pw_bn_small_pays(const TV& x);
+int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* rmean, float* rvar, float* mean, float* invstd, float* scale, float* shift,
+                    const TV* x2, int act, const TV& out, hipStream_t st);
+int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
+                    float* dgamma, float* dbeta, const TV* dres, hipStream_t st);
 int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st);
 int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st);
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,

@@ -223,20 +223,32 @@ struct FAttnMul {  // attentive = state * sigmoid(x[..., C-1])  (representation_
         if (c == 0 && att.p) att.p[tv_off(att, HW, q)] = a;
     }
 };
-struct FAttnMulBwd {  // per pixel (C4 == 1)
-    TV x, dout, datt, dx; int HW;
-    __device__ void operator()(long q, int) const {
-        const float* xp = x.p + tv_off(x, HW, q);
-        const float* gp = dout.p + tv_off(dout, HW, q);
-        float* dp = dx.p + tv_off(dx, HW, q);
-        int Cs = x.C - 1;
-        float a = sigm(xp[Cs]);
-        float dot = 0.f;
-        for (int c = 0; c < Cs; c++) { float g = gp[c]; dot += g * xp[c]; dp[c] += g * a; }
-        if (datt.p) dot += datt.p[tv_off(datt, HW, q)];
-        dp[Cs] += dot * a * (1.f - a);
+// attention gate backward (action_network.py: x[:, :-1] * sigmoid(x[:, -1:])): 16 lanes per pixel, each a float4 of channels
+// (coalesced), the per-pixel dot product d_att = sum_c dout[c] * x[c] reduced with width-16 shuffles.
+struct AttnBwdArgs { TV x, dout, datt, dx; int HW; long npix; };
+__global__ __launch_bounds__(256) void k_attn_mul_bwd(AttnBwdArgs a) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    const long q = gid >> 4;
+    const int j = (int)(gid & 15);
+    const bool ok = q < a.npix;
+    const int Cs = a.x.C - 1;
+    float dot = 0.f, att = 0.f;
+    const float *xp = nullptr, *gp = nullptr; float* dp = nullptr;
+    if (ok) {
+        xp = a.x.p + tv_off(a.x, a.HW, q); gp = a.dout.p + tv_off(a.dout, a.HW, q); dp = a.dx.p + tv_off(a.dx, a.HW, q);
+        att = sigm(xp[Cs]);
+        for (int c = j * 4; c < Cs; c += 64) {
+            float4 g = ld4(gp + c, c, Cs), xv = ld4(xp + c, c, Cs);
+            dot += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
+            st4(dp + c, c, Cs, ld4(dp + c, c, Cs) + att * g);
+        }
     }
-};
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (ok && j == 0) {
+        if (a.datt.p) dot += a.datt.p[tv_off(a.datt, a.HW, q)];
+        dp[Cs] += dot * att * (1.f - att);
+    }
+}
 struct FGapBwd {
     TV dx; const float* dout; int HW; float inv;
     __device__ void operator()(long q, int c) const {
@@ -325,9 +337,32 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums, float* dgamma, float* dbeta) {
+// optional BatchNorm finalisation fused into the fold of the forward statistics (saves one launch per BatchNorm call)
+struct BnFin { double count; const float *gamma, *beta; float *rmean, *rvar; int C; float momentum, eps; float *mean, *invstd, *scale, *shift; };
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, double sum, double sq, int training) {
+    float m, is;
+    if (training) {
+        double mu = sum / f.count;
+        double var = sq / f.count - mu * mu;
+        if (var < 0) var = 0;
+        m = (float)mu;
+        is = (float)(1.0 / sqrt(var + (double)f.eps));
+        double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+        f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * m;
+        f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unb;
+    } else {
+        m = f.rmean[c];
+        is = 1.f / sqrtf(f.rvar[c] + f.eps);
+    }
+    float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    f.mean[c] = m; f.invstd[c] = is; f.scale[c] = g * is; f.shift[c] = b - m * g * is;
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums, float* dgamma, float* dbeta, BnFin fin) {
     // sums[i] = sum_b partials[b][i] (assign: no memset needed); one wave per output index (4 per workgroup), lanes stride over blocks.
     // Optionally fused BatchNorm parameter gradients: dbeta[c] += sums[2c], dgamma[c] += sums[2c+1].
+    __shared__ double sh[4];
     int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     double s = 0.0;
     if (i < n2c) for (int b = lane; b < nb; b += 64) s += partials[(long)b * n2c + i];
@@ -336,10 +371,16 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* partials, in
         sums[i] = s;
         if (dgamma) { if (i & 1) dgamma[i >> 1] += (float)s; else dbeta[i >> 1] += (float)s; }
     }
+    if (fin.mean) {                                   // workgroup b owns channels 2b, 2b+1 (indices 4b .. 4b+3)
+        if (lane == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        int c = blockIdx.x * 2 + threadIdx.x;
+        if (threadIdx.x < 2 && c < fin.C) bn_finalize_channel(fin, c, sh[2 * threadIdx.x], sh[2 * threadIdx.x + 1], 1);
+    }
 }
 
 template <int MODE>
-int run_reduce(RedArgs a, hipStream_t st) {
+int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
     int HW = a.x.H * a.x.W;
     long P = (long)a.x.N * HW;
     if ((a.x.C + 3) / 4 > 256) return -1;
@@ -356,32 +397,112 @@ int run_reduce(RedArgs a, hipStream_t st) {
         a.pix_per_block = (int)ppb;
         int nb = cdiv(P, ppb);
         hipLaunchKernelGGL((k_reduce<MODE>), dim3(nb), dim3(256), 0, st, a);
-        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums, a.dgamma, a.dbeta);
+        BnFin nofin{}; nofin.mean = nullptr;
+        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums, a.dgamma, a.dbeta, fin ? *fin : nofin);
     }
     return 0;
 }
 
 // BN statistics -> (mean, invstd, scale, shift) + running-stat update (nn.BatchNorm2d train / eval semantics)
-__global__ void k_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
-                              int training, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float m, is;
-    if (training) {
-        double mu = sums[2 * c] / count;
-        double var = sums[2 * c + 1] / count - mu * mu;
-        if (var < 0) var = 0;
-        m = (float)mu;
-        is = (float)(1.0 / sqrt(var + (double)eps));
-        double unb = count > 1 ? var * count / (count - 1) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    } else {
-        m = rmean[c];
-        is = 1.f / sqrtf(rvar[c] + eps);
+// ---- fused BatchNorm for small feature maps (R's 16x16 / 32x32 maps: <= 8192 pixels) ------------------------------------------
+// The generic path is 4 launches forward (partial sums, fold+finalise, apply) and 3-4 backward, each 5-8 us of pure launch
+// latency on these sizes.  Here ONE workgroup owns four channels and ALL pixels: every thread keeps its <= 32 pixels (float4) in
+// registers, the block reduces in fp64 (shuffles + LDS), finalises, and applies from registers -- one launch, one read of x.
+constexpr int BNS_PPT = 32;                  // pixels per thread -> up to 256 * 32 = 8192 pixels
+struct BnSmallFwd { TV x, x2, out; int has2, act; BnFin fin; };
+struct BnSmallBwd { TV dout, outm, x, dx, dres; int act, has_res; const float *mean, *invstd, *gamma; float *dgamma, *dbeta; };
+
+__device__ __forceinline__ void block_reduce8(double* s, double* sh, int tid) {   // result valid for all threads in sh[0..7]
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        for (int o = 32; o > 0; o >>= 1) s[e] += __shfl_xor(s[e], o);
+    if ((tid & 63) == 0) for (int e = 0; e < 8; e++) sh[(tid >> 6) * 8 + e] = s[e];
+    __syncthreads();
+    if (tid < 8) sh[32 + tid] = sh[tid] + sh[8 + tid] + sh[16 + tid] + sh[24 + tid];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_bn_small_fwd(BnSmallFwd a) {
+    __shared__ double sh[40];
+    __shared__ float ss[8];
+    const int tid = threadIdx.x, c = blockIdx.x * 4, C = a.x.C, HW = a.x.H * a.x.W;
+    const long P = (long)a.x.N * HW;
+    float4 v[BNS_PPT];
+    double s[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < BNS_PPT; i++) {
+        long q = tid + 256L * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < P) {
+            v[i] = ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C);
+            s[0] += v[i].x; s[1] += v[i].y; s[2] += v[i].z; s[3] += v[i].w;
+            s[4] += (double)v[i].x * v[i].x; s[5] += (double)v[i].y * v[i].y; s[6] += (double)v[i].z * v[i].z; s[7] += (double)v[i].w * v[i].w;
+        }
     }
-    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    mean[c] = m; invstd[c] = is; scale[c] = g * is; shift[c] = b - m * g * is;
+    block_reduce8(s, sh, tid);
+    if (tid < 4 && c + tid < C) {
+        bn_finalize_channel(a.fin, c + tid, sh[32 + tid], sh[36 + tid], 1);
+        ss[tid] = a.fin.scale[c + tid]; ss[4 + tid] = a.fin.shift[c + tid];
+    }
+    __syncthreads();
+    const float4 sc = make_float4(ss[0], ss[1], ss[2], ss[3]), sf = make_float4(ss[4], ss[5], ss[6], ss[7]);
+#pragma unroll
+    for (int i = 0; i < BNS_PPT; i++) {
+        long q = tid + 256L * i;
+        if (q < P) {
+            float4 o = v[i] * sc + sf;
+            if (a.has2) o = o + ld4(a.x2.p + tv_off(a.x2, HW, q) + c, c, C);
+            if (a.act) o = lrelu4(o);
+            st4(a.out.p + tv_off(a.out, HW, q) + c, c, C, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_small_bwd(BnSmallBwd a) {
+    __shared__ double sh[40];
+    const int tid = threadIdx.x, c = blockIdx.x * 4, C = a.x.C, HW = a.x.H * a.x.W;
+    const long P = (long)a.x.N * HW;
+    const float4 mu = ld4(a.mean + c, c, C), is = ld4(a.invstd + c, c, C), ga = ld4(a.gamma + c, c, C);
+    float4 dz[BNS_PPT];
+    double s[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < BNS_PPT; i++) {
+        long q = tid + 256L * i;
+        dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < P) {
+            dz[i] = ld4(a.dout.p + tv_off(a.dout, HW, q) + c, c, C);
+            if (a.act) dz[i] = dz[i] * lmask4(ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
+            float4 xh = (ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C) - mu) * is;
+            s[0] += dz[i].x; s[1] += dz[i].y; s[2] += dz[i].z; s[3] += dz[i].w;
+            s[4] += (double)dz[i].x * xh.x; s[5] += (double)dz[i].y * xh.y; s[6] += (double)dz[i].z * xh.z; s[7] += (double)dz[i].w * xh.w;
+        }
+    }
+    block_reduce8(s, sh, tid);
+    if (tid < 4 && c + tid < C) { a.dbeta[c + tid] += (float)sh[32 + tid]; a.dgamma[c + tid] += (float)sh[36 + tid]; }
+    const double invM = 1.0 / (double)P;
+    const float4 s1 = make_float4((float)(sh[32] * invM), (float)(sh[33] * invM), (float)(sh[34] * invM), (float)(sh[35] * invM));
+    const float4 s2 = make_float4((float)(sh[36] * invM), (float)(sh[37] * invM), (float)(sh[38] * invM), (float)(sh[39] * invM));
+#pragma unroll
+    for (int i = 0; i < BNS_PPT; i++) {
+        long q = tid + 256L * i;
+        if (q < P) {
+            float4 xh = (ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C) - mu) * is;
+            float4 g = ga * is * (dz[i] - s1 - xh * s2);
+            float* o = a.dx.p + tv_off(a.dx, HW, q) + c;
+            st4(o, c, C, ld4(o, c, C) + g);
+            if (a.has_res) { float* r = a.dres.p + tv_off(a.dres, HW, q) + c; st4(r, c, C, ld4(r, c, C) + dz[i]); }
+        }
+    }
+}
+
+__global__ void k_bn_finalize(const double* sums, BnFin f, int training) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= f.C) return;
+    bn_finalize_channel(f, c, training ? sums[2 * c] : 0.0, training ? sums[2 * c + 1] : 0.0, training);
 }
 __global__ void k_bn_param_grad(const double* sums, int C, float* dgamma, float* dbeta) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,9 +602,42 @@ int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map
 int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
 int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
 int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch; return run_reduce<0>(a, st); }
+static BnFin make_fin(long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, float* mean, float* invstd, float* scale, float* shift) {
+    BnFin f; f.count = (double)count; f.gamma = gamma; f.beta = beta; f.rmean = rmean; f.rvar = rvar; f.C = C; f.momentum = 0.1f; f.eps = 1e-5f;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    return f;
+}
 int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
                    float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, (double)count, gamma, beta, rmean, rvar, C, training, 0.1f, 1e-5f, mean, invstd, scale, shift);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, make_fin(count, gamma, beta, rmean, rvar, C, mean, invstd, scale, shift), training);
+    return 0;
+}
+// train-mode statistics + finalisation: k_reduce<0> (per-block partials) -> k_sum_partials with the finalisation fused
+int pw_bn_stats_finalize(const TV& x, double* sums, double* scratch, const float* gamma, const float* beta, float* rmean, float* rvar,
+                         float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+    if (!scratch) return -1;
+    RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch;
+    BnFin f = make_fin((long)x.N * x.H * x.W, gamma, beta, rmean, rvar, x.C, mean, invstd, scale, shift);
+    return run_reduce<0>(a, st, &f);
+}
+// measured on the MI355X: one workgroup per 4 channels streams at ~13 GB/s (per-CU memory parallelism), so the one-launch path only
+// wins below ~1024 pixels (Breakout's 13x10 maps, unit tests); BAIR's smallest map (16x16x8) stays on the multi-workgroup path
+bool pw_bn_small_pays(const TV& x) { return (long)x.N * x.H * x.W <= 1024 && x.C >= 4; }
+bool pw_bn_small_ok(const TV& x) { return (long)x.N * x.H * x.W <= 256L * BNS_PPT && x.C >= 4; }       // what the kernels can do
+// train-mode BatchNorm forward in one launch: statistics, running-stat update, (mean, invstd, scale, shift) and out = act(bn(x) [+ x2])
+int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* rmean, float* rvar, float* mean, float* invstd, float* scale, float* shift,
+                    const TV* x2, int act, const TV& out, hipStream_t st) {
+    if (!pw_bn_small_ok(x)) return -1;
+    BnSmallFwd a{x, x2 ? *x2 : x, out, x2 ? 1 : 0, act, make_fin((long)x.N * x.H * x.W, gamma, beta, rmean, rvar, x.C, mean, invstd, scale, shift)};
+    hipLaunchKernelGGL(k_bn_small_fwd, dim3(cdiv(x.C, 4)), dim3(256), 0, st, a);
+    return 0;
+}
+// BatchNorm backward in one launch: dx += ..., dgamma/dbeta +=, and (optional) dres += dout * act'(out) for the residual input
+int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
+                    float* dgamma, float* dbeta, const TV* dres, hipStream_t st) {
+    if (!pw_bn_small_ok(x)) return -1;
+    BnSmallBwd a{dout, outm ? *outm : dout, x, dx, dres ? *dres : dx, outm ? 1 : 0, dres ? 1 : 0, mean, invstd, gamma, dgamma, dbeta};
+    hipLaunchKernelGGL(k_bn_small_bwd, dim3(cdiv(x.C, 4)), dim3(256), 0, st, a);
     return 0;
 }
 int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st) {
@@ -509,7 +663,13 @@ int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, co
 }
 int pw_tanh_bwd(const TV& dy, const TV& y, const TV& dz, hipStream_t st) { return run_map((long)y.N * y.H * y.W, y.C, FTanhBwd{dy, y, dz, y.H * y.W}, st); }
 int pw_attn_mul(const TV& x, const TV& out, const TV& att, hipStream_t st) { return run_map((long)x.N * x.H * x.W, out.C, FAttnMul{x, out, att, x.H * x.W}, st); }
-int pw_attn_mul_bwd(const TV& x, const TV& dout, const TV& datt, const TV& dx, hipStream_t st) { return run_map((long)x.N * x.H * x.W, 1, FAttnMulBwd{x, dout, datt, dx, x.H * x.W}, st); }
+int pw_attn_mul_bwd(const TV& x, const TV& dout, const TV& datt, const TV& dx, hipStream_t st) {
+    long npix = (long)x.N * x.H * x.W;
+    if (npix <= 0) return 0;
+    if ((x.ld & 3) || (dout.ld & 3) || (dx.ld & 3) || (x.sn & 3) || (dout.sn & 3) || (dx.sn & 3)) return -1;
+    hipLaunchKernelGGL(k_attn_mul_bwd, dim3((unsigned)cdiv(npix * 16, 256)), dim3(256), 0, st, AttnBwdArgs{x, dout, datt, dx, x.H * x.W, npix});
+    return 0;
+}
 int pw_gap(const TV& x, float* out, hipStream_t st) {
     hipMemsetAsync(out, 0, sizeof(float) * (size_t)x.N * x.C, st);
     RedArgs a{}; a.x = x; a.outf = out; a.out_sn = x.C; a.scale = 1.f / (float)(x.H * x.W);

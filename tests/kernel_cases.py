@@ -194,8 +194,9 @@ def pool_up_case(lib, dev, N=2, Cc=6, H=4, W=6, seed=0):
     assert (to_nchw(gx, Cc) - 1 - x.grad).abs().max() < 2e-6
 
 
-def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed=0):
-    """out = lrelu(BN(x) + second) with second in {None, 'plain', 'bn'}; forward, running stats, backward."""
+def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed=0, fused=False):
+    """out = lrelu(BN(x) + second) with second in {None, 'plain', 'bn'}; forward, running stats, backward.
+    fused=True: the one-launch small-map kernels (k_bn_small_fwd / k_bn_small_bwd) instead of the generic multi-launch path."""
     g = torch.Generator().manual_seed(seed)
     st = stream(dev)
     x = (_rand(g, N, Cc, H, W) * 2 + 0.5).requires_grad_(True)
@@ -220,14 +221,41 @@ def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed
         sums = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
         if training and seed % 2 == 0:
             assert lib.caddy_k_stats(C.byref(tv(xb, Cc)), P(sums), st) == 0
-        elif training:                          # atomics-free variant: per-block partials + second-stage sum
-            scratch = torch.zeros(512 * 2 * Cc, dtype=torch.float64, device=dev)
-            assert lib.caddy_k_stats_partials(C.byref(tv(xb, Cc)), P(sums), P(scratch), st) == 0
         o = [torch.zeros(Cc, device=dev) for _ in range(4)]
         gmd, btd, rmd, rvd = gm.detach().to(dev), bt.detach().to(dev), rmean.to(dev), rvar.to(dev)
+        if training and seed % 2 == 1:          # the driver's path: per-block partials + fold with the finalisation fused (no atomics)
+            scratch = torch.zeros(512 * 2 * Cc, dtype=torch.float64, device=dev)
+            assert lib.caddy_k_bn_stats_finalize(C.byref(tv(xb, Cc)), P(sums), P(scratch), P(gmd), P(btd), P(rmd), P(rvd), *[P(t) for t in o], st) == 0
+            return xb, o, gmd, rmd, rvd
         assert lib.caddy_k_bn_finalize(P(sums), C.c_long(M), P(gmd), P(btd), P(rmd), P(rvd), Cc, training, *[P(t) for t in o], st) == 0
         return xb, o, gmd, rmd, rvd
 
+    if fused:
+        assert training and second != "bn"
+        xb = nhwc(x.detach(), dev=dev)
+        mean, invstd, scale, shift = [torch.zeros(Cc, device=dev) for _ in range(4)]
+        gmd, btd, rmd, rvd = gam.detach().to(dev), bet.detach().to(dev), rm.to(dev), rv.to(dev)
+        x2b = nhwc(x2.detach(), dev=dev) if second == "plain" else None
+        out = torch.zeros_like(xb)
+        x2tv = tv(x2b, Cc) if x2b is not None else None
+        assert lib.caddy_k_bn_small_fwd(C.byref(tv(xb, Cc)), P(gmd), P(btd), P(rmd), P(rvd), P(mean), P(invstd), P(scale), P(shift),
+                                        C.byref(x2tv) if x2tv else None, act, C.byref(tv(out, Cc)), st) == 0
+        sync(dev)
+        assert (to_nchw(out, Cc) - y.detach()).abs().max() < 2e-6
+        assert (rmd.cpu() - rm_r).abs().max() < 1e-6 and (rvd.cpu() - rv_r).abs().max() < 1e-6
+        dyb = nhwc(dy, dev=dev)
+        dx, dres = torch.ones_like(xb), torch.ones_like(xb)
+        dg, db = torch.ones(Cc, device=dev), torch.ones(Cc, device=dev)
+        dtv = tv(dres, Cc)
+        assert lib.caddy_k_bn_small_bwd(C.byref(tv(dyb, Cc)), C.byref(tv(out, Cc)) if act else None, C.byref(tv(xb, Cc)), P(mean), P(invstd), P(gmd),
+                                        C.byref(tv(dx, Cc)), P(dg), P(db), C.byref(dtv) if second == "plain" else None, st) == 0
+        sync(dev)
+        assert (to_nchw(dx, Cc) - 1 - x.grad).abs().max() < 5e-6 * max(1.0, x.grad.abs().max().item())
+        assert (dg.cpu() - 1 - gam.grad).abs().max() < 2e-5 * max(1.0, gam.grad.abs().max().item())
+        assert (db.cpu() - 1 - bet.grad).abs().max() < 2e-5 * max(1.0, bet.grad.abs().max().item())
+        if second == "plain":
+            assert (to_nchw(dres, Cc) - 1 - x2.grad).abs().max() < 2e-6
+        return
     xb, (mean, invstd, scale, shift), gmd, rmd, rvd = run_bn(x, gam, bet, rm, rv)
     x2b = None
     if second == "bn":

@@ -53,6 +53,12 @@ def test_batchnorm(second, act, training):
     K.bn_case(load_emu(), "cpu", second=second, act=act, training=training, seed=1, N=2, H=9, W=8)
 
 
+@pytest.mark.parametrize("second,act", [(None, 1), (None, 0), ("plain", 1), ("plain", 0)])
+def test_batchnorm_fused_small(second, act):
+    K.bn_case(load_emu(), "cpu", second=second, act=act, training=1, fused=True)
+    K.bn_case(load_emu(), "cpu", second=second, act=act, training=1, fused=True, seed=1, N=2, H=33, W=31, Cc=13)     # > 8 pixels per thread, channel tail
+
+
 def test_lstm_gates():
     K.lstm_case(load_emu(), "cpu")
 

@@ -58,6 +58,12 @@ def test_batchnorm(lib, second, act, training):
     K.bn_case(lib, "cuda", N=4, Cc=65, H=32, W=32, second=second, act=act, training=training, seed=2)
 
 
+@pytest.mark.parametrize("second,act", [(None, 1), (None, 0), ("plain", 1), ("plain", 0)])
+def test_batchnorm_fused_small(lib, second, act):
+    K.bn_case(lib, "cuda", second=second, act=act, training=1, fused=True)
+    K.bn_case(lib, "cuda", second=second, act=act, training=1, fused=True, seed=1, N=2, H=33, W=31, Cc=13)     # > 8 pixels per thread, channel tail
+
+
 def test_lstm_gates(lib):
     K.lstm_case(lib, "cuda")
     K.lstm_case(lib, "cuda", N=4, Cc=128, H=16, W=16, seed=3)
