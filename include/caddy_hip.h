@@ -78,6 +78,14 @@ size_t caddy_workspace_bytes(const caddy_config* cfg);
 caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes);
 void caddy_ctx_destroy(caddy_ctx* ctx);
 int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
+/* Evaluation samplers (evaluation/action_sampler.py:14,63; evaluation/action_variation_sampler.py:14), consumed mid-forward exactly where
+ * model/main_model/model.py:171-173,189-190 call them.  The hook runs stream-ordered on device pointers inside the workspace:
+ *   stage 0 (if provides_samples):    write samples (n, K)    given log_probs (n, K)                      [n = batch * (seq_len - 1)]
+ *   stage 1 (if provides_variations): write variations (n, Da) given sampled_dirs (n, Da) and the final samples (n, K)
+ * hook == NULL clears it.  Affects caddy_forward_full / caddy_forward_pretraining until cleared. */
+typedef void (*caddy_sampler_hook)(const float* log_probs, const float* sampled_dirs, float* samples, float* variations,
+                                   int n, int K, int Da, int stage, void* user);
+int caddy_set_sampler_hook(caddy_ctx* ctx, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations);
 /* Data parallelism (one process per GPU): `hook(ptr, n, user)` must sum the n floats at device pointer `ptr` (inside the
  * workspace) over all ranks, in place, stream-ordered (RCCL all-reduce).  It is called for the centroid-EMA sums
  * (centroid_estimator.py:61-63) during caddy_forward_* and for the K x K joint matrix of the mutual-information loss

@@ -35,6 +35,10 @@ struct SampleCfg {
     const float* variations_in; // optional external variations (evaluation action_variation_sampler)
 };
 typedef void (*allreduce_hook_t)(float* device_ptr, int count, void* user);   // in-place sum over ranks, enqueued on the caller's stream
+// evaluation samplers (evaluation/action_sampler.py:14,63, action_variation_sampler.py:14; model.py:171-190), stream-ordered callbacks on
+// device pointers.  stage 0: write samples (n,K) from log_probs (n,K);  stage 1: write variations (n,Da) from sampled_dirs (n,Da) and samples.
+typedef void (*sampler_hook_t)(const float* log_probs, const float* sampled_dirs, float* samples, float* variations, int n, int K, int Da, int stage, void* user);
+struct SamplerHooks { sampler_hook_t fn; void* user; int action, variation; float *samples_buf, *var_buf; };
 
 struct SmallLossArgs {
     int K, Da, NS, NT;
@@ -49,7 +53,7 @@ struct SmallLossArgs {
 
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st);
 int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
-int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, hipStream_t st);
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, const SamplerHooks* sh, hipStream_t st);
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st);
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st);
 int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st);

@@ -391,11 +391,22 @@ int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream
     hipLaunchKernelGGL(k_head_dirs, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, B, T);
     return 0;
 }
-int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, hipStream_t st) {
+int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, const SamplerHooks* sh, hipStream_t st) {
     if (p.K > 16 || p.Da > 8 || p.K + p.Da > AUX_LD) return -1;
     hipLaunchKernelGGL(k_head_probs, dim3(1), dim3(256), 0, st, h, p, NS, cen_sums);
     if (hook && c.training) hook(cen_sums, p.K * p.Da + p.K, user);
-    hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c, NS, (const float*)cen_sums);
+    SampleCfg c2 = c;
+    if (sh && sh->fn && sh->action) {        // model.py:171-173: an explicit action sampler replaces Gumbel / soft-max sampling
+        sh->fn(h.logp, h.dirs, sh->samples_buf, nullptr, NS, p.K, p.Da, 0, sh->user);
+        c2.mode = 2; c2.samples_in = sh->samples_buf;
+    }
+    hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c2, NS, (const float*)cen_sums);
+    if (sh && sh->fn && sh->variation) {     // model.py:189-190: the variation sampler sees the final samples; re-emit aux / variations with its result
+        sh->fn(h.logp, h.dirs, h.samples, sh->var_buf, NS, p.K, p.Da, 1, sh->user);
+        SampleCfg c3 = c2;
+        c3.mode = 2; c3.samples_in = h.samples; c3.variations_in = sh->var_buf; c3.training = 0;     // centroids already updated above
+        hipLaunchKernelGGL(k_head_sample, dim3(1), dim3(256), 0, st, h, p, c3, NS, (const float*)cen_sums);
+    }
     return 0;
 }
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {

@@ -511,7 +511,16 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     sc = SampleCfg{};
     sc.mode = samples_in ? 2 : (cfg.use_gumbel ? 1 : 0); sc.hard = cfg.hard_gumbel; sc.training = training ? 1 : 0; sc.use_variations = cfg.use_variations;
     sc.tau = tau; sc.alpha = cfg.centroid_alpha; sc.centroids = centroids; sc.samples_in = samples_in; sc.variations_in = variations_in;
-    if (first) { float* cs = falloc(16 * 8 + 16); RUN(head_sample(b, hp, sc, NS, cs, hook, hook_user, stream)); }
+    if (first) {
+        float* cs = falloc(16 * 8 + 16);
+        SamplerHooks sh = samplers;
+        sh.samples_buf = falloc((size_t)NS * K); sh.var_buf = falloc((size_t)NS * Da);       // always allocated: the arena layout must not depend on the hooks
+        if (samples_in) sh.action = 0;
+        if (variations_in) sh.variation = 0;
+        RUN(head_sample(b, hp, sc, NS, cs, hook, hook_user, sh.fn ? &sh : nullptr, stream));
+        if (sh.fn && sh.action) { sc.mode = 2; sc.samples_in = sh.samples_buf; }             // what the backward pass must assume
+        if (sh.fn && sh.variation) sc.variations_in = sh.var_buf;
+    }
     if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tape.push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
@@ -862,6 +871,11 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
+    c->samplers = SamplerHooks{};
+    if (hook && (provides_samples || provides_variations)) { c->samplers.fn = hook; c->samplers.user = user; c->samplers.action = provides_samples; c->samplers.variation = provides_variations; }
+    return 0;
+}
 int caddy_set_allreduce_hook(caddy_ctx* c, void (*hook)(float*, int, void*), void* user, int world_size) {
     c->hook = hook; c->hook_user = user; c->world = world_size > 1 ? world_size : 1;
     return 0;

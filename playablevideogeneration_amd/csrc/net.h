@@ -81,6 +81,7 @@ struct caddy_ctx {
     float *q_prob = nullptr;
     double* loss_acc = nullptr;
     allreduce_hook_t hook = nullptr; void* hook_user = nullptr; int world = 1;   // data-parallel reductions of the K x K MI matrix / centroid sums
+    SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     bool have_forward = false;

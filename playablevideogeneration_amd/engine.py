@@ -47,6 +47,7 @@ def _bind(lib):
     lib.caddy_ctx_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.caddy_ctx_destroy.argtypes = [C.c_void_p]
     lib.caddy_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_set_sampler_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.caddy_set_allreduce_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.caddy_forward_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.caddy_forward_pretraining.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -100,6 +101,30 @@ class Engine:
         self.adam_m = self.adam_v = None
         self.mi_ema = None
         self._keep = []
+
+    def set_samplers(self, action_sampler=None, action_variation_sampler=None, gt_actions: Optional[torch.Tensor] = None):
+        """Evaluation samplers of the reference (model.py:171-190): `action_sampler(log_probs (n,K), gt_actions (n,)) -> (n,K)` and
+        `action_variation_sampler(sampled_dirs (n,Da), samples (n,K)) -> (n,Da)`, called mid-forward on views of the workspace.
+        Pass None for both to clear."""
+        if action_sampler is None and action_variation_sampler is None:
+            self._sampler_keepalive = None
+            self._check(self.lib.caddy_set_sampler_hook(self.ctx, None, None, 0, 0))
+            return
+        base = self._ws_raw.data_ptr()
+
+        def view(ptr, n, cols):
+            off = ptr - base
+            return self._ws_raw[off:off + 4 * n * cols].view(torch.float32).view(n, cols)
+
+        def _hook(logp, dirs, samples, variations, n, K, Da, stage, _user):
+            if stage == 0:
+                view(samples, n, K).copy_(action_sampler(view(logp, n, K), gt_actions).to(torch.float32))
+            else:
+                view(variations, n, Da).copy_(action_variation_sampler(view(dirs, n, Da), view(samples, n, K)).to(torch.float32))
+
+        self._sampler_keepalive = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)(_hook)
+        self._check(self.lib.caddy_set_sampler_hook(self.ctx, C.cast(self._sampler_keepalive, C.c_void_p), None,
+                                                    int(action_sampler is not None), int(action_variation_sampler is not None)))
 
     def enable_data_parallel(self, process_group=None, force=False):
         """Register the all-reduce hook (torch.distributed: RCCL on the MI355X, gloo in the CPU tests) for the small

@@ -195,18 +195,21 @@ class Model(nn.Module):
             raise Exception("To forward the full model specify a number of ground truth observations > 0")
         if self._forbid_gt_actions:
             raise Exception("The use of ground truth actions during training is not supported by the selected model")
-        if action_sampler is not None or action_variation_sampler is not None:
-            raise NotImplementedError("evaluation action samplers (evaluation/action_sampler.py) are a 'next' row (SURVEY 8f-3)")
         observations = batch_tuple[0]
         B, T = observations.shape[:2]
         eng = self.engine(B, T)
+        gt_actions = None
+        if action_sampler is not None:                       # model.py:172-173: actions[:, :-1].reshape((-1,))
+            gt_actions = batch_tuple[1][:, :-1].reshape((-1,)).to(self._flat.device)
+        eng.set_samplers(action_sampler, action_variation_sampler, gt_actions)
         if gumbel_temperature is not None:
             self.current_temperature = gumbel_temperature
         d = self.dims
         Da, K, n = d["action_dim"], d["actions"], T - 1
         # RNG draws in the reference's order; all independent of data, so they can be drawn up front
         noise = {"eps_states": torch.randn((B * T, Da), dtype=torch.float32), "eps_dirs": torch.randn((B, n, Da), dtype=torch.float32).reshape(B * n, Da)}
-        noise["gumbel_uniform"] = torch.rand((B * n, K)) if d["use_gumbel"] else torch.zeros((B * n, K))
+        draw_gumbel = d["use_gumbel"] and action_sampler is None      # model.py:171-176: an explicit sampler skips the Gumbel draw
+        noise["gumbel_uniform"] = torch.rand((B * n, K)) if draw_gumbel else torch.full((B * n, K), 0.5)
         for _ in range(n):
             torch.randn((B, self.random_noise_size))        # model.py:220/496: drawn, never consumed by R
         noise["eps_states_rec"] = torch.randn((B * T, Da), dtype=torch.float32)
@@ -234,6 +237,16 @@ class Model(nn.Module):
         variation = torch.randn((1, self.dims["action_dim"]), dtype=torch.float32)[0] if noise else None
         torch.randn((1, self.random_noise_size))             # generate_noise(batch_size=1), unused by R (model.py:596)
         return self._infer.generate_next(observation, action, variation)
+
+    def generate_next_interpolation(self, observation: torch.Tensor, first_action: int, second_action: int, interpolation_factor: float):
+        """model.py:609-655: act with the centroid nearer to the interpolated point, the offset to it as the action variation."""
+        if self._infer is None:
+            raise Exception("start_inference() must be called before generate_next_interpolation()")
+        cen = self.centroid_estimator.get_estimated_centroids()
+        selected = second_action if interpolation_factor > 0.5 else first_action
+        point = (cen[second_action] - cen[first_action]) * interpolation_factor + cen[first_action]
+        torch.randn((1, self.random_noise_size))             # generate_noise(batch_size=1), unused by R
+        return self._infer.generate_next(observation, selected, (point - cen[selected]).detach())
 
 
 def model(config):

@@ -7,11 +7,13 @@ from playablevideogeneration_amd.engine import Engine
 from tests import helpers as H
 
 
-def noise_dict(rec, B, T, K, Da):
-    """Map the oracle's recorded RNG draws (reference order) to the engine's noise arguments."""
+def noise_dict(rec, B, T, K, Da, gumbel=True):
+    """Map the oracle's recorded RNG draws (reference order) to the engine's noise arguments.
+    gumbel=False: an explicit action sampler replaced the Gumbel draw (model.py:171-176), so the record is one entry shorter."""
     n = T - 1
-    return {"eps_states": rec[0], "eps_dirs": rec[1].reshape(B * n, Da), "gumbel_uniform": rec[2],
-            "eps_states_rec": rec[3 + n], "eps_dirs_rec": rec[4 + n].reshape(B * n, Da)}
+    g = 1 if gumbel else 0
+    return {"eps_states": rec[0], "eps_dirs": rec[1].reshape(B * n, Da), "gumbel_uniform": rec[2] if gumbel else torch.full((B * n, K), 0.5),
+            "eps_states_rec": rec[2 + g + n], "eps_dirs_rec": rec[3 + g + n].reshape(B * n, Da)}
 
 
 def make_engine(c, lib, dev):
@@ -211,3 +213,90 @@ def rollout_case(name, lib, dev, tol=2e-4):
         err = (f.cpu().numpy() - z["frames"][i])
         assert np.abs(err).max() < tol and (err ** 2).mean() < 1e-5, (i, np.abs(err).max())
     assert np.abs(o.cpu().numpy() - z["last_obs"]).max() < tol
+    cen = P["centroid_estimator.estimated_centroids"]
+    for j, (a1, a2, al) in enumerate(H.INTERP):      # generate_next_interpolation: nearer centroid + offset as the variation
+        a1, a2 = a1 % c["K"], a2 % c["K"]
+        sel = a2 if al > 0.5 else a1
+        f, _ = eng.generate_next(o, sel, (cen[a2] - cen[a1]) * al + cen[a1] - cen[sel])
+        assert np.abs(f.cpu().numpy() - z["interp_frames"][j]).max() < tol, ("interpolation", j)
+
+
+def sampler_case(name, lib, dev, tol=2e-4):
+    """eval-mode forward_full_model with the evaluation samplers called mid-forward through caddy_set_sampler_hook, vs the
+    reference golden (reference samplers) and the oracle."""
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    acts, sampler, vsampler = H.sampler_inputs(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        oout = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=False).forward_full(
+            obs, c["gt"], tau=c["tau"], noise=nz, action_sampler=sampler, variation_sampler=vsampler, gt_actions=acts)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    eng.set_samplers(sampler, vsampler, acts[:, :-1].reshape(-1).to(dev))
+    nd = noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"], gumbel=False)
+    out = eng.forward_full(obs, c["gt"], c["tau"], nd, training=False)
+    _cmp(out, list(oout), tol, name + " vs oracle")
+    _cmp(out, H.golden_outputs(z), tol, name + " vs reference golden")
+    eng.set_samplers(None, None)
+    out2 = eng.forward_full(obs, c["gt"], c["tau"], nd, training=False)
+    assert not torch.equal(out2[7].cpu(), out[7].cpu())        # cleared: Gumbel samples again
+
+
+def property_case(lib, dev, c, seed=3):
+    """Size-independent properties of the whole path, for geometries where the oracle is too slow (the BASELINE workload:
+    BAIR 256x256, T=16, B=8):  (1) the forward pass is bit-reproducible; (2) in eval mode clips are independent, so permuting
+    the batch permutes every output bit-exactly (action indices included); (3) the reported total is the weighted sum of the
+    reported components; (4) the backward pass is linear in the loss weights (all weights x2 -> all gradients x2);
+    (5) frames are tanh-bounded, probabilities normalised, gradients finite and non-trivial."""
+    from playablevideogeneration_amd.init import init_parameters
+    B, T, K, Da, S, Hh, W = c["B"], c["T"], c["K"], c["Da"], c["S"], c["H"], c["W"]
+    eng = make_engine(c, lib, dev)
+    init_parameters(eng, seed)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    obs = torch.rand(B, T, 3 * S, Hh, W, device=dev, generator=g) * 2 - 1
+    n = T - 1
+    noise = {"eps_states": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs": torch.randn(B * n, Da, device=dev, generator=g),
+             "gumbel_uniform": torch.rand(B * n, K, device=dev, generator=g),
+             "eps_states_rec": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs_rec": torch.randn(B * n, Da, device=dev, generator=g)}
+    saved = eng.params.clone()
+
+    def flat(o):
+        return [t for x in o for t in (x if isinstance(x, (list, tuple)) else [x])]
+
+    # (1) reproducibility (train mode mutates BN running stats / centroids: restore the parameter buffer in between)
+    a = flat(eng.forward_full(obs, c["gt"], c["tau"], noise, training=True))
+    eng.params.copy_(saved)
+    b = flat(eng.forward_full(obs, c["gt"], c["tau"], noise, training=True))
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), ("forward not reproducible", i)
+    # (5) ranges
+    assert a[0].abs().max().item() <= 1.0 and torch.isfinite(a[0]).all()
+    # (3) total = weighted sum; (4) linearity of the backward in the weights
+    w1 = dict(H.LOSS_W)
+    l1 = eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    g1 = eng.grads.clone()
+    tot = sum(w1[k] * l1[k] for k in ("rec", "states", "entropy", "dir_kl", "mi", "state_kl"))
+    assert abs(tot - l1["total"]) <= 1e-6 * max(1.0, abs(tot)), (tot, l1["total"])
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    l2 = eng.loss_backward({k: 2 * v for k, v in w1.items() if k != "mi_entropy"}, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    g2 = eng.grads.clone()
+    assert abs(l2["total"] - 2 * l1["total"]) <= 1e-6 * max(1.0, abs(l1["total"]))
+    rel = ((g2 - 2 * g1).double().norm() / (2 * g1).double().norm()).item()
+    assert rel < 1e-4, ("backward not linear in the loss weights", rel)
+    # (2) eval-mode batch permutation
+    if B > 1:
+        eng.params.copy_(saved)
+        perm = torch.arange(B - 1, -1, -1, device=dev)
+
+        def pn(t, per):
+            return t.reshape(B, per, -1)[perm].reshape(t.shape).contiguous()
+        noise_p = {"eps_states": pn(noise["eps_states"], T), "eps_dirs": pn(noise["eps_dirs"], n), "gumbel_uniform": pn(noise["gumbel_uniform"], n),
+                   "eps_states_rec": pn(noise["eps_states_rec"], T), "eps_dirs_rec": pn(noise["eps_dirs_rec"], n)}
+        e0 = flat(eng.forward_full(obs, c["gt"], c["tau"], noise, training=False))
+        e1 = flat(eng.forward_full(obs[perm].contiguous(), c["gt"], c["tau"], noise_p, training=False))
+        for i, (x, y) in enumerate(zip(e0, e1)):
+            if x.dim() >= 1 and x.shape[0] == B:
+                assert torch.equal(x[perm], y), ("eval-mode output is not batch-permutation equivariant", i)
+    return eng

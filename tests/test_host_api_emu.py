@@ -82,3 +82,31 @@ def test_trainer_schedules_step_and_checkpoint(tmp_path):
     tr2 = smooth_mi_trainer.trainer(cfg, m2, dataset=None, logger=None)
     tr2.load_checkpoint(m2)
     assert torch.equal(m2._flat, m._flat) and tr2.global_step == 5000 and torch.equal(tr2.mi_ema, tr.mi_ema)
+
+
+def test_model_mirror_eval_samplers_and_interpolation_match_reference_goldens():
+    """Model.__call__(..., action_sampler=, action_variation_sampler=) and generate_next_interpolation through the plugin mirror,
+    seeded like the reference run that produced the goldens."""
+    from tests import model_cases as MC
+    c, z = H.load_case("eval_reduced_s1_gt")
+    d, P, obs = H.inputs_of(c)
+    acts, sampler, vsampler = H.sampler_inputs(c)
+    m = _make_model(_config())
+    m.load_state_dict(P)
+    m.eval()
+    torch.manual_seed(H.NOISE_SEED)
+    out = m((obs, acts, None, None), c["gt"], gumbel_temperature=c["tau"], action_sampler=sampler, action_variation_sampler=vsampler)
+    MC._cmp(list(out), H.golden_outputs(z), 2e-4, "mirror + samplers vs reference golden")
+    # play.py path with interpolation
+    c, z = H.load_case("rollout_reduced_s1")
+    d, P, obs = H.inputs_of(c)
+    m = _make_model(_config(res=(c["H"] // 8, c["W"] // 8)))
+    m.load_state_dict(P)
+    m.eval()
+    o = obs[0, 0]
+    m.start_inference()
+    for i in range(c["steps"]):
+        f, o = m.generate_next(o, i % c["K"])
+    for j, (a1, a2, al) in enumerate(H.INTERP):
+        f, _ = m.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
+        assert np.abs(f.cpu().numpy() - z["interp_frames"][j]).max() < 2e-4, j

@@ -33,3 +33,13 @@ def test_rollout_main_s4():
 
 def test_pretraining_main_s4():
     M.pretraining_case(load_emu(), "cpu")
+
+
+def test_size_independent_properties_small():
+    """the property set that the GPU suite runs at the BASELINE geometry, validated here on a geometry the simulator can afford"""
+    M.property_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=32, W=32, gt=2, tau=0.8))
+
+
+@pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])
+def test_eval_samplers(name):
+    M.sampler_case(name, load_emu(), "cpu")

@@ -61,3 +61,21 @@ def test_allreduce_hook_over_rccl_world1(lib):
         assert calls
     finally:
         dist.destroy_process_group()
+
+
+def test_baseline_geometry_properties(lib):
+    """BASELINE.json configs[1] at full size (BAIR 256x256, T=16, B=8, gt=6): reproducibility, batch-permutation equivariance,
+    loss composition, linearity of the backward (the oracle cannot run this size in test time)."""
+    M.property_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=8, T=16, H=256, W=256, gt=6, tau=1.0))
+    torch.cuda.empty_cache()
+
+
+def test_tennis_stacked_geometry_properties(lib):
+    """observation_stacking = 4 at 256x256 (Tennis-main shape), shortened sequence"""
+    M.property_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=4, B=2, T=6, H=256, W=256, gt=3, tau=0.9))
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])
+def test_eval_samplers(lib, name):
+    M.sampler_case(name, lib, "cuda")

@@ -74,6 +74,22 @@ def test_oracle_rollout_matches_reference_golden(name):
             f, o = orc.generate_next(o, i % c["K"])
             assert np.allclose(f.numpy(), z["frames"][i], atol=1e-6), i
     assert np.allclose(o.numpy(), z["last_obs"], atol=1e-6)
+    with torch.no_grad():                       # generate_next_interpolation (model.py:609-655) continues the same sequence
+        for j, (a1, a2, al) in enumerate(H.INTERP):
+            f, _ = orc.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
+            assert np.allclose(f.numpy(), z["interp_frames"][j], atol=1e-6), j
+
+
+@pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])
+def test_oracle_eval_samplers_match_reference_golden(name):
+    """eval-mode forward_full_model driven by the reference's evaluation samplers (evaluation/action_sampler.py)"""
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    acts, sampler, vsampler = H.sampler_inputs(c)
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        out = O.Oracle(d, P, training=False).forward_full(obs, c["gt"], tau=c["tau"], action_sampler=sampler, variation_sampler=vsampler, gt_actions=acts)
+    _cmp(out, H.golden_outputs(z), 1e-6, name)
 
 
 def test_loss_known_answers():

@@ -26,6 +26,11 @@ CASES = {
     "full_main_s4_hard": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=6, H=32, W=48, gt=2, tau=0.9, hard=True, pre=False),
     "pre_main_s4": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=4, H=32, W=32, gt=0, tau=1.0, hard=False, pre=True),
 }
+INTERP = [(1, 2, 0.3), (0, 2, 0.8)]           # (first_action, second_action, interpolation_factor) appended to the roll-out cases
+SAMPLER_CASES = {
+    "eval_main_s1_onehot_zero": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=5, H=32, W=32, gt=1, tau=1.0, hard=False, pre=False, sampler="onehot", zero_var=True),
+    "eval_reduced_s1_gt": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=1.0, hard=False, pre=False, sampler="gt", zero_var=False),
+}
 LOSS_W = dict(O.DEFAULT_LOSS_WEIGHTS, state_kl=1e-5, entropy=0.01)
 PARAM_SEED, OBS_SEED, NOISE_SEED = 7, 1, 5
 
@@ -115,8 +120,32 @@ def main():
             for i in range(c["steps"]):
                 f, o = ref.generate_next(o, i % c["K"])
                 frames.append(f.numpy())
+            # generate_next_interpolation (model.py:609-655) and generate_next(noise=True) continue the same sequence
+            interp = []
+            for (a1, a2, al) in INTERP:
+                f, o2 = ref.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
+                interp.append(f.numpy())
         np.savez_compressed(os.path.join(outdir, name + ".npz"), case=np.array(repr(cc | {"steps": c["steps"]})),
-                            frames=np.stack(frames), last_obs=o.numpy())
+                            frames=np.stack(frames), last_obs=o.numpy(), interp_frames=np.stack(interp))
+        print(name, "written")
+
+    # eval-mode forward_full_model with the evaluation samplers (evaluation/evaluator.py:126, evaluation_dataset_builder.py:57-63)
+    import evaluation.action_sampler as AS
+    import evaluation.action_variation_sampler as AVS
+    for name, c in SAMPLER_CASES.items():
+        cfg, d, P, obs = case_inputs(c)
+        ref = rh.build_reference_model(cfg, P)
+        ref.eval()
+        acts = (torch.arange(c["B"] * c["T"]).reshape(c["B"], c["T"]) % c["K"]).to(torch.int32)
+        sampler = AS.OneHotActionSampler() if c["sampler"] == "onehot" else AS.GroundTruthActionSampler({i: (i + 1) % c["K"] for i in range(c["K"])})
+        torch.manual_seed(NOISE_SEED)
+        random.seed(NOISE_SEED)
+        with torch.no_grad():
+            out = ref((obs, acts, None, None), c["gt"], gumbel_temperature=c["tau"], action_sampler=sampler,
+                      action_variation_sampler=AVS.ZeroActionVariationSampler() if c["zero_var"] else None)
+        data = flat_outputs(out)
+        data["case"] = np.array(repr(c))
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **data)
         print(name, "written")
 
 
