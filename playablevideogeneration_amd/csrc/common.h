@@ -55,6 +55,9 @@ struct ConvArgs {
     int precision;      // 0: exact fp32 MFMA; 3: 3-way split bf16 (hi/mid/lo planes, 6 products, ~fp32 accuracy); 2: 2-way split (3 products)
     int splitk;         // set by the launcher: K range split across blockIdx.z (atomic accumulation; accumulate mode only)
     float* aux;         // optional device scratch (>= CONV_AUX_BYTES, private to the launching stream): compact weight table of the thin kernels
+    float* split_scratch;   // optional: deterministic split-K of under-filled NON-accumulating launches (slabs + fixed-order reduce)
+    long split_cap;         // capacity of split_scratch in floats
+    long split_stride;      // set by the launcher: slab stride in floats (0 = atomics)
 };
 constexpr int CONV_AUX_BYTES = 128 * 1024;
 

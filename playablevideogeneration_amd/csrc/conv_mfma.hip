@@ -311,10 +311,25 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
                 float v = acc[i][j][r] + bv;
                 if (a.act == 1) v = tanhf(v);
                 float* o = a.out + off + col;
-                if (a.splitk > 1) atomicAdd(o, v);
+                if (a.splitk > 1) { if (a.split_stride) o[blockIdx.z * a.split_stride] = v; else atomicAdd(o, v); }
                 else { if (a.accumulate) v += *o; *o = v; }
             }
         }
+    }
+}
+
+// fixed-order sum of the split-K slabs of a forward conv: out[p][c] = sum_z slab_z[p][c]   (deterministic, unlike atomics)
+__global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld) {
+    const int C4 = ldc >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P * C4; i += (long)gridDim.x * 256) {
+        long p = i / C4; int c = (int)(i - p * C4) * 4;
+        const float* q = scr + p * ldc + c;
+        float4 v = *reinterpret_cast<const float4*>(q);
+        for (int z = 1; z < splits; z++) { float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        long n = p / HW;
+        float* o = out + n * out_sn + (p - n * HW) * (long)out_ld + c;
+        if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
+        else { if (c < C) o[0] = v.x; if (c + 1 < C) o[1] = v.y; if (c + 2 < C) o[2] = v.z; }
     }
 }
 
@@ -680,6 +695,20 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
     }
     if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
+    // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
+    // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
+    a.split_stride = 0;
+    float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld;
+    static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
+    if (!a.accumulate && a.act == 0 && a.bias == nullptr && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks < 256) {
+        int want = (int)((384 + blocks - 1) / blocks);
+        int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
+        int ldc = round_up(a.Cout, 4);
+        if (sk > 1 && (long)sk * P * ldc <= a.split_cap) {
+            a.splitk = sk; a.split_stride = P * ldc;
+            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc;
+        }
+    }
     static const int force_prec = getenv("CADDY_PRECISION") ? atoi(getenv("CADDY_PRECISION")) : -1;   // tuning / A-B aid
     if (force_prec >= 0) a.precision = force_prec;
     const int ns = (a.precision == 2 || a.precision == 3) ? a.precision : 0;
@@ -696,14 +725,20 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
         LAUNCH_CONV(1, 1, 2, 2);
         g_last_conv_kernel = CK_FWD_64x64;
-        return 0;
+    } else {
+        dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
+        g_last_conv_kernel = bn == 128 ? CK_FWD_128x128 : (bn == 64 ? CK_FWD_128x64 : CK_FWD_128x32);
+        if (bn == 128) LAUNCH_CONV(2, 2, 2, 2);
+        else if (bn == 64) LAUNCH_CONV(2, 1, 2, 2);
+        else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
     }
-    dim3 grid(cdiv(P, 128), a.Cout_pad / bn, a.splitk);
-    g_last_conv_kernel = bn == 128 ? CK_FWD_128x128 : (bn == 64 ? CK_FWD_128x64 : CK_FWD_128x32);
-    if (bn == 128) LAUNCH_CONV(2, 2, 2, 2);
-    else if (bn == 64) LAUNCH_CONV(2, 1, 2, 2);
-    else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
 #undef LAUNCH_CONV
+    if (a.split_stride) {
+        int ldc = a.out_ld;
+        long items = P * (ldc >> 2);
+        hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st,
+                           (const float*)a.split_scratch, a.split_stride, a.splitk, ldc, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld);
+    }
     return 0;
 }
 

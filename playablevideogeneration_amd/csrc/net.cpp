@@ -134,6 +134,7 @@ void make_bn(caddy_ctx* c, BNL& b, const std::string& p) {
     b.name = p; b.C = e.shape[0];
     b.gamma = PP(c, p + ".weight"); b.beta = PP(c, p + ".bias"); b.dgamma = GP(c, p + ".weight"); b.dbeta = GP(c, p + ".bias");
     b.rmean = PP(c, p + ".running_mean"); b.rvar = PP(c, p + ".running_var");
+    b.eval_stash = (float*)c->persist.alloc(sizeof(float) * 4 * (size_t)round_up(b.C, 4));
     c->bns.push_back(&b);
 }
 void make_res(caddy_ctx* c, ResL& R, const std::string& p, int cin, int cout, int ds) {
@@ -197,6 +198,8 @@ void build_layers(caddy_ctx* c) {
     c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
+    c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
+    c->conv_split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
 }
 }  // namespace
 
@@ -275,7 +278,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     ConvArgs a{};
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
-    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux;
+    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
     if (recording) {
@@ -342,7 +345,16 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     if (c->training) {
         if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, bn.rmean, bn.rvar, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
         if (!dry) bn.calls++;
-    } else if (!dry) c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
+        bn.eval_valid = false;
+        return s;
+    }
+    // eval mode: the affine form depends only on the parameters -> once per roll-out (generate_next runs ~25 BatchNorms per frame)
+    int cp = round_up(bn.C, 4);
+    s.mean = bn.eval_stash; s.invstd = bn.eval_stash + cp; s.scale = bn.eval_stash + 2 * cp; s.shift = bn.eval_stash + 3 * cp;
+    if (!dry && !bn.eval_valid) {
+        c->ck(pw_bn_finalize(s.sums, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, 0, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize");
+        bn.eval_valid = true;
+    }
     return s;
 }
 T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into) {
@@ -553,6 +565,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     c->act.reset(); c->tape.clear(); c->dbg.clear();
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
+    for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
     c->pack_all();
     caddy_noise z{}; if (nz) z = *nz;
@@ -608,6 +621,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     bool dry = c->dry;
     c->act.reset(); c->tape.clear(); c->dbg.clear();
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
+    for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
     c->pack_all();
     caddy_noise z{}; if (nz) z = *nz;
@@ -747,6 +761,7 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
 static int start_inference(caddy_ctx* c) {
     bool dry = c->dry;
     c->training = false; c->recording = false;
+    for (BNL* b : c->bns) b->eval_valid = false;      // parameters may have changed since the last roll-out
     c->pack_all();
     for (int i = 0; i < 3; i++) {
         LstmL& L = c->lstm[i];

@@ -39,7 +39,8 @@ struct ConvL {
     const float* bias = nullptr; float* dbias = nullptr;
     size_t wp_floats = 0;
 };
-struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0; };
+struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
+             float* eval_stash = nullptr; bool eval_valid = false; };   // eval mode: (mean, invstd, scale, shift) from the running statistics, computed once per start_inference / eval forward
 struct ResL { ConvL conv1, conv2, down; BNL bn1, bn2, bnd; bool has_down = false; int ds = 1; };
 struct LstmL { ConvL gates; BNL bn; float *init_h, *init_c, *ginit_h, *ginit_c;   // boundary (C,h,w) params + grads
                T4 ih, ic;        // HWC copies (1,h,w,C) in the persistent arena (data + grad)
@@ -82,6 +83,7 @@ struct caddy_ctx {
     double* loss_acc = nullptr;
     allreduce_hook_t hook = nullptr; void* hook_user = nullptr; int world = 1;   // data-parallel reductions of the K x K MI matrix / centroid sums
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
+    float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     bool have_forward = false;

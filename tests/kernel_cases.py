@@ -107,6 +107,8 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     a.precision = precision
     aux = torch.zeros(128 * 1024 // 4, device=dev)     # CONV_AUX_BYTES scratch (compact weight tables of the thin kernels)
     a.aux = aux.data_ptr() if use_aux else None
+    split = torch.zeros(9 * N * H * W * round_up(Cout, 4), device=dev)     # slabs of the deterministic forward split-K
+    a.split_scratch, a.split_cap = (split.data_ptr(), split.numel()) if use_aux else (None, 0)
     out_ld = round_up(Cout, 4) + 4
     out = torch.full((N, H, W, out_ld), 9.0, device=dev)
     a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0

@@ -42,6 +42,8 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     a.accumulate = 1 if name.startswith('dgrad') else 0
     aux = torch.zeros(128 * 1024 // 4, device='cuda')
     a.aux = aux.data_ptr()
+    split = torch.zeros(9 * 4096 * 256, device='cuda')
+    a.split_scratch, a.split_cap = split.data_ptr(), split.numel()
     dy = torch.randn(N, H, W, round_up(Cout, 4), device="cuda")
     dwp = torch.zeros_like(wp)
     wa = WgradArgs()
