@@ -126,12 +126,12 @@ int caddy_start_inference(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.
- *     out48 = 12 kernels {k_conv_fwd<2,2,2,2,*>, k_conv_fwd<2,1,2,2,*>, k_conv_fwd<1,1,2,2,*>, k_conv_fwd<1,1,4,1,*>, k_conv_thin_out,
+ *     out52 = 13 kernels {k_conv_fwd<2,2,2,2,*>, k_conv_fwd<2,1,2,2,*>, k_conv_fwd<1,1,2,2,*>, k_conv_fwd<1,1,4,1,*>, k_conv_thin_out,
  *             k_conv_thin_in, k_conv_wgrad<2,2,2,2>, k_conv_wgrad<1,2,2,2>, k_conv_wgrad<1,1,1,4>, k_conv_wgrad_small, k_wgrad_thin,
- *             k_conv_wgrad_tile}
+ *             k_conv_wgrad_tile, k_conv_narrow}
  *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
 int caddy_profile_begin(caddy_ctx* ctx);
-int caddy_profile_end(caddy_ctx* ctx, double* out48);
+int caddy_profile_end(caddy_ctx* ctx, double* out52);
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each
  * {kind 0 fwd / 1 dgrad / 2 wgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
 int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);

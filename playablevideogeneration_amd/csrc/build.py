@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["conv_mfma.hip", "conv_thin.hip", "pointwise.hip", "pack.hip", "head.hip", "net.cpp", "capi_kernels.cpp", "capi.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_thin.hip", "conv_narrow.hip", "pointwise.hip", "pack.hip", "head.hip", "net.cpp", "capi_kernels.cpp", "capi.cpp"]
 LIB = os.path.join(HERE, "libcaddy_hip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libcaddy_emu.so")
 

@@ -77,10 +77,12 @@ struct WgradArgs {
 };
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
-enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_COUNT };
+enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW, CK_COUNT };
 extern thread_local int g_last_conv_kernel;
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
+int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st);
+int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st);   // conv_narrow.hip: 1 = handled (3x3, 13..32 channels in, 5..32 out)
 int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st);   // N-tile (32/64/128) the launcher will use for this Cout

@@ -678,6 +678,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
     if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
+    if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;
     // tile choice: 128-row tiles when they fill the chip (256 CUs x ~3 resident workgroups), otherwise 64x64 tiles; the
     // remaining deficit of accumulating launches (dgrad) is covered by splitting K across blockIdx.z (fp32 atomics).
@@ -748,6 +749,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     if (conv_thin_wgrad_try(a, st) == 1) return 0;
+    if (conv_narrow_wgrad_try(a, st) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
     static const int narrow_tile = getenv("CADDY_WGRAD_NARROW_TILE") ? atoi(getenv("CADDY_WGRAD_NARROW_TILE")) : 1;   // A/B aid: K = 64 narrow layers -> tile-resident kernel

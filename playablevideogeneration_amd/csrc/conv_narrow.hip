@@ -1,0 +1,279 @@
+// Narrow 3x3 convolutions (16 / 32 channels in AND out: E's first residual blocks on all B*T frames, their dgrads, the last
+// decoder block) on v_mfma_f32_16x16x4_f32.
+//
+// The generic implicit-GEMM kernel (conv_mfma.hip) is a poor fit here: its 32-wide N tile is half padding for 16 output
+// channels, and with only 16-32 input channels per tap it re-reads the input nine times through L2 (measured 302 us for a
+// 16->16 layer over 128 frames of 128x128 whose HBM-bound time is ~70 us).  Here a workgroup stages the 10x34 halo of an 8x32
+// pixel tile in LDS ONCE and all nine taps read from it; M = output channels (16 per MFMA, no padding), N = 16 pixels,
+// K = 4 channels per MFMA.  One ds_read_b128 per lane (pixel = lane & 15, channels 4g..4g+3, g = lane >> 4) feeds four MFMAs
+// (the j-th uses component j, i.e. the k-set {j, 4+j, 8+j, 12+j} on both operands); the weights of all taps live in registers
+// for the lifetime of the (persistent) workgroup.  The D fragment (4 consecutive output channels of one pixel per lane) is a
+// float4 NHWC store.  Exact fp32, same packed weight layout / ConvArgs contract as conv_mfma.hip; forward and dgrad.
+// Roofline: HBM for 16->16 (AI ~ 18 FLOP/B), fp32 matrix rate for 32->32.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+constexpr int NTW = 32, NTH = 8, NHW = NTW + 2, NHH = NTH + 2;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 nld4(const float* q, int c, int C) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 4 <= C) v = *reinterpret_cast<const float4*>(q);
+    else { if (c < C) v.x = q[0]; if (c + 1 < C) v.y = q[1]; if (c + 2 < C) v.z = q[2]; }
+    return v;
+}
+
+// CI4 = input channels / 16 (1 or 2), NT = output channels / 16 (1 or 2)
+template <int CI4, int NT>
+__global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int CI = 16 * CI4, PITCH = CI + 4, Q = CI / 4;        // Q float4 per pixel
+    constexpr int NLOAD = (NHH * NHW * Q + 255) / 256;               // halo float4 per thread (6 or 11)
+    __shared__ float xs[NHH * NHW * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, g = lane >> 4;
+    const ConvSrc s = a.src[0];
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+
+    // weights: W[tap][mt*16 + lp][ch*16 + 4g .. +3]
+    float4 w[9][NT][CI4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int m = 0; m < NT; m++)
+#pragma unroll
+            for (int ch = 0; ch < CI4; ch++)
+                w[t][m][ch] = *reinterpret_cast<const float4*>(a.wp + ((long)t * a.Cout_pad + m * 16 + lp) * a.Ktot + ch * 16 + 4 * g);
+
+    // halo loader: float4 index idx = tid + 256 i -> (pixel idx / Q, quad idx % Q); Q is a power of two
+    float4 pre[NLOAD];
+    auto gload = [&](long tile) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int ty = rem / tiles_x;
+        int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+        const float* base = s.p + (long)n * s.sn;
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            int idx = tid + 256 * i, hp = idx / Q, c = (idx % Q) * 4;
+            int hy = hp / NHW, hx = hp - hy * NHW;
+            int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NHH * NHW && y >= 0 && y < a.H && x >= 0 && x < a.W && c < s.C) pre[i] = nld4(base + ((long)y * a.W + x) * s.ld + c, c, s.C);
+        }
+    };
+
+    long tile = blockIdx.x;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            int idx = tid + 256 * i, hp = idx / Q;
+            if (hp < NHH * NHW) *reinterpret_cast<float4*>(&xs[hp * PITCH + (idx % Q) * 4]) = pre[i];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int m = 0; m < NT; m++) acc[nt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {                       // n-tile = (row 2*wave + (nt >> 1), columns 16*(nt & 1) .. +15)
+                const float* xp = &xs[((2 * wave + (nt >> 1) + dy) * NHW + 16 * (nt & 1) + lp + dx) * PITCH + 4 * g];
+#pragma unroll
+                for (int ch = 0; ch < CI4; ch++) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xp + 16 * ch);
+#pragma unroll
+                    for (int m = 0; m < NT; m++) {
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m][ch].x, xv.x, acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m][ch].y, xv.y, acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m][ch].z, xv.z, acc[nt][m], 0, 0, 0);
+                        acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m][ch].w, xv.w, acc[nt][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // epilogue: lane holds output channels m*16 + 4g .. +3 of pixel (row, col)
+        {
+            int n = (int)(tile / (tiles_x * tiles_y));
+            int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+            int ty = rem / tiles_x;
+            int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + lp;
+                if (y >= a.H || x >= a.W) continue;
+                float* o = a.out + (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld;
+#pragma unroll
+                for (int m = 0; m < NT; m++) {
+                    int c = m * 16 + 4 * g;
+                    if (c >= a.Cout) continue;
+                    float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
+                    if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
+                    if (c + 4 <= a.Cout) {
+                        float4 r = make_float4(v[0], v[1], v[2], v[3]);
+                        if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+                        *reinterpret_cast<float4*>(o + c) = r;
+                    } else {
+                        for (int e = 0; e < 4 && c + e < a.Cout; e++) o[c + e] = a.accumulate ? o[c + e] + v[e] : v[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// returns 1 if handled, 0 if the shape does not qualify
+int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st) {
+    static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;      // A/B aid
+    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || a.act != 0 || a.splitk > 1) return 0;
+    if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
+    if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.out_ld & 3) || (a.out_sn & 3) || a.Cout_pad < 16 * ((a.Cout + 15) / 16)) return 0;
+    if ((long)a.N * a.H * a.W < 4096) return 0;                    // tiny maps: the generic kernel's split-K paths do better
+    const int tx = cdiv(a.W, NTW), ty = cdiv(a.H, NTH);
+    const long ntiles = (long)a.N * tx * ty;
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    const int ci4 = a.Ktot / 16, nt = (a.Cout + 15) / 16;
+    if (ci4 == 1 && nt == 1) hipLaunchKernelGGL((k_conv_narrow<1, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else if (ci4 == 1) hipLaunchKernelGGL((k_conv_narrow<1, 2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else if (nt == 1) hipLaunchKernelGGL((k_conv_narrow<2, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((k_conv_narrow<2, 2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    g_last_conv_kernel = CK_NARROW;
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// wgrad of the same layers when one side has only 16 channels (the 32x32x2 tile of k_conv_wgrad_small is 50-75 % padding there).
+// M = 16 output channels, N = 16 input channels, K = 4 horizontally adjacent pixels per MFMA; operands are single floats read
+// from [pixel][channel] LDS tiles whose pitch (16 floats for 16 channels, 48 for 32) puts the four k-lanes (pixels x .. x+3)
+// on four disjoint 16-bank ranges.  A wave owns two rows of the 8x32 tile, keeps all nine taps' accumulators in registers over a
+// persistent tile loop (one dY fragment + nine shifted X fragments per 9 MFMAs) and flushes once with fp32 atomics.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int CI16, int CO16>
+__global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int tiles_x, int tiles_y) {
+    constexpr int PX = CI16 == 1 ? 16 : 48, PY = CO16 == 1 ? 16 : 48;
+    constexpr int QX = 4 * CI16, QY = 4 * CO16;
+    constexpr int NX = (NHH * NHW * QX + 255) / 256, NY = NTH * NTW * QY / 256;
+    __shared__ float xs[NHH * NHW * PX];
+    __shared__ float ys[NTH * NTW * PY];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, g = lane >> 4;
+    const ConvSrc s = a.src[0];
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+    f32x4 acc[9][CO16][CI16];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int m = 0; m < CO16; m++)
+#pragma unroll
+            for (int n = 0; n < CI16; n++) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 px[NX], py[NY];
+    auto gload = [&](long tile) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int ty = rem / tiles_x;
+        int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+        const float* bx = s.p + (long)n * s.sn;
+        const float* by = a.dy + (long)n * a.dy_sn;
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            int idx = tid + 256 * i, hp = idx / QX, c = (idx % QX) * 4;
+            int hy = hp / NHW, hx = hp - hy * NHW;
+            int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NHH * NHW && y >= 0 && y < a.H && x >= 0 && x < a.W && c < s.C) px[i] = nld4(bx + ((long)y * a.W + x) * s.ld + c, c, s.C);
+        }
+#pragma unroll
+        for (int i = 0; i < NY; i++) {
+            int idx = tid + 256 * i, p = idx / QY, c = (idx % QY) * 4;
+            int y = y0 + p / NTW, x = x0 + (p & (NTW - 1));
+            py[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < a.H && x < a.W && c < a.Cout) py[i] = nld4(by + ((long)y * a.W + x) * a.dy_ld + c, c, a.Cout);
+        }
+    };
+
+    long tile = blockIdx.x;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            int idx = tid + 256 * i, hp = idx / QX;
+            if (hp < NHH * NHW) *reinterpret_cast<float4*>(&xs[hp * PX + (idx % QX) * 4]) = px[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NY; i++) {
+            int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(&ys[(idx / QY) * PY + (idx % QY) * 4]) = py[i];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+#pragma unroll 2
+        for (int grp = 0; grp < 16; grp++) {                 // 4-pixel groups of this wave's two rows
+            const int row = 2 * wave + (grp >> 3), x0 = 4 * (grp & 7) + g;
+            float fa[CO16];
+#pragma unroll
+            for (int m = 0; m < CO16; m++) fa[m] = ys[(row * NTW + x0) * PY + m * 16 + lp];
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int dy = t / 3, dx = t - 3 * dy;
+                const float* xp = &xs[((row + dy) * NHW + x0 + dx) * PX + lp];
+#pragma unroll
+                for (int n = 0; n < CI16; n++) {
+                    const float fb = xp[n * 16];
+#pragma unroll
+                    for (int m = 0; m < CO16; m++) acc[t][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fb, acc[t][m][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // fold the four waves' partial sums in LDS (ds_add_f32 on the now idle X tile), then one global atomic per weight and workgroup
+    constexpr int NW = 9 * CO16 * 16 * CI16 * 16;
+    static_assert(NW <= NHH * NHW * PX, "LDS reduction buffer must fit in the X tile");
+    float* red = xs;
+    for (int i = tid; i < NW; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int m = 0; m < CO16; m++)
+#pragma unroll
+            for (int n = 0; n < CI16; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(&red[((t * CO16 * 16) + m * 16 + 4 * g + r) * (CI16 * 16) + n * 16 + lp], acc[t][m][n][r]);
+    __syncthreads();
+    for (int i = tid; i < NW; i += 256) {
+        int k = i % (CI16 * 16), to = i / (CI16 * 16);
+        int o = to % (CO16 * 16), t = to / (CO16 * 16);
+        if (k < a.Ktot && o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, red[i]);
+    }
+}
+}  // namespace
+
+int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st) {
+    static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;
+    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3) return 0;
+    if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
+    const int ci = a.Ktot / 16, co = (a.Cout + 15) / 16;
+    if (ci == 2 && co == 2) return 0;                              // 32 x 32: no padding in the 32x32x2 kernel
+    if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.dy_ld & 3) || (a.dy_sn & 3)) return 0;
+    if ((long)a.N * a.H * a.W < 4096) return 0;
+    const int tx = cdiv(a.W, NTW), ty = cdiv(a.H, NTH);
+    const long ntiles = (long)a.N * tx * ty;
+    long want = ntiles / 4;                                        // >= 4 tiles per workgroup amortise the flush
+    const int grid = (int)(want < 64 ? (ntiles < 64 ? ntiles : 64) : (want < 512 ? want : 512));
+    if (ci == 1 && co == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else if (ci == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_narrow<2, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    g_last_conv_kernel = CK_WGRAD_SMALL;
+    return 1;
+}

@@ -932,7 +932,7 @@ int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per
     }
     return n;
 }
-int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (12) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 48 doubles
+int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (13) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 52 doubles
     hipStreamSynchronize(c->stream);
     if (c->side) hipStreamSynchronize(c->side);
     for (int i = 0; i < 4 * CK_COUNT; i++) out18[i] = 0.0;

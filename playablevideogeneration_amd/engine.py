@@ -289,7 +289,7 @@ class Engine:
 
     CONV_FAMILIES = ["k_conv_fwd<2, 2, 2, 2, 0, 1>", "k_conv_fwd<2, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 4, 1, 0, 1>",
                      "k_conv_thin_out", "k_conv_thin_in", "k_conv_wgrad<2, 2, 2, 2>", "k_conv_wgrad<1, 2, 2, 2>", "k_conv_wgrad<1, 1, 1, 4>",
-                     "k_conv_wgrad_small", "k_wgrad_thin", "k_conv_wgrad_tile"]      # rocprofv3 kernel names (exact-fp32 build of k_conv_fwd)
+                     "k_conv_wgrad_small", "k_wgrad_thin", "k_conv_wgrad_tile", "k_conv_narrow"]      # rocprofv3 kernel names (exact-fp32 build of k_conv_fwd)
 
     def profile_begin(self):
         self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))
@@ -301,7 +301,7 @@ class Engine:
 
     def profile_end(self):
         """-> {kernel: (launches, algorithmic FLOPs, milliseconds, algorithmic bytes)}, HIP events on the launch stream."""
-        out = (C.c_double * 48)()
+        out = (C.c_double * 52)()
         self._check(self.lib.caddy_profile_end(C.c_void_p(self.ctx), out))
         return {n: (int(out[4 * i]), out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]) for i, n in enumerate(self.CONV_FAMILIES)}
 

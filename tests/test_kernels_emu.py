@@ -25,6 +25,10 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=9, W=40, segs=[(24, 0)], Cout=16, KS=3, bias=True),
     dict(N=2, H=13, W=10, segs=[(64, 0), (9, 1), (40, 0)], Cout=72, KS=3),    # tile-resident wgrad: ragged tiles, 3 segments, 2 k-tiles
     dict(N=1, H=6, W=21, segs=[(80, 0)], Cout=24, KS=3),                       # tile-resident wgrad, 32-channel output variant
+    dict(N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3),                      # narrow conv kernel <1,1> (16x16x4 MFMA), ragged tiles
+    dict(N=2, H=42, W=50, segs=[(32, 0)], Cout=24, KS=3, bias=True),           # narrow conv <2,2>, channel tail, bias; dgrad runs <2,2> as 24 -> 32
+    dict(N=1, H=64, W=64, segs=[(20, 0)], Cout=16, KS=3),                      # narrow conv <2,1>; dgrad <1,2>; wgrad <2,1>
+    dict(N=1, H=65, W=66, segs=[(16, 0)], Cout=29, KS=3),                      # narrow wgrad <1,2>, ragged tiles, channel tail
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)

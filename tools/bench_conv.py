@@ -24,6 +24,8 @@ SHAPES += [("dgrad lstm0-x 512->64 @32", 8, 32, 32, 512, 64, 3), ("dgrad lstm1-x
            ("stem 3->16 @256x128f", 128, 256, 256, 3, 16, 3), ("stem 3->16 @256x8f", 8, 256, 256, 3, 16, 3), ("final 64->3 k3 @128", 8, 128, 128, 64, 3, 3),
            ("fdgrad 3->32 k7 @256", 8, 256, 256, 3, 32, 7), ("fdgrad 3->64 k3 @128", 8, 128, 128, 3, 64, 3), ("fdgrad 3->128 k3 @64", 8, 64, 64, 3, 128, 3),
            ("final 128->3 k3 @64", 8, 64, 64, 128, 3, 3), ("sdgrad 16->3 k7 @256", 8, 256, 256, 16, 3, 7),
+           ("narrow 32->32 @64x128f", 128, 64, 64, 32, 32, 3), ("narrow 16->32 @128x128f", 128, 128, 128, 16, 32, 3), ("narrow 16->16 @128x8f", 8, 128, 128, 16, 16, 3),
+           ("narrow 32->32 @256x8f", 8, 256, 256, 32, 32, 3), ("narrow 32->16 @128x128f", 128, 128, 128, 32, 16, 3),
            ("A res0 64->128 @32x128f", 128, 32, 32, 64, 128, 3), ("A res1 128->128 @16x128f", 128, 16, 16, 128, 128, 3), ("E 32->64 @64x128f", 128, 64, 64, 32, 64, 3)]
 for name, N, H, W, Cin, Cout, KS in SHAPES:
     if ONLY and ONLY not in name:

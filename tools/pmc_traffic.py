@@ -16,7 +16,7 @@ def short(name):
     if m:
         return "k_map<" + m.group(1) + ">"
     n = n.split("(")[0]
-    n = re.sub(r"^(k_conv_thin_out|k_conv_thin_in|k_wgrad_thin|k_conv_wgrad_small|k_conv_wgrad_tile)<.*>$", r"\1", n)
+    n = re.sub(r"^(k_conv_thin_out|k_conv_thin_in|k_wgrad_thin|k_conv_wgrad_small|k_conv_wgrad_tile|k_conv_narrow)<.*>$", r"\1", n)
     return n
 
 
