@@ -62,6 +62,6 @@ int caddy_k_colsum(const TV* x, float* out, void* s) { return pw_colsum(*x, out,
 int caddy_k_spatial_sum(const TV* x, float* out, long out_sn, void* s) { return pw_spatial_sum(*x, out, out_sn, ST(s)); }
 int caddy_k_nchw_to_nhwc(const float* src, long src_sn, const TV* d, void* s) { return pw_nchw_to_nhwc(src, src_sn, *d, ST(s)); }
 int caddy_k_nhwc_to_nchw(const TV* src, float* dst, long dst_sn, int acc, void* s) { return pw_nhwc_to_nchw(*src, dst, dst_sn, acc, ST(s)); }
-int caddy_k_bcast_input_grad(const TV* dz, const PackDesc* d, int seg, float* S, float* g, long g_sn, void* s) { return pw_bcast_input_grad(*dz, *d, seg, S, g, g_sn, ST(s)); }
+int caddy_k_bcast_input_grad(const TV* dz, const PackDesc* d, int seg, float* S, float* g, long g_sn, float* dbias, void* s) { return pw_bcast_input_grad(*dz, *d, seg, S, g, g_sn, dbias, ST(s)); }
 int caddy_k_batch_sum(const float* src, long sn, long n_el, int N, float* dst, void* s) { return pw_batch_sum(src, sn, n_el, N, dst, ST(s)); }
 }

@@ -84,5 +84,7 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st);
+int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st);
+int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA
 int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st);   // conv_narrow.hip: 1 = handled (3x3, 13..32 channels in, 5..32 out)
 int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st);   // N-tile (32/64/128) the launcher will use for this Cout

@@ -677,6 +677,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
+    if (conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
     if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
     if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;
@@ -748,6 +749,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC) return -1;
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
+    if (conv_c4_wgrad_try(a, st) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
     if (conv_thin_wgrad_try(a, st) == 1) return 0;
     if (conv_narrow_wgrad_try(a, st) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;

@@ -277,3 +277,246 @@ int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st) {
     g_last_conv_kernel = CK_WGRAD_SMALL;
     return 1;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 3-channel INPUT (pitch 4) convolutions: E's stem and the dgrad of the FinalBlocks (3x3 and 7x7).  v_mfma_f32_16x16x4_f32's K = 4
+// is exactly one pixel's padded channel vector, so one MFMA per (tap, 16 output channels, 16 pixels) with NO channel padding beyond
+// 3 -> 4: B operand = xs[pixel + tap][lane >> 4] straight from the staged halo tile (64 consecutive floats per wave read:
+// conflict-free), A operand = the tap's weight column held in registers.  Replaces the vector-ALU k_conv_thin_in (200 us -> see
+// DESIGN.md for the measured figure on the 7x7 3->32 dgrad at 256x256).
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void k_conv_c4(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int R = KS / 2, HW_ = NTW + 2 * R, HH_ = NTH + 2 * R, TAPS = KS * KS;
+    constexpr int NL = (HH_ * HW_ + 255) / 256;
+    __shared__ float xs[HH_ * HW_ * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, g = lane >> 4;
+    const ConvSrc s = a.src[0];
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+    const int og = blockIdx.y * NT * 16;                    // first output channel of this workgroup
+
+    float w[TAPS][NT];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int m = 0; m < NT; m++) w[t][m] = a.wp[((long)t * a.Cout_pad + og + m * 16 + lp) * a.Ktot + g];
+
+    float4 pre[NL];
+    auto gload = [&](long tile) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int ty = rem / tiles_x;
+        int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+        const float* base = s.p + (long)n * s.sn;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            int hp = tid + 256 * i;
+            int hy = hp / HW_, hx = hp - hy * HW_;
+            int y = y0 - R + hy, x = x0 - R + hx;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < HH_ * HW_ && y >= 0 && y < a.H && x >= 0 && x < a.W) pre[i] = nld4(base + ((long)y * a.W + x) * 4, 0, s.C);
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            int hp = tid + 256 * i;
+            if (hp < HH_ * HW_) *reinterpret_cast<float4*>(&xs[hp * 4]) = pre[i];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int m = 0; m < NT; m++) acc[nt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            const int dy = t / KS, dx = t - KS * dy;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const float b = xs[((2 * wave + (nt >> 1) + dy) * HW_ + 16 * (nt & 1) + lp + dx) * 4 + g];
+#pragma unroll
+                for (int m = 0; m < NT; m++) acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m], b, acc[nt][m], 0, 0, 0);
+            }
+        }
+        {
+            int n = (int)(tile / (tiles_x * tiles_y));
+            int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+            int ty = rem / tiles_x;
+            int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + lp;
+                if (y >= a.H || x >= a.W) continue;
+                float* o = a.out + (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld;
+#pragma unroll
+                for (int m = 0; m < NT; m++) {
+                    int c = og + m * 16 + 4 * g;
+                    if (c >= a.Cout) continue;
+                    float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
+                    if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
+                    if (c + 4 <= a.Cout) {
+                        float4 r = make_float4(v[0], v[1], v[2], v[3]);
+                        if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+                        *reinterpret_cast<float4*>(o + c) = r;
+                    } else {
+                        for (int e = 0; e < 4 && c + e < a.Cout; e++) o[c + e] = a.accumulate ? o[c + e] + v[e] : v[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st) {
+    static const bool off = getenv("CADDY_C4") && atoi(getenv("CADDY_C4")) == 0;      // A/B aid
+    if (off || a.nsrc != 1 || a.src[0].bcast || a.act != 0 || a.splitk > 1 || (a.KS != 3 && a.KS != 7)) return 0;
+    if (a.src[0].C > 4 || a.src[0].ld != 4 || (a.src[0].sn & 3) || a.Ktot != 16 || a.Cout < 8 || (a.out_ld & 3) || (a.out_sn & 3)) return 0;
+    const int mt = (a.Cout + 15) / 16;                       // 16-channel output tiles
+    if (a.Cout_pad < mt * 16) return 0;
+    const int tx = cdiv(a.W, NTW), ty = cdiv(a.H, NTH);
+    const long ntiles = (long)a.N * tx * ty;
+    const int nt = a.KS == 7 ? (mt >= 2 ? 2 : 1) : (mt >= 8 ? 8 : (mt >= 4 ? 4 : (mt >= 2 ? 2 : 1)));
+    const int groups = cdiv(mt, nt);
+    long gx = 1024 / groups; if (gx < 64) gx = 64; if (gx > ntiles) gx = ntiles;
+    dim3 grid((unsigned)gx, groups);
+#define C4_LAUNCH(KS_, NT_) hipLaunchKernelGGL((k_conv_c4<KS_, NT_>), grid, dim3(256), 0, st, a, tx, ty)
+    if (a.KS == 7) { if (nt == 2) C4_LAUNCH(7, 2); else C4_LAUNCH(7, 1); }
+    else if (nt == 8) C4_LAUNCH(3, 8);
+    else if (nt == 4) C4_LAUNCH(3, 4);
+    else if (nt == 2) C4_LAUNCH(3, 2);
+    else C4_LAUNCH(3, 1);
+#undef C4_LAUNCH
+    g_last_conv_kernel = CK_THIN_IN;
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// wgrad with a 3-channel (pitch 4) side: G[tap][t][w] = sum_p Wide[p][w] * Thin[p + sigma * off(tap)][t]
+//   swap = 0 (FinalBlocks: thin = dY, wide = X, sigma = -1)  -> dwp[(tap * Cout_pad + t) * Ktot + w]
+//   swap = 1 (E's stem:    thin = X,  wide = dY, sigma = +1) -> dwp[(tap * Cout_pad + w) * Ktot + t]
+// 16x16x4 MFMA: M = 16 wide channels, N = 16 = (4 horizontal taps) x (4 thin channels), K = 4 horizontally adjacent pixels.  A 7x7
+// layer is 7 x 2 such column groups: per 4-pixel group one wide fragment + 14 thin fragments (all single-float LDS reads, the thin
+// ones mostly broadcasts) feed 14 MFMAs.  Waves own two rows of the 8x32 tile, accumulate over a persistent tile loop, fold in LDS and
+// flush once with atomics.  blockIdx.y = 16-channel chunk of the wide tensor.  Replaces the vector-ALU k_wgrad_thin for C <= 4.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int KS>
+__global__ __launch_bounds__(256) void k_wgrad_c4(const float* thin, long thin_sn, int TC, const float* wide, long wide_sn, int wide_ld, int WC,
+                                                   int N, int H, int W, int swap, int Cout_pad, int Ktot, float* dwp, int tiles_x, int tiles_y) {
+    constexpr int R = KS / 2, HW_ = NTW + 2 * R, HH_ = NTH + 2 * R, DXG = (KS + 3) / 4, TAPS = KS * KS;
+    constexpr int NLT = (HH_ * HW_ + 255) / 256, NLW = NTH * NTW * 4 / 256;
+    constexpr int NG = KS * DXG * 16 * 16;                     // floats of the per-workgroup partial G (dy, dx group, column, row)
+    __shared__ float th[HH_ * HW_ * 4];
+    __shared__ float wd[(NTH * NTW * 16 > NG) ? NTH * NTW * 16 : NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, g = lane >> 4;
+    const int w0 = blockIdx.y * 16;
+    const int sg = swap ? 1 : -1;
+    const long ntiles = (long)N * tiles_x * tiles_y;
+    f32x4 acc[KS][DXG];
+#pragma unroll
+    for (int i = 0; i < KS; i++)
+#pragma unroll
+        for (int j = 0; j < DXG; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's column = (horizontal tap dxi, thin channel t); per column group the tap is dx = 4*dxg + dxi (clamped: extra columns are dropped)
+    const int dxi = lp >> 2, tch = lp & 3;
+    int hoff[DXG];
+#pragma unroll
+    for (int j = 0; j < DXG; j++) { int dx = 4 * j + dxi; if (dx > KS - 1) dx = KS - 1; hoff[j] = (R + sg * (dx - R)) * 4 + tch; }
+
+    float4 pt[NLT], pw[NLW];
+    auto gload = [&](long tile) {
+        int n = (int)(tile / (tiles_x * tiles_y));
+        int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        int ty = rem / tiles_x;
+        int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+#pragma unroll
+        for (int i = 0; i < NLT; i++) {
+            int hp = tid + 256 * i;
+            int hy = hp / HW_, hx = hp - hy * HW_;
+            int y = y0 - R + hy, x = x0 - R + hx;
+            pt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < HH_ * HW_ && y >= 0 && y < H && x >= 0 && x < W) pt[i] = nld4(thin + (long)n * thin_sn + ((long)y * W + x) * 4, 0, TC);
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; i++) {
+            int idx = tid + 256 * i, p = idx >> 2, c = w0 + (idx & 3) * 4;
+            int y = y0 + p / NTW, x = x0 + (p & (NTW - 1));
+            pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < H && x < W && c < WC) pw[i] = nld4(wide + (long)n * wide_sn + ((long)y * W + x) * wide_ld + c, c, WC);
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < ntiles) gload(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NLT; i++) { int hp = tid + 256 * i; if (hp < HH_ * HW_) *reinterpret_cast<float4*>(&th[hp * 4]) = pt[i]; }
+#pragma unroll
+        for (int i = 0; i < NLW; i++) { int idx = tid + 256 * i; *reinterpret_cast<float4*>(&wd[(idx >> 2) * 16 + (idx & 3) * 4]) = pw[i]; }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+#pragma unroll 2
+        for (int grp = 0; grp < 16; grp++) {
+            const int row = 2 * wave + (grp >> 3), x0 = 4 * (grp & 7) + g;
+            const float fa = wd[(row * NTW + x0) * 16 + lp];
+#pragma unroll
+            for (int i = 0; i < KS; i++) {
+                const float* tp = &th[((row + R + sg * (i - R)) * HW_ + x0) * 4];
+#pragma unroll
+                for (int j = 0; j < DXG; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, tp[hoff[j]], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // fold the four waves in LDS, then one global atomic per element and workgroup
+    float* red = wd;
+    for (int i = tid; i < NG; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KS; i++)
+#pragma unroll
+        for (int j = 0; j < DXG; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&red[((i * DXG + j) * 16 + lp) * 16 + 4 * g + r], acc[i][j][r]);
+    __syncthreads();
+    for (int e = tid; e < NG; e += 256) {
+        int wr = e & 15, col = (e >> 4) & 15, ij = e >> 8;
+        int j = ij % DXG, i = ij / DXG;
+        int dx = 4 * j + (col >> 2), t = col & 3, wch = w0 + wr;
+        if (dx >= KS || t >= TC || wch >= WC) continue;
+        int tap = i * KS + dx;
+        float* d = swap ? dwp + ((long)tap * Cout_pad + wch) * Ktot + t : dwp + ((long)tap * Cout_pad + t) * Ktot + wch;
+        atomicAdd(d, red[e]);
+    }
+    (void)TAPS;
+}
+}  // namespace
+
+int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st) {
+    static const bool off = getenv("CADDY_C4") && atoi(getenv("CADDY_C4")) == 0;
+    if (off || w.nsrc != 1 || w.src[0].bcast || (w.KS != 3 && w.KS != 7)) return 0;
+    const float *thin, *wide; long thin_sn, wide_sn; int TC, WC, wide_ld, swap;
+    if (w.Cout <= 4 && w.dy_ld == 4 && w.src[0].C >= 16) {            // FinalBlocks: thin = dY
+        swap = 0; thin = w.dy; thin_sn = w.dy_sn; TC = w.Cout; wide = w.src[0].p; wide_sn = w.src[0].sn; wide_ld = w.src[0].ld; WC = w.src[0].C;
+    } else if (w.src[0].C <= 4 && w.src[0].ld == 4 && w.Cout >= 8) {   // stem / FinalBlock dgrad side: thin = X
+        swap = 1; thin = w.src[0].p; thin_sn = w.src[0].sn; TC = w.src[0].C; wide = w.dy; wide_sn = w.dy_sn; wide_ld = w.dy_ld; WC = w.Cout;
+    } else return 0;
+    if ((thin_sn & 3) || (wide_sn & 3) || (wide_ld & 3)) return 0;
+    const int tx = cdiv(w.W, NTW), ty = cdiv(w.H, NTH), chunks = cdiv(WC, 16);
+    const long ntiles = (long)w.N * tx * ty;
+    long want = ntiles / 4, cap = 512 / chunks > 32 ? 512 / chunks : 32;
+    long gx = want < 32 ? (ntiles < 32 ? ntiles : 32) : (want < cap ? want : cap);
+    dim3 grid((unsigned)gx, chunks);
+    if (w.KS == 7) hipLaunchKernelGGL((k_wgrad_c4<7>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_c4<3>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
+    g_last_conv_kernel = CK_WGRAD_THIN;
+    return 1;
+}

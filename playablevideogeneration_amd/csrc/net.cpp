@@ -297,10 +297,16 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
             w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
             RUN(timed_conv_wgrad(w, px_taps * Lp->pd.Cin * Lp->pd.Cout));
-            if (Lp->dbias) RUN(pw_colsum(dzv, Lp->dbias, stream));
+            bool bias_done = !Lp->dbias;
+            for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
+                if (!(sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3)) continue;
+                RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, bias_done ? nullptr : Lp->dbias, stream));
+                bias_done = true;
+            }
+            if (!bias_done) RUN(pw_colsum(dzv, Lp->dbias, stream));
             for (int s = 0; s < nseg; s++) {
                 if (!sg[s].need_grad) continue;
-                if (sg[s].bcast && Lp->pd.KS == 3) { RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, stream)); continue; }
+                if (sg[s].bcast && Lp->pd.KS == 3) continue;
                 ConvArgs d{};
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;

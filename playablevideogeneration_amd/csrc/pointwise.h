@@ -37,5 +37,6 @@ int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st);
 int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st);
 int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st);
 struct PackDesc;
-int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S /* N*Cout*9 scratch */, float* g, long g_sn, hipStream_t st);
+int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S /* N*Cout*9 scratch */, float* g, long g_sn,
+                        float* dbias /* nullable: the conv's bias gradient falls out of the same sums */, hipStream_t st);
 int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st);

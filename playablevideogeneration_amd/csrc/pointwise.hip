@@ -582,12 +582,22 @@ __global__ __launch_bounds__(256) void k_bcast_grad(PackDesc d, int seg, const f
     if (threadIdx.x == 0) g[n * g_sn + c] += sh[0];
 }
 
+// the centre tap's sum is the plain per-sample channel sum: the conv's bias gradient comes for free (dbias[c] += sum_n S[n][c][1,1])
+__global__ void k_bias_from_sums(const float* S, int N, int C, float* dbias) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int n = 0; n < N; n++) s += S[((long)n * C + c) * 9 + 4];
+    dbias[c] += s;
+}
+
 }  // namespace
 
-int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S, float* g, long g_sn, hipStream_t st) {
+int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S, float* g, long g_sn, float* dbias, hipStream_t st) {
     if (d.KS != 3 || dz.C != d.Cout) return -1;
     hipLaunchKernelGGL(k_border_sums, dim3(dz.N, cdiv((dz.C + 3) / 4, 16)), dim3(256), 0, st, dz, S);
     hipLaunchKernelGGL(k_bcast_grad, dim3(dz.N, d.seg_C[seg]), dim3(256), 0, st, d, seg, (const float*)S, g, g_sn);
+    if (dbias) hipLaunchKernelGGL(k_bias_from_sums, dim3(cdiv(dz.C, 256)), dim3(256), 0, st, (const float*)S, dz.N, dz.C, dbias);
     return 0;
 }
 
