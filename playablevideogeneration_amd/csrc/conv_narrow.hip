@@ -297,12 +297,15 @@ __global__ __launch_bounds__(256) void k_conv_c4(ConvArgs a, int tiles_x, int ti
     const long ntiles = (long)a.N * tiles_x * tiles_y;
     const int og = blockIdx.y * NT * 16;                    // first output channel of this workgroup
 
-    float w[TAPS][NT];
-#pragma unroll
-    for (int t = 0; t < TAPS; t++)
-#pragma unroll
-        for (int m = 0; m < NT; m++) w[t][m] = a.wp[((long)t * a.Cout_pad + og + m * 16 + lp) * a.Ktot + g];
-
+    // A operands (weight column of lane (cout lp, channel g)) live in LDS as [tap][m][lane]: 64 consecutive floats per read, and only the
+    // accumulators stay in registers -> 4+ waves per SIMD hide the staging / epilogue behind other waves' MFMAs (holding all 49 x NT
+    // weights in registers forced 1 wave per SIMD)
+    __shared__ float ws[TAPS * NT * 64];
+    for (int i = tid; i < TAPS * NT * 64; i += 256) {
+        int l = i & 63, tm = i >> 6;
+        int m = tm % NT, t = tm / NT;
+        ws[i] = a.wp[((long)t * a.Cout_pad + og + m * 16 + (l & 15)) * a.Ktot + (l >> 4)];
+    }
     float4 pre[NL];
     auto gload = [&](long tile) {
         int n = (int)(tile / (tiles_x * tiles_y));
@@ -334,14 +337,19 @@ __global__ __launch_bounds__(256) void k_conv_c4(ConvArgs a, int tiles_x, int ti
         for (int nt = 0; nt < 4; nt++)
 #pragma unroll
             for (int m = 0; m < NT; m++) acc[nt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int dy = 0; dy < KS; dy++) {
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) {
-            const int dy = t / KS, dx = t - KS * dy;
+            for (int dx = 0; dx < KS; dx++) {
+                float wa[NT];
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const float b = xs[((2 * wave + (nt >> 1) + dy) * HW_ + 16 * (nt & 1) + lp + dx) * 4 + g];
+                for (int m = 0; m < NT; m++) wa[m] = ws[((dy * KS + dx) * NT + m) * 64 + lane];
 #pragma unroll
-                for (int m = 0; m < NT; m++) acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m], b, acc[nt][m], 0, 0, 0);
+                for (int nt = 0; nt < 4; nt++) {
+                    const float b = xs[((2 * wave + (nt >> 1) + dy) * HW_ + 16 * (nt & 1) + lp + dx) * 4 + g];
+#pragma unroll
+                    for (int m = 0; m < NT; m++) acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m], b, acc[nt][m], 0, 0, 0);
+                }
             }
         }
         {
@@ -383,13 +391,12 @@ int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st) {
     if (a.Cout_pad < mt * 16) return 0;
     const int tx = cdiv(a.W, NTW), ty = cdiv(a.H, NTH);
     const long ntiles = (long)a.N * tx * ty;
-    const int nt = a.KS == 7 ? (mt >= 2 ? 2 : 1) : (mt >= 8 ? 8 : (mt >= 4 ? 4 : (mt >= 2 ? 2 : 1)));
+    const int nt = a.KS == 7 ? (mt >= 2 ? 2 : 1) : (mt >= 4 ? 4 : (mt >= 2 ? 2 : 1));      // 16-channel tiles per workgroup (register budget)
     const int groups = cdiv(mt, nt);
     long gx = 1024 / groups; if (gx < 64) gx = 64; if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, groups);
 #define C4_LAUNCH(KS_, NT_) hipLaunchKernelGGL((k_conv_c4<KS_, NT_>), grid, dim3(256), 0, st, a, tx, ty)
     if (a.KS == 7) { if (nt == 2) C4_LAUNCH(7, 2); else C4_LAUNCH(7, 1); }
-    else if (nt == 8) C4_LAUNCH(3, 8);
     else if (nt == 4) C4_LAUNCH(3, 4);
     else if (nt == 2) C4_LAUNCH(3, 2);
     else C4_LAUNCH(3, 1);

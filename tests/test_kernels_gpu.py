@@ -40,7 +40,7 @@ def lib():
     dict(N=2, H=42, W=50, segs=[(32, 0)], Cout=24, KS=3, bias=True),           # narrow conv <2,2>, channel tail, bias; dgrad runs <2,2> as 24 -> 32
     dict(N=1, H=64, W=64, segs=[(20, 0)], Cout=16, KS=3),                      # narrow conv <2,1>; dgrad <1,2>; wgrad <2,1>
     dict(N=1, H=65, W=66, segs=[(16, 0)], Cout=29, KS=3),                      # narrow wgrad <1,2>, ragged tiles, channel tail
-    dict(N=1, H=16, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1),    # FinalBlock at 64x64 scale: dgrad = 3 -> 128 on k_conv_c4<3,8>
+    dict(N=1, H=16, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1),    # FinalBlock at 64x64 scale: dgrad = 3 -> 128 on k_conv_c4<3,4> x 2 groups
     dict(N=2, H=12, W=40, segs=[(3, 0)], Cout=16, KS=7),                       # 7x7 stem shape on k_conv_c4<7,1>
     dict(N=1, H=9, W=33, segs=[(3, 0)], Cout=40, KS=3, bias=True),             # k_conv_c4<3,2>, two output groups, channel tail
     dict(N=8, H=32, W=32, segs=[(128, 0), (9, 1), (128, 0)], Cout=512, KS=3, tol=1e-4),   # ConvLSTM gates at R's first resolution (persistent tiles)
