@@ -103,22 +103,30 @@ def main():
     ap.add_argument("--no-rollout", action="store_true")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    run(a, torch.device("cuda", local), lib=None, backend="nccl")
+
+
+def run(a, dev, lib=None, backend="nccl"):
+    """The benchmark proper.  `lib` / `backend` exist so that tests/test_cabi_and_dp.py can drive the multi-rank control flow
+    (hooks, collectives, profiled steps on every rank, max-over-ranks timing) on CPU with gloo and the simulator build."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    on_gpu = dev.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if not dist.is_initialized():
+            dist.init_process_group(backend, **({"device_id": dev} if on_gpu else {}))      # RCCL over xGMI
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     wl = configs.WORKLOADS[a.workload]
     B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
-    eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev)
+    eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev, lib=lib)
     log(f"engine created: workspace {eng.ws_bytes / 2**30:.1f} GiB, {eng.n_train} trainable floats")
     init_parameters(eng, seed=0)                            # identical replicas on every rank
     log("parameters initialised")
@@ -140,11 +148,11 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for i in range(a.warmup):
         losses = step()
-        torch.cuda.synchronize()
+        sync()
         log(f"warm-up step {i} done, loss {losses['total']:.5f}")
     fence()
     t0 = time.perf_counter()
@@ -171,6 +179,7 @@ def main():
             step()
         fam = eng.profile_end()
         name, (n, fl, ms, by) = max(fam.items(), key=lambda kv: kv[1][2])
+        ms = max(ms, 1e-9)                                   # (the simulator's events report 0)
         tot_ms = sum(v[2] for v in fam.values())
         traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
         try:
@@ -200,18 +209,19 @@ def main():
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
                           "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
                "loss": losses["total"], "roofline": roof}
-        if world == 1 and not a.no_rollout:
+        if world == 1 and not a.no_rollout and on_gpu:
             del eng
             torch.cuda.empty_cache()
             res["rollout"] = rollout_fps(dev)
             log(f"roll-out: {res['rollout']['value']:.1f} frames/s")
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and on_gpu:
             log("cpu baseline (oracle, 1 clip) ...")
             res["cpu_baseline"] = cpu_baseline(wl)
             log("cpu baseline done")
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 and on_gpu:
         dist.destroy_process_group()
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":

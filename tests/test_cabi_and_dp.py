@@ -88,3 +88,38 @@ def test_data_parallel_step_gloo_world2(tmp_path):
     assert not torch.equal(r0["local"], r1["local"])                                 # shards really differed
     # global-batch semantics of the small reductions: identical centroids and MI estimator state on every rank
     assert torch.equal(r0["centroids"], r1["centroids"]) and torch.equal(r0["mi_ema"], r1["mi_ema"])
+
+
+def _bench_worker(rank, world, port, out):
+    """bench.run() exactly as torchrun would drive it on N GPUs, but gloo + the simulator build + a tiny workload."""
+    import argparse
+    import json
+    import torch.distributed as dist
+    from tests.emu.loader import load_emu
+    from playablevideogeneration_amd import configs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    configs.WORKLOADS["tiny"] = dict(configs.BREAKOUT, batch=1, seq_len=3, height=32, width=32, gt_init=2, tau=0.8)
+    a = argparse.Namespace(gpus=world, steps=2, warmup=1, workload="tiny", no_cpu_baseline=True, profile_steps=1, no_rollout=True)
+    res = bench.run(a, torch.device("cpu"), lib=load_emu(), backend="gloo")
+    if rank == 0:
+        with open(os.path.join(out, "bench.json"), "w") as f:
+            json.dump(res, f)
+    else:
+        assert res is None
+    dist.barrier()
+
+
+def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
+    """The N>1 path of bench.py (all-reduce hook, gradient all-reduce, profiled step on every rank, barriers, max-over-ranks
+    timing, one JSON line from rank 0) cannot be launched on a multi-GPU node from here: run its control flow on CPU."""
+    import json
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = json.load(open(tmp_path / "bench.json"))
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["roofline"] is not None
+    for k in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
+        assert k in res
