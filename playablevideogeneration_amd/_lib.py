@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
-                ("dwp", C.c_void_p), ("slabs", C.c_int)]
+                ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long)]
 
 
 class PackDesc(C.Structure):

@@ -74,6 +74,12 @@ struct WgradArgs {
     int Ktot;
     float* dwp;         // packed gradient, same layout as wp
     int slabs;          // split of the pixel reduction across blocks (atomicAdd when > 1)
+    // time-batched launches: N = groups x group_n samples; sample n lives at p + (n / group_n) * gs + (n % group_n) * sn.  The weight
+    // gradient of a layer is accumulated over several BPTT time steps in ONE launch, which amortises the atomic flush of the
+    // persistent tile kernel (measured 21-27 % of a per-step launch).  group_n = 0: plain (N, sn) addressing.
+    int group_n;
+    long src_gs[CONV_MAX_SRC];
+    long dy_gs;
 };
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
@@ -83,8 +89,8 @@ int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
-int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st);
-int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st);
+int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
+int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA
 int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st);   // conv_narrow.hip: 1 = handled (3x3, 13..32 channels in, 5..32 out)
-int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st);   // N-tile (32/64/128) the launcher will use for this Cout
+int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // N-tile (32/64/128) the launcher will use for this Cout

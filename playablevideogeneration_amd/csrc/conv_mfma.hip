@@ -21,13 +21,13 @@ namespace {
 constexpr int BK = CONV_BK;
 constexpr int LDSK = BK + 4;
 
-struct SegRef { const float* p; long sn; int ld; int C; int bcast; int c0; };
+struct SegRef { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; };
 
 // locate channel `k` (index into the padded concatenation) -> segment + channel inside it
 __device__ __forceinline__ SegRef find_seg(const ConvSrc* src, int nsrc, int k) {
     int s = 0;
     while (s + 1 < nsrc && k >= src[s].Cpad) { k -= src[s].Cpad; s++; }
-    SegRef r; r.p = src[s].p; r.sn = src[s].sn; r.ld = src[s].ld; r.C = src[s].C; r.bcast = src[s].bcast; r.c0 = k;
+    SegRef r; r.p = src[s].p; r.sn = src[s].sn; r.ld = src[s].ld; r.C = src[s].C; r.bcast = src[s].bcast; r.c0 = k; r.idx = s;
     return r;
 }
 
@@ -513,18 +513,26 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_tile(WgradArgs a, int tiles_
         int rem = (int)(tile - (long)n * tiles_x * tiles_y);
         int ty = rem / tiles_x;
         int y0 = ty * WT_H, x0 = (rem - ty * tiles_x) * WT_W;
+        SegRef s2 = sg;
+        const float* dyb = a.dy;
+        if (a.group_n > 0) {                       // time-batched launch: (group, sample) addressing
+            int grp = n / a.group_n;
+            n -= grp * a.group_n;
+            s2.p += grp * a.src_gs[sg.idx];
+            dyb += grp * a.dy_gs;
+        }
 #pragma unroll
         for (int i = 0; i < WT_XLOADS; i++) {
             int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
             bool ok = kok && xhy[i] < WT_HH && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            rx[i] = load_src4(sg, xq & 3, ok, n, y, x, a.W);
+            rx[i] = load_src4(s2, xq & 3, ok, n, y, x, a.W);
         }
 #pragma unroll
         for (int i = 0; i < YLOADS; i++) {
             int pix = ypix0 + (256 / (OC / 4)) * i;
             int y = y0 + pix / WT_W, x = x0 + (pix & (WT_W - 1));
             ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y < a.H && x < a.W && yc < a.Cout) ry[i] = load4_masked(a.dy + (long)n * a.dy_sn + ((long)y * a.W + x) * a.dy_ld + yc, yc, a.Cout);
+            if (y < a.H && x < a.W && yc < a.Cout) ry[i] = load4_masked(dyb + (long)n * a.dy_sn + ((long)y * a.W + x) * a.dy_ld + yc, yc, a.Cout);
         }
     };
 
@@ -744,14 +752,30 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     return 0;
 }
 
+static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry);   // dry: only report the kernel (g_last_conv_kernel)
 int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
+    if (a0.group_n <= 0 || a0.N <= a0.group_n) return conv_wgrad_launch1(a0, st, false);
+    if (conv_wgrad_launch1(a0, st, true) == 0 && g_last_conv_kernel == CK_WGRAD_TILE) return conv_wgrad_launch1(a0, st, false);
+    // time-batched arguments on a kernel without (group, sample) addressing: one launch per group
+    for (int g = 0; g * a0.group_n < a0.N; g++) {
+        WgradArgs a = a0;
+        a.N = a0.group_n; a.group_n = 0;
+        for (int s = 0; s < a0.nsrc; s++) a.src[s].p = a0.src[s].p + g * a0.src_gs[s];
+        a.dy = a0.dy + g * a0.dy_gs;
+        int rc = conv_wgrad_launch1(a, st, false);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     WgradArgs a = a0;
     if (a.nsrc < 1 || a.nsrc > CONV_MAX_SRC) return -1;
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
-    if (conv_c4_wgrad_try(a, st) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
-    if (conv_thin_wgrad_try(a, st) == 1) return 0;
-    if (conv_narrow_wgrad_try(a, st) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
+    if (a.group_n > 0 && a.N <= a.group_n) a.group_n = 0;
+    if (conv_c4_wgrad_try(a, st, dry) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
+    if (conv_thin_wgrad_try(a, st, dry) == 1) return 0;
+    if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
     static const int narrow_tile = getenv("CADDY_WGRAD_NARROW_TILE") ? atoi(getenv("CADDY_WGRAD_NARROW_TILE")) : 1;   // A/B aid: K = 64 narrow layers -> tile-resident kernel
@@ -759,6 +783,8 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
         int tx = cdiv(a.W, STW), ty = cdiv(a.H, STH);
         long ntiles = (long)a.N * tx * ty;
         int grid = (int)(ntiles < 512 ? ntiles : 512);
+        g_last_conv_kernel = CK_WGRAD_SMALL;
+        if (dry) return 0;
         if (a.Ktot <= 32) hipLaunchKernelGGL((k_conv_wgrad_small<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_small<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         g_last_conv_kernel = CK_WGRAD_SMALL;
@@ -776,6 +802,8 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
         if (g < 1) g = 1;
         if (g > ntiles) g = ntiles;
         dim3 grid(kt, ot, (unsigned)g);
+        g_last_conv_kernel = CK_WGRAD_TILE;
+        if (dry) return 0;
         if (o32) hipLaunchKernelGGL((k_conv_wgrad_tile<1>), grid, dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_tile<2>), grid, dim3(256), 0, st, a, tx, ty);
         g_last_conv_kernel = CK_WGRAD_TILE;
@@ -793,6 +821,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
         if (a.slabs < 1) a.slabs = 1;
     }
     g_last_conv_kernel = bmo == 128 ? CK_WGRAD_128 : (bmo == 64 ? CK_WGRAD_64 : CK_WGRAD_32);
+    if (dry) return 0;
     dim3 grid(ktiles, otiles, taps * a.slabs);
     if (bmo == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
     else if (bmo == 64) hipLaunchKernelGGL((k_conv_wgrad<1, 2, 2, 2>), grid, dim3(256), 0, st, a);

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int tiles_x, 
 }
 }  // namespace
 
-int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st) {
+int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;
     if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3) return 0;
     if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
@@ -271,6 +271,8 @@ int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st) {
     const long ntiles = (long)a.N * tx * ty;
     long want = ntiles / 4;                                        // >= 4 tiles per workgroup amortise the flush
     const int grid = (int)(want < 64 ? (ntiles < 64 ? ntiles : 64) : (want < 512 ? want : 512));
+    g_last_conv_kernel = CK_WGRAD_SMALL;
+    if (dry) return 1;
     if (ci == 1 && co == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
     else if (ci == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
     else hipLaunchKernelGGL((k_wgrad_narrow<2, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256) void k_wgrad_c4(const float* thin, long thin_s
 }
 }  // namespace
 
-int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st) {
+int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st, bool dry) {
     static const bool off = getenv("CADDY_C4") && atoi(getenv("CADDY_C4")) == 0;
     if (off || w.nsrc != 1 || w.src[0].bcast || (w.KS != 3 && w.KS != 7)) return 0;
     const float *thin, *wide; long thin_sn, wide_sn; int TC, WC, wide_ld, swap;
@@ -522,6 +524,8 @@ int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st) {
     long want = ntiles / 4, cap = 512 / chunks > 32 ? 512 / chunks : 32;
     long gx = want < 32 ? (ntiles < 32 ? ntiles : 32) : (want < cap ? want : cap);
     dim3 grid((unsigned)gx, chunks);
+    g_last_conv_kernel = CK_WGRAD_THIN;
+    if (dry) return 1;
     if (w.KS == 7) hipLaunchKernelGGL((k_wgrad_c4<7>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
     else hipLaunchKernelGGL((k_wgrad_c4<3>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
     g_last_conv_kernel = CK_WGRAD_THIN;

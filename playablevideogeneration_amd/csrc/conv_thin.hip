@@ -282,7 +282,7 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st) {
+int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st, bool dry) {
     if (w.nsrc != 1 || w.src[0].bcast) return 0;
     ThinWgradArgs a{};
     a.N = w.N; a.H = w.H; a.W = w.W; a.KS = w.KS; a.Cout_pad = w.Cout_pad; a.Ktot = w.Ktot; a.dwp = w.dwp;
@@ -298,6 +298,8 @@ int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st) {
     long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
     long gx = 512 / a.chunks; if (gx < 32) gx = 32; if (gx > ntiles) gx = ntiles;
     dim3 grid((unsigned)gx, a.chunks);
+    g_last_conv_kernel = CK_WGRAD_THIN;
+    if (dry) return 1;
     if (a.TC <= 4) hipLaunchKernelGGL((k_wgrad_thin<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_thin<12>), grid, dim3(256), 0, st, a);
     g_last_conv_kernel = CK_WGRAD_THIN;

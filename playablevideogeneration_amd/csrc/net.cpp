@@ -257,6 +257,47 @@ hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everyth
     hipStreamWaitEvent(side, e, 0);
     return side;
 }
+void caddy_ctx::flush_wgrad(PendingW& p) {
+    if (p.count == 0) return;
+    WgradArgs w = p.first;
+    if (p.count > 1) {
+        w.group_n = p.first.N; w.N = p.first.N * p.count;
+        for (int s = 0; s < w.nsrc; s++) w.src_gs[s] = p.src_gs[s];
+        w.dy_gs = p.dy_gs;
+    }
+    double fl = p.flops;
+    p.count = 0; p.flops = 0;
+    RUN(timed_conv_wgrad(w, fl));
+}
+void caddy_ctx::flush_all_wgrad() { for (auto& kv : pending) flush_wgrad(kv.second); }
+void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
+    static const int chunk = getenv("CADDY_WGRAD_BATCH") ? atoi(getenv("CADDY_WGRAD_BATCH")) : 5;      // time steps per launch (1 = off)
+    if (chunk <= 1 || dry) { RUN(timed_conv_wgrad(w, flops)); return; }
+    PendingW* p = nullptr;
+    for (auto& kv : pending) if (kv.first == L) { p = &kv.second; break; }
+    if (!p) { pending.emplace_back(L, PendingW{}); p = &pending.back().second; }
+    if (p->count > 0) {
+        const WgradArgs& f = p->first;
+        bool ok = f.N == w.N && f.H == w.H && f.W == w.W && f.nsrc == w.nsrc && f.dy_sn == w.dy_sn && f.dy_ld == w.dy_ld && f.dwp == w.dwp;
+        long ds[CONV_MAX_SRC] = {0, 0, 0};
+        for (int s = 0; ok && s < w.nsrc; s++) {
+            ok = f.src[s].sn == w.src[s].sn && f.src[s].ld == w.src[s].ld && f.src[s].C == w.src[s].C && f.src[s].bcast == w.src[s].bcast;
+            ds[s] = w.src[s].p - p->last_src[s];
+        }
+        long dd = w.dy - p->last_dy;
+        if (ok && p->count > 1) {                 // the stride between consecutive time steps must stay the same
+            for (int s = 0; s < w.nsrc; s++) ok = ok && ds[s] == p->src_gs[s];
+            ok = ok && dd == p->dy_gs;
+        }
+        if (!ok) flush_wgrad(*p);
+        else if (p->count == 1) { for (int s = 0; s < w.nsrc; s++) p->src_gs[s] = ds[s]; p->dy_gs = dd; }
+    }
+    if (p->count == 0) p->first = w;
+    p->count++; p->flops += flops;
+    for (int s = 0; s < w.nsrc; s++) p->last_src[s] = w.src[s].p;
+    p->last_dy = w.dy;
+    if (p->count >= chunk) flush_wgrad(*p);
+}
 int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
     hipStream_t stream = wgrad_stream();
     if (!prof) return conv_wgrad_launch(a, stream);
@@ -296,7 +337,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             fill_srcs(w.src, sg, nseg);
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
             w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
-            RUN(timed_conv_wgrad(w, px_taps * Lp->pd.Cin * Lp->pd.Cout));
+            queue_wgrad(Lp, w, px_taps * Lp->pd.Cin * Lp->pd.Cout);
             bool bias_done = !Lp->dbias;
             for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
                 if (!(sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3)) continue;
@@ -724,6 +765,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     if (!dry) c->ck(loss_small(a, c->hook, c->hook_user, st), "loss_small");
     if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, st), "loss_finalize");
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
+    c->flush_all_wgrad();
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
         hipEvent_t e = c->sev();
         hipEventRecord(e, c->side);

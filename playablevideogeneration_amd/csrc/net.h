@@ -103,6 +103,13 @@ struct caddy_ctx {
     hipEvent_t sev() { if (sev_used == sev_pool.size()) { hipEvent_t e; hipEventCreate(&e); sev_pool.push_back(e); } return sev_pool[sev_used++]; }
     hipStream_t wgrad_stream();
     void ensure_side();
+    // weight gradients of a layer are queued over consecutive BPTT time steps and launched as ONE time-batched kernel (WgradArgs.group_n)
+    struct PendingW { WgradArgs first{}; int count = 0; long src_gs[CONV_MAX_SRC] = {0, 0, 0}; long dy_gs = 0; double flops = 0;
+                      const float* last_src[CONV_MAX_SRC] = {nullptr, nullptr, nullptr}; const float* last_dy = nullptr; };
+    std::vector<std::pair<ConvL*, PendingW>> pending;
+    void queue_wgrad(ConvL* L, const WgradArgs& w, double flops);
+    void flush_wgrad(PendingW& p);
+    void flush_all_wgrad();
 
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);

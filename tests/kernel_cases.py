@@ -138,6 +138,33 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     for i in range(nw):
         e = (gws_d[i].cpu() - ws_r[i].grad).abs().max().item()
         assert e < tol * max(1.0, ws_r[i].grad.abs().max().item()) * 4, ("wgrad", i, e)
+    # time-batched addressing (WgradArgs.group_n): the same batch laid out as 2 groups with a padded group stride must give the same dW
+    if N % 2 == 0:
+        gn = N // 2
+        wg = WgradArgs()
+        keep = []
+        for i, (c, bc) in enumerate(segs):
+            sn = a.src[i].sn
+            flat = bufs[i].reshape(-1)
+            gs = gn * sn + 64
+            buf = torch.full((2 * gs,), 5.0, device=dev)
+            buf[:gn * sn] = flat[:gn * sn]; buf[gs:gs + gn * sn] = flat[gn * sn:2 * gn * sn]
+            keep.append(buf)
+            wg.src[i] = ConvSrc(buf.data_ptr(), sn, a.src[i].ld, a.src[i].C, a.src[i].Cpad, a.src[i].bcast)
+            wg.src_gs[i] = gs
+        dsn = H * W * dz_d.shape[3]
+        dgs = gn * dsn + 128
+        dbuf = torch.full((2 * dgs,), 5.0, device=dev)
+        dflat = dz_d.reshape(-1)
+        dbuf[:gn * dsn] = dflat[:gn * dsn]; dbuf[dgs:dgs + gn * dsn] = dflat[gn * dsn:]
+        dwp2 = torch.zeros_like(wp)
+        wg.nsrc, wg.N, wg.H, wg.W, wg.KS = a.nsrc, N, H, W, KS
+        wg.dy, wg.dy_sn, wg.dy_ld, wg.dy_gs, wg.group_n = dbuf.data_ptr(), dsn, dz_d.shape[3], dgs, gn
+        wg.Cout, wg.Cout_pad, wg.Ktot, wg.dwp, wg.slabs = Cout, d.Cout_pad, d.Ktot, dwp2.data_ptr(), 0
+        assert lib.caddy_k_conv_wgrad(C.byref(wg), st) == 0
+        sync(dev)
+        e = (dwp2 - dwp).abs().max().item()
+        assert e < tol * max(1.0, dwp.abs().max().item()) * 4, ("grouped wgrad", e)
     # dgrad per segment = conv of dz with flipped/transposed weights
     for si, ((c, bc), x_r) in enumerate(zip(segs, xs_r)):
         bn = lib.caddy_k_conv_pick_bn(c)
