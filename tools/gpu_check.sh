@@ -3,6 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.txt 2>&1; tail -4 gpurun_out/pytest_gpu.txt
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.json
 rm -rf gpurun_out/prof_stats
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err
