@@ -272,7 +272,9 @@ void caddy_ctx::flush_wgrad(PendingW& p) {
 void caddy_ctx::flush_all_wgrad() { for (auto& kv : pending) flush_wgrad(kv.second); }
 void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
     static const int chunk = getenv("CADDY_WGRAD_BATCH") ? atoi(getenv("CADDY_WGRAD_BATCH")) : 5;      // time steps per launch (1 = off)
-    if (chunk <= 1 || dry) { RUN(timed_conv_wgrad(w, flops)); return; }
+    // only the per-time-step calls (N == batch) repeat; the B*T-frame passes of E / A run once or twice: launch those immediately so that
+    // they overlap with the rest of the backward instead of piling up behind flush_all_wgrad()
+    if (chunk <= 1 || dry || w.N != cfg.batch) { RUN(timed_conv_wgrad(w, flops)); return; }
     PendingW* p = nullptr;
     for (auto& kv : pending) if (kv.first == L) { p = &kv.second; break; }
     if (!p) { pending.emplace_back(L, PendingW{}); p = &pending.back().second; }
@@ -626,6 +628,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(B * (T - 1), H >> r, W >> r, 3);
     for (int t = 0; t < gt_init && t < T; t++) c->copy_op(tslice(c->x65_gt, B, T, t), tslice(c->rec_x65, B, T, t));
     T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
+    if (c->recording) c->tape.push_back([c]() { c->flush_all_wgrad(); });      // runs AFTER the time loop's backward: the queued chunks overlap with the A / E tail
     for (int t = 0; t < T - 1; t++) {
         T4 state = chan(tslice(c->rec_x65, B, T, t), 0, 64);
         T4 aux = tslice(aux_all, B, T - 1, t);
@@ -684,6 +687,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     // R on ground-truth states
     c->hidden = c->alloc(B * (T - 1), c->hs, c->ws, g.hidden);
     T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
+    if (c->recording) c->tape.push_back([c]() { c->flush_all_wgrad(); });
     for (int t = 0; t < T - 1; t++) {
         T4 hslot = tslice(c->hidden, B, T - 1, t);
         c->dynamics(chan(tslice(c->x65_gt, B, T, t), 0, 64), tslice(aux_all, B, T - 1, t), &hslot);
