@@ -110,3 +110,19 @@ def test_model_mirror_eval_samplers_and_interpolation_match_reference_goldens():
     for j, (a1, a2, al) in enumerate(H.INTERP):
         f, _ = m.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
         assert np.abs(f.cpu().numpy() - z["interp_frames"][j]).max() < 2e-4, j
+
+
+def test_device_prefetcher_passthrough_and_batch_objects():
+    from playablevideogeneration_amd.prefetch import DevicePrefetcher
+
+    class FakeBatch:                      # the reference's Batch interface (dataset/batching.py:67): to_tuple(cuda=True)
+        def __init__(self, i):
+            self.obs = torch.full((1, 2, 3, 4, 4), float(i))
+        def to_tuple(self, cuda=True):
+            assert cuda is False
+            return self.obs, torch.zeros(1, 2, dtype=torch.int32), None, None
+
+    got = list(DevicePrefetcher([FakeBatch(i) for i in range(3)], "cpu"))
+    assert len(got) == 3 and [g[0].flatten()[0].item() for g in got] == [0.0, 1.0, 2.0] and got[0][2] is None
+    got = list(DevicePrefetcher([(torch.ones(2), torch.zeros(2))], "cpu"))
+    assert len(got) == 1 and torch.equal(got[0][0], torch.ones(2))

@@ -79,3 +79,12 @@ def test_tennis_stacked_geometry_properties(lib):
 @pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])
 def test_eval_samplers(lib, name):
     M.sampler_case(name, lib, "cuda")
+
+
+def test_device_prefetcher_on_gpu(lib):
+    from playablevideogeneration_amd.prefetch import DevicePrefetcher
+    batches = [(torch.full((2, 3, 3, 8, 8), float(i)), torch.zeros(2, 3, dtype=torch.int32)) for i in range(4)]
+    got = list(DevicePrefetcher(batches, "cuda"))
+    torch.cuda.synchronize()
+    assert len(got) == 4 and all(g[0].is_cuda for g in got)
+    assert [g[0].flatten()[0].item() for g in got] == [0.0, 1.0, 2.0, 3.0]
