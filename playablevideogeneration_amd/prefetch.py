@@ -29,6 +29,7 @@ class DevicePrefetcher:
         self.pin = pin and self.on_gpu
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._pinned = {}          # (slot, index) -> pinned staging tensor, reused across batches of the same shape
+        self._slot_event = [None, None]   # last copy issued from each slot's pinned buffers (host waits on it before overwriting them)
 
     def _stage(self, batch, slot):
         items = _as_tuple(batch)
@@ -64,10 +65,13 @@ class DevicePrefetcher:
                 return None, None
             if not self.on_gpu:
                 return self._stage(b, 0), None
+            if self._slot_event[slot] is not None:
+                self._slot_event[slot].synchronize()       # the DMA that read this slot's pinned buffers two batches ago must be done
             with torch.cuda.stream(self.stream):
                 staged = self._stage(b, slot)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
+            self._slot_event[slot] = ev
             slot ^= 1
             return staged, ev
 
