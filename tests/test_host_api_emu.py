@@ -126,3 +126,24 @@ def test_device_prefetcher_passthrough_and_batch_objects():
     assert len(got) == 3 and [g[0].flatten()[0].item() for g in got] == [0.0, 1.0, 2.0] and got[0][2] is None
     got = list(DevicePrefetcher([(torch.ones(2), torch.zeros(2))], "cpu"))
     assert len(got) == 1 and torch.equal(got[0][0], torch.ones(2))
+
+
+def test_training_progress_on_fixed_batch():
+    """12 optimisation steps of the trainer mirror (schedules, fused losses + BPTT, fused Adam) on one fixed batch: reconstruction improves"""
+    from playablevideogeneration_amd import smooth_mi_trainer
+    cfg = _config()
+    cfg["logging"] = {"save_root_directory": "/tmp"}
+    m = _make_model(cfg)
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    m.load_state_dict(O.make_params(d, seed=7))
+    obs = torch.rand(2, 4, 3, 32, 32, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    m.train()
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    tr.global_step = 20000
+    rec = []
+    for i in range(12):
+        torch.manual_seed(100 + i)
+        _, info, _ = tr.compute_losses(m, (obs, None, None, None), 4)
+        tr.optimizer_step(m)
+        rec.append(info["avg_observations_rec_loss"])
+    assert rec[-1] < 0.9 * rec[0], rec
