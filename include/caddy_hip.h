@@ -78,6 +78,14 @@ size_t caddy_workspace_bytes(const caddy_config* cfg);
 caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes);
 void caddy_ctx_destroy(caddy_ctx* ctx);
 int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
+/* Bucketed gradient all-reduce (BASELINE north star: "all-reduce of gradients overlapped with the backward on a side HIP stream").
+ * All weights are shared over time, so nothing is final before BPTT reaches t = 0; what IS final once the time loop's backward
+ * is done are the dynamics_network (85 % of the bytes) and rendering_network ranges of the flat gradient buffer.  During
+ * caddy_loss_backward of a caddy_forward_full graph the hook is called once per range, `stream` being the HIP stream on which those
+ * gradients become valid (the caller enqueues its all-reduce behind it); the ranges must not be touched again until the caller has waited
+ * for its collective.  The remaining ranges are valid when caddy_loss_backward returns (on the ctx stream), as before. */
+typedef void (*caddy_grads_ready_hook)(float* grads, long offset, long count, void* stream, void* user);
+int caddy_set_grads_ready_hook(caddy_ctx* ctx, caddy_grads_ready_hook hook, void* user);
 /* Evaluation samplers (evaluation/action_sampler.py:14,63; evaluation/action_variation_sampler.py:14), consumed mid-forward exactly where
  * model/main_model/model.py:171-173,189-190 call them.  The hook runs stream-ordered on device pointers inside the workspace:
  *   stage 0 (if provides_samples):    write samples (n, K)    given log_probs (n, K)                      [n = batch * (seq_len - 1)]

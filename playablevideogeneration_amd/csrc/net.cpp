@@ -196,6 +196,18 @@ void build_layers(caddy_ctx* c) {
     }
     c->centroids = PP(c, "centroid_estimator.estimated_centroids");
     c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
+    {   // gradient buckets: trainable parameters of dynamics_network (R) and rendering_network (D) are contiguous ranges of the flat buffer
+        const char* pre[2] = {"dynamics_network.", "rendering_network."};
+        for (int b = 0; b < 2; b++) {
+            long lo = -1, hi = -1;
+            for (auto& e : c->table) if (e.kind == 0 && e.name.rfind(pre[b], 0) == 0) { if (lo < 0 || e.offset < lo) lo = e.offset; long en = e.offset + (e.numel + 3) / 4 * 4; if (en > hi) hi = en; }
+            c->bucket_lo[b] = lo < 0 ? 0 : lo; c->bucket_hi[b] = lo < 0 ? 0 : hi;
+        }
+        for (int i = 0; i < 3; i++) c->lstm[i].gates.early_bucket = true;
+        c->r_c0.early_bucket = c->r_c1.early_bucket = c->r_c2.early_bucket = true;
+        for (int i = 0; i < 3; i++) { c->d_up[i].early_bucket = true; c->d_final[i].early_bucket = true; }
+        for (int i = 0; i < 2; i++) { c->d_res[i].conv1.early_bucket = c->d_res[i].conv2.early_bucket = true; if (c->d_res[i].has_down) c->d_res[i].down.early_bucket = true; }
+    }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
@@ -596,11 +608,26 @@ void caddy_ctx::pack_all() {
     }
 }
 void caddy_ctx::unpack_all() {
-    for (ConvL* L : convs) RUN(unpack_wgrad(L->pd, L->dwp, stream));
-    for (int i = 0; i < 3; i++) {
+    for (ConvL* L : convs) { if (!L->early_done) RUN(unpack_wgrad(L->pd, L->dwp, stream)); L->early_done = false; }
+    for (int i = 0; i < 3 && !lstm_early_done; i++) {
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, stream));
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ic), lstm[i].ginit_c, 0, 0, stream));
     }
+    lstm_early_done = false;
+}
+// called from the tape right after the time loop's backward (forward_full graphs only): everything that contributes to R's and D's
+// parameter gradients has been enqueued.  Unpack those layers on the side stream (behind the queued wgrad chunks) and hand the two
+// ranges to the caller, who starts their all-reduce while A and E-on-ground-truth-frames are still in their backward.
+void caddy_ctx::early_gradient_buckets() {
+    if (!grads_hook || dry) return;
+    hipStream_t s2 = wgrad_stream();
+    for (ConvL* L : convs) if (L->early_bucket) { RUN(unpack_wgrad(L->pd, L->dwp, s2)); L->early_done = true; }
+    for (int i = 0; i < 3; i++) {
+        RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, s2));
+        RUN(pw_nhwc_to_nchw(gv(lstm[i].ic), lstm[i].ginit_c, 0, 0, s2));
+    }
+    lstm_early_done = true;
+    for (int b = 0; b < 2; b++) if (bucket_hi[b] > bucket_lo[b]) grads_hook(G, bucket_lo[b], bucket_hi[b] - bucket_lo[b], (void*)s2, grads_user);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -628,7 +655,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(B * (T - 1), H >> r, W >> r, 3);
     for (int t = 0; t < gt_init && t < T; t++) c->copy_op(tslice(c->x65_gt, B, T, t), tslice(c->rec_x65, B, T, t));
     T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
-    if (c->recording) c->tape.push_back([c]() { c->flush_all_wgrad(); });      // runs AFTER the time loop's backward: the queued chunks overlap with the A / E tail
+    if (c->recording) c->tape.push_back([c]() { c->flush_all_wgrad(); c->early_gradient_buckets(); });      // runs AFTER the time loop's backward: the queued chunks (and the R / D gradient buckets) overlap with the A / E tail
     for (int t = 0; t < T - 1; t++) {
         T4 state = chan(tslice(c->rec_x65, B, T, t), 0, 64);
         T4 aux = tslice(aux_all, B, T - 1, t);
@@ -938,6 +965,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }
 int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
     c->samplers = SamplerHooks{};
     if (hook && (provides_samples || provides_variations)) { c->samplers.fn = hook; c->samplers.user = user; c->samplers.action = provides_samples; c->samplers.variation = provides_variations; }

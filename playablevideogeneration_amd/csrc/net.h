@@ -33,6 +33,7 @@ struct Arena {
 struct ConvL {
     PackDesc pd{};
     float* wp = nullptr; float* dwp = nullptr;
+    bool early_bucket = false, early_done = false;   // member of the R / D gradient buckets that are final after the time loop's backward
     float* wpd[CONV_MAX_SRC] = {nullptr, nullptr, nullptr};
     int cd_pad[CONV_MAX_SRC] = {0, 0, 0};
     int kd = 0;
@@ -81,7 +82,12 @@ struct caddy_ctx {
     HeadState head1, head2;
     float *q_prob = nullptr;
     double* loss_acc = nullptr;
-    allreduce_hook_t hook = nullptr; void* hook_user = nullptr; int world = 1;   // data-parallel reductions of the K x K MI matrix / centroid sums
+    allreduce_hook_t hook = nullptr; void* hook_user = nullptr; int world = 1;
+    // bucketed gradient all-reduce: R's and D's parameter ranges are final once the time loop's backward is done; they are
+    // unpacked on the side stream and handed to the caller while A and E-on-ground-truth-frames still run their backward
+    void (*grads_hook)(float* grads, long offset, long count, void* stream, void* user) = nullptr; void* grads_user = nullptr;
+    long bucket_lo[2] = {0, 0}, bucket_hi[2] = {0, 0}; bool lstm_early_done = false;
+    void early_gradient_buckets();   // data-parallel reductions of the K x K MI matrix / centroid sums
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)

@@ -47,6 +47,7 @@ def _bind(lib):
     lib.caddy_ctx_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.caddy_ctx_destroy.argtypes = [C.c_void_p]
     lib.caddy_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_set_grads_ready_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_set_sampler_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.caddy_set_allreduce_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.caddy_forward_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -126,11 +127,17 @@ class Engine:
         self._check(self.lib.caddy_set_sampler_hook(self.ctx, C.cast(self._sampler_keepalive, C.c_void_p), None,
                                                     int(action_sampler is not None), int(action_variation_sampler is not None)))
 
-    def enable_data_parallel(self, process_group=None, force=False):
-        """Register the all-reduce hook (torch.distributed: RCCL on the MI355X, gloo in the CPU tests) for the small
-        global-batch reductions (centroid sums, MI joint matrix).  Gradients: call dist.all_reduce(engine.grads) yourself."""
+    def enable_data_parallel(self, process_group=None, force=False, overlap=True):
+        """Data parallelism over torch.distributed (RCCL on the MI355X, gloo in the CPU tests), one process per GPU.
+        Registers (a) the all-reduce hook of the small global-batch reductions (centroid sums, MI joint matrix) and (b) with
+        `overlap`, the gradient-bucket hook: the dynamics / rendering ranges of the flat gradient buffer (~91 % of the bytes) are
+        all-reduced asynchronously as soon as the time loop's backward is done, behind the side HIP stream, while the backward of A
+        and of E on the ground-truth frames is still running.  After `loss_backward` call `allreduce_gradients()`."""
         import torch.distributed as dist
         world = dist.get_world_size(process_group)
+        self._dp_group = process_group
+        self._dp_active = True
+        self._early = []                     # (offset, count, work) of the buckets already in flight
         if world == 1 and not force:
             return
         base = self._ws_raw.data_ptr()
@@ -141,6 +148,38 @@ class Engine:
 
         self._hook_keepalive = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)(_hook)
         self._check(self.lib.caddy_set_allreduce_hook(self.ctx, C.cast(self._hook_keepalive, C.c_void_p), None, world))
+        if not overlap:
+            return
+        on_gpu = self.device.type == "cuda"
+
+        def _ready(_grads, offset, count, stream, _user):
+            sl = self.grads[offset:offset + count]
+            if on_gpu and stream:               # enqueue behind the stream on which this range becomes valid (the driver's side stream)
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                    work = dist.all_reduce(sl, group=process_group, async_op=True)
+            else:
+                work = dist.all_reduce(sl, group=process_group, async_op=True)
+            self._early.append((offset, count, work))
+
+        self._ready_keepalive = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p)(_ready)
+        self._check(self.lib.caddy_set_grads_ready_hook(self.ctx, C.cast(self._ready_keepalive, C.c_void_p), None))
+
+    def allreduce_gradients(self):
+        """Sum the flat gradient buffer over the ranks: waits for the buckets started during `loss_backward` (the current stream
+        waits, not the host) and all-reduces what is left (E, A, state_to_hidden_state)."""
+        import torch.distributed as dist
+        group = getattr(self, "_dp_group", None)
+        early = sorted(getattr(self, "_early", []), key=lambda e: e[0])
+        pos = 0
+        for off, cnt, _ in early:
+            if off > pos:
+                dist.all_reduce(self.grads[pos:off], group=group)
+            pos = max(pos, off + cnt)
+        if pos < self.grads.numel():
+            dist.all_reduce(self.grads[pos:], group=group)
+        for _, _, work in early:
+            work.wait()
+        self._early = []
 
     def __del__(self):
         if getattr(self, "ctx", None):

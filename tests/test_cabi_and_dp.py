@@ -61,20 +61,28 @@ def _dp_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = O.Dims(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1, state_res=(2, 2))
     P = O.make_params(d, seed=3)
-    eng = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device="cpu", lib=load_emu())
-    eng.load_state_dict(P)
-    eng.enable_data_parallel()
     g = torch.Generator().manual_seed(100 + rank)
     obs = torch.rand(1, 3, 3, 16, 16, generator=g) * 2 - 1
     noise = {"eps_states": torch.randn(3, 1, generator=g), "eps_dirs": torch.randn(2, 1, generator=g), "gumbel_uniform": torch.rand(2, 3, generator=g),
              "eps_states_rec": torch.randn(3, 1, generator=g), "eps_dirs_rec": torch.randn(2, 1, generator=g)}
-    eng.forward_full(obs, 1, 0.8, noise, training=True, fetch_outputs=False)
-    eng.loss_backward(dict(O.DEFAULT_LOSS_WEIGHTS))
+
+    def fresh(overlap):
+        e = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device="cpu", lib=load_emu())
+        e.load_state_dict(P)
+        e.enable_data_parallel(overlap=overlap)
+        e.forward_full(obs, 1, 0.8, noise, training=True, fetch_outputs=False)
+        e.loss_backward(dict(O.DEFAULT_LOSS_WEIGHTS))
+        return e
+
+    eng = fresh(overlap=False)                      # plain path: one flat all-reduce after the backward
     local = eng.grads.clone()
-    dist.all_reduce(eng.grads)                      # the N>1 path of bench.py: one flat all-reduce, then Adam with 1/world
+    dist.all_reduce(eng.grads)
+    eng2 = fresh(overlap=True)                      # bench.py's path: R / D buckets start during loss_backward, the rest afterwards
+    assert len(eng2._early) == 2 and sum(c for _, c, _ in eng2._early) > 0.5 * eng2.grads.numel()
+    eng2.allreduce_gradients()
     eng.adam_step(1, grad_scale=1.0 / world)
-    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params[:eng.n_train].clone(), "centroids": eng.view("centroid_estimator.estimated_centroids").clone(),
-                "mi_ema": eng.mi_ema.clone()}, os.path.join(out, f"r{rank}.pt"))
+    torch.save({"local": local, "reduced": eng.grads.clone(), "reduced_overlap": eng2.grads.clone(), "params": eng.params[:eng.n_train].clone(),
+                "centroids": eng.view("centroid_estimator.estimated_centroids").clone(), "mi_ema": eng.mi_ema.clone()}, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -86,6 +94,9 @@ def test_data_parallel_step_gloo_world2(tmp_path):
     assert torch.allclose(r0["reduced"], r0["local"] + r1["local"], atol=1e-6)       # sum over ranks
     assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["params"], r1["params"])   # trainable replicas stay identical (BN running stats are rank-local, as under nn.DataParallel)
     assert not torch.equal(r0["local"], r1["local"])                                 # shards really differed
+    # bucketed, overlapped all-reduce == flat all-reduce (two separate runs: the simulator's float atomics are not order-deterministic)
+    assert torch.equal(r0["reduced_overlap"], r1["reduced_overlap"])
+    assert torch.allclose(r0["reduced_overlap"], r0["reduced"], atol=1e-4 * r0["reduced"].abs().max().item())
     # global-batch semantics of the small reductions: identical centroids and MI estimator state on every rank
     assert torch.equal(r0["centroids"], r1["centroids"]) and torch.equal(r0["mi_ema"], r1["mi_ema"])
 

@@ -57,8 +57,15 @@ def test_allreduce_hook_over_rccl_world1(lib):
             eng.enable_data_parallel(force=True)
             inner = eng._hook_keepalive
             calls.append(inner)
-        M.full_case("full_main_s1", lib, "cuda", prep=prep)
+        eng, _ = M.full_case("full_main_s1", lib, "cuda", prep=prep)
         assert calls
+        # gradient buckets: the R / D ranges were handed to RCCL during loss_backward (behind the driver's side stream); finish the rest
+        assert len(eng._early) == 2 and sum(c for _, c, _ in eng._early) > 0.5 * eng.grads.numel()
+        torch.cuda.synchronize()
+        before = eng.grads.clone()
+        eng.allreduce_gradients()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, before) and not eng._early          # world size 1: the sum over ranks is the identity
     finally:
         dist.destroy_process_group()
 
