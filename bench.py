@@ -131,7 +131,8 @@ def run(a, dev, lib=None, backend="nccl"):
     init_parameters(eng, seed=0)                            # identical replicas on every rank
     log("parameters initialised")
     if world > 1:
-        eng.enable_data_parallel()                          # global-batch centroid sums + MI joint matrix (tiny all-reduces)
+        # global-batch centroid sums + MI joint matrix (tiny all-reduces) and the bucketed gradient all-reduce (CADDY_DP_OVERLAP=0: one flat all-reduce)
+        eng.enable_data_parallel(overlap=os.environ.get("CADDY_DP_OVERLAP", "1") != "0")
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1     # each rank owns its shard of the global batch
     step_no = [0]
