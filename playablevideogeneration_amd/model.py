@@ -198,6 +198,9 @@ class Model(nn.Module):
         observations = batch_tuple[0]
         B, T = observations.shape[:2]
         eng = self.engine(B, T)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 \
+                and not getattr(eng, "_dp_active", False):
+            eng.enable_data_parallel()           # one process per GPU replaces nn.DataParallel (train.py:40): hooks for the global-batch reductions
         gt_actions = None
         if action_sampler is not None:                       # model.py:172-173: actions[:, :-1].reshape((-1,))
             gt_actions = batch_tuple[1][:, :-1].reshape((-1,)).to(self._flat.device)

@@ -103,8 +103,11 @@ class Trainer:
 
     def optimizer_step(self, model, world_size: int = 1):
         """optimizer.zero_grad(); loss.backward(); optimizer.step(); lr_scheduler.step() (trainer.py:584-587): backward already
-        ran inside compute_losses; gradients of all ranks are summed by the caller (one flat all-reduce) before this."""
+        ran inside compute_losses.  Under torch.distributed (one process per GPU) the gradients of all ranks are summed here."""
         eng = model.module.last_engine
+        if getattr(eng, "_dp_active", False) and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            eng.allreduce_gradients()            # R / D buckets were started during the backward; the rest + the wait happen here
+            world_size = torch.distributed.get_world_size()
         if self.adam_m is None:
             self.adam_m, self.adam_v = torch.zeros_like(eng.grads), torch.zeros_like(eng.grads)
         eng.adam_m, eng.adam_v = self.adam_m, self.adam_v

@@ -134,3 +134,36 @@ def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
     assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["roofline"] is not None
     for k in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
         assert k in res
+
+
+def _trainer_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from tests.test_host_api_emu import _config, _make_model
+    from playablevideogeneration_amd import smooth_mi_trainer
+    from oracle import caddy_oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = _config()
+    cfg["logging"] = {"save_root_directory": out}
+    m = _make_model(cfg)
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    m.load_state_dict(O.make_params(d, seed=7))
+    m.train()
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    tr.global_step = 20000
+    obs = torch.rand(1, 4, 3, 32, 32, generator=torch.Generator().manual_seed(10 + rank)) * 2 - 1      # each rank: its own shard
+    for i in range(2):
+        torch.manual_seed(50 + 7 * rank + i)
+        tr.compute_losses(m, (obs, None, None, None), 4)
+        tr.optimizer_step(m)
+    torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone()}, os.path.join(out, f"t{rank}.pt"))
+    dist.barrier()
+
+
+def test_trainer_mirror_is_data_parallel_aware_gloo_world2(tmp_path):
+    """Model / Trainer mirrors under torch.distributed: hooks registered on first use, gradients summed in optimizer_step -> identical replicas"""
+    import torch.multiprocessing as mp
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
+    assert torch.equal(t0["params"], t1["params"]) and torch.equal(t0["centroids"], t1["centroids"])
