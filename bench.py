@@ -204,7 +204,7 @@ def run(a, dev, lib=None, backend="nccl"):
     if world > 1:
         dist.barrier()
     if rank == 0:
-        res = {"metric": "training clips/sec (B x16x256x256)", "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        res = {"metric": f"training clips/sec (B x{T}x{H}x{W})", "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": a.workload, "model": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",

@@ -95,3 +95,9 @@ def test_device_prefetcher_on_gpu(lib):
     torch.cuda.synchronize()
     assert len(got) == 4 and all(g[0].is_cuda for g in got)
     assert [g[0].flatten()[0].item() for g in got] == [0.0, 1.0, 2.0, 3.0]
+
+
+def test_breakout160_smooth_mi_geometry_properties(lib):
+    """BASELINE.json configs[4] shard: Breakout hyper-parameters (reduced model) at 160x160, T=9, B=8, smooth MI loss"""
+    M.property_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=8, T=9, H=160, W=160, gt=6, tau=0.4))
+    torch.cuda.empty_cache()
