@@ -1,11 +1,13 @@
-// Thin-channel convolutions on the vector ALUs (fp32 FMA rate == fp32 MFMA rate on gfx950, so padding 3 channels to a
-// 32-wide MFMA tile would waste 10x):
+// Thin-channel convolutions on the vector ALUs (fp32 FMA rate == fp32 MFMA rate on gfx950, so padding 3 OUTPUT channels to a
+// 16/32-wide MFMA tile would waste 5-10x):
 //   k_conv_thin_out : OUT <= 12 channels (FinalBlock 3-channel heads, final_block.py:9-29; dgrad of E's stem)
-//   k_conv_thin_in  : IN  <= 12 channels (E's stem conv, representation_network.py:19; dgrad of the FinalBlocks)
-//   k_wgrad_thin    : weight gradients of both (one operand thin)
+//   k_conv_thin_in  : IN  <= 12 channels -- only the observation_stacking > 1 case (12-channel stem); the 3-channel (pitch 4) input
+//                     side runs on the 16x16x4 MFMA kernels of conv_narrow.hip (k_conv_c4 / k_wgrad_c4), tried first by the launchers
+//   k_wgrad_thin    : weight gradients with one thin operand, same remark
 // Same math, weight layout ([tap][OUT_pad][K]) and ConvArgs/WgradArgs contract as conv_mfma.hip, so the launchers there
 // dispatch here purely on shape.  Output tile = 8 x 32 pixels per workgroup; the input halo tile is staged through LDS
-// with a 20-float pixel pitch (conflict-free ds_read_b128); weights are wave-uniform -> scalar loads.
+// with a 20-float pixel pitch (conflict-free ds_read_b128); weights are wave-uniform: read with scalar loads from a compact
+// per-launch table (ConvArgs.aux) -- the packed layout's 2-4 KB tap stride maps every row to the same scalar-cache set.
 // These layers move ~1 byte per 10-50 FLOP: bound = HBM for the 3-channel side, VALU for the wide side.
 #include "common.h"
 
