@@ -300,3 +300,31 @@ def property_case(lib, dev, c, seed=3):
             if x.dim() >= 1 and x.shape[0] == B:
                 assert torch.equal(x[perm], y), ("eval-mode output is not batch-permutation equivariant", i)
     return eng
+
+
+def full_geometry_case(lib, dev, c):
+    """The BASELINE geometry against the fp32 oracle.  For t >= gt_init the model runs closed-loop (D -> E feedback, train-mode BatchNorm
+    over a batch of 2): round-off is amplified ~1.7x per step -- measured for the ORACLE ITSELF, fp32 vs fp64 at this geometry: 1.2e-5 max
+    error for t < 6 growing to 3.2e-3 (MSE 1.6e-7) at t = 14.  Two fp32 trajectories therefore differ by up to ~2x that, so the bounds are:
+    action indices bit-exact; teacher-forced steps and every open-loop output within 2e-4; closed-loop frames: per-(b,t) MSE < 1e-6
+    (north star: 1e-5) and max error < 2e-2; closed-loop states / hidden states within 1e-2 of their range."""
+    d, P, obs = H.inputs_of(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        oout = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    out = eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+    gt = c["gt"]
+    assert torch.equal(out[5].cpu(), oout[5]), "action indices"
+    f, fo = out[0].cpu(), oout[0]
+    assert (f[:, :gt] - fo[:, :gt]).abs().max().item() < 2e-4                         # teacher-forced reconstructions
+    mse = ((f - fo) ** 2).mean(dim=(2, 3, 4))
+    assert mse.max().item() < 1e-6 and (f - fo).abs().max().item() < 2e-2, (mse.max().item(), (f - fo).abs().max().item())
+    for i in (3, 6, 7, 8, 10, 11, 12, 13, 14):                                        # open-loop outputs: states, logits, samples, attention, A's distributions
+        _cmp(out[i], oout[i], 2e-4, f"open-loop output {i}")
+    for i in (2, 4, 9):                                                               # closed-loop: reconstructed states, hidden states, reconstructed attention
+        a, b = out[i].cpu(), oout[i]
+        assert (a - b).abs().max().item() < 1e-2 * max(1.0, b.abs().max().item()), (i, (a - b).abs().max().item())
+    return eng

@@ -101,3 +101,11 @@ def test_breakout160_smooth_mi_geometry_properties(lib):
     """BASELINE.json configs[4] shard: Breakout hyper-parameters (reduced model) at 160x160, T=9, B=8, smooth MI loss"""
     M.property_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=8, T=9, H=160, W=160, gt=6, tau=0.4))
     torch.cuda.empty_cache()
+
+
+def test_bair256_t16_full_geometry_vs_oracle(lib):
+    """BASELINE.json configs[1] geometry (BAIR-main 256x256, T=16, gt=6) at batch 2 against the CPU oracle itself (the batch-8 run is
+    covered by the size-independent properties); bounds and their justification: model_cases.full_geometry_case."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    M.full_geometry_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=16, H=256, W=256, gt=6, tau=0.4))
+    torch.cuda.empty_cache()
