@@ -109,3 +109,11 @@ def test_bair256_t16_full_geometry_vs_oracle(lib):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     M.full_geometry_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=16, H=256, W=256, gt=6, tau=0.4))
     torch.cuda.empty_cache()
+
+
+def test_bair256_t16_full_geometry_gradients_vs_fp64_oracle(lib):
+    """backward through the kernels that only large feature maps reach, BAIR 256x256, T=16, batch 1 (fp64 oracle: ~1 min of host time)"""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    res = M.full_geometry_grad_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=1, T=16, H=256, W=256, gt=6, tau=0.4))
+    print(res)
+    torch.cuda.empty_cache()
