@@ -269,6 +269,21 @@ class Engine:
         out[1] = multi
         return out
 
+    def output(self, idx: int, pretraining: bool = False) -> torch.Tensor:
+        """One entry of the output tuple (same indices as the reference's tuple) without materialising the others."""
+        B, T, K, Da, Ch, hs, ws = self.B, self.T, self.K, self.Da, self.Ch, self.H // 8, self.W // 8
+        n = T - 1
+        small = {10: (B, n, 2, Da), 11: (B, n, Da), 12: (B, T, 2, Da), 13: (B, T, Da), 14: (B, n, Da), 15: (B, n, K), 16: (B, n, 2, Da), 17: (B, n, Da),
+                 18: (B, T, 2, Da), 19: (B, T, Da)}
+        if pretraining:
+            small.update({2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, T, Ch, hs, ws), 5: (B, n, Ch, hs, ws), 7: (B, n, K), 8: (B, n, K)})
+        else:
+            small.update({2: (B, T, 64, hs, ws), 3: (B, T, 64, hs, ws), 4: (B, n, Ch, hs, ws), 6: (B, n, K), 7: (B, n, K)})
+        t = torch.empty(small[idx], dtype=torch.float32, device=self.device)
+        self._stream()
+        self._check(self.lib.caddy_get_output(self.ctx, idx, t.data_ptr()))
+        return t
+
     def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
                      samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
         obs, cn, si, vi = self._prepare(obs, noise, samples_in, variations_in)

@@ -56,6 +56,33 @@ class Trainer:
             w["hidden"] = lw["hidden_states_rec_lambda_pretraining"]
         return w
 
+    # ---- logging-only diagnostics of the reference's loss_info (trainer.py:475-491, :358-375), from the small outputs of the forward ----
+    def diagnostics(self, model, eng, pretraining=False) -> Dict[str, float]:
+        if not self.config["training"].get("loss_diagnostics", True):
+            return {}
+        o = (lambda i: eng.output(i, pretraining))
+        s = 1 if pretraining else 0                       # forward_pretraining's tuple has one extra entry before the logits / samples
+        with torch.no_grad():
+            samples = o(7 + s)
+
+            def prob_entropy(p):                           # EntropyProbabilityLoss (losses.py:359-376): no epsilon, as in the reference
+                p = p.reshape(-1, p.shape[-1])
+                return (-(p * torch.log(p)).sum() / p.shape[0]).item()
+            ddist, rdist, var = o(10), o(16), o(14)
+            cen = model.module.centroid_estimator.get_estimated_centroids()
+            kc = cen.shape[0]
+            cdist = (cen.unsqueeze(0) - cen.unsqueeze(1)).pow(2).sum(2).sqrt().sum() / (kc * (kc - 1))
+            rv = rdist[:, :, 1].reshape(-1, rdist.shape[-1]); rm = rdist[:, :, 0].reshape(-1, rdist.shape[-1])
+            return {"samples_entropy": prob_entropy(samples), "action_distribution_entropy": prob_entropy(samples.mean(dim=(0, 1)).unsqueeze(0)),
+                    "states_magnitude": o(3).abs().mean().item(), "hidden_states_magnitude": o(5 if pretraining else 4).abs().mean().item(),
+                    "action_directions_mean_magnitude": ddist[:, :, 0].abs().mean().item(), "action_directions_variance_magnitude": ddist[:, :, 1].abs().mean().item(),
+                    "reconstructed_action_directions_mean_magnitude": rdist[:, :, 0].abs().mean().item(),
+                    "reconstructed_action_directions_variance_magnitude": rdist[:, :, 1].abs().mean().item(),
+                    "action_directions_reconstruction_error": (rdist[:, :, 0] - ddist[:, :, 0]).pow(2).mean().item(),
+                    "reconstructed_action_directions_kl_loss": (-0.5 * (1 + torch.log(rv) - rm.pow(2) - rv).sum(1)).mean().item(),   # losses.py:146-169
+                    "centroids_mean_magnitude": cen.abs().mean().item(), "average_centroids_distance": cdist.item(),
+                    "average_action_variations_norm_l2": var.pow(2).sum(-1).sqrt().mean().item(), "action_variations_mean": var.mean().item()}
+
     # ---- Trainer.compute_losses (trainer.py:400-550): forward + fused losses + backward ----
     def compute_losses(self, model, batch, observations_count: int):
         gt = self.get_ground_truth_observations_count()
@@ -78,6 +105,7 @@ class Trainer:
                      "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
                      "observations_rec_loss_r0": li["l1_r0"], "observations_rec_loss_r1": li["l1_r1"], "observations_rec_loss_r2": li["l1_r2"],
                      "ground_truth_observations": gt, "gumbel_temperature": tau, "observations_count": observations_count}
+        loss_info.update(self.diagnostics(model, eng))
         return li["total"], loss_info, {}
 
     # ---- Trainer.compute_losses_pretraining (trainer.py:241-398) ----
@@ -99,6 +127,7 @@ class Trainer:
                      "avg_observations_rec_loss": li["rec"], "states_rec_loss": li["states"], "hidden_states_rec_loss": li["hidden"], "entropy_loss": li["entropy"],
                      "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
                      "gumbel_temperature": tau, "observations_count": observations_count}
+        loss_info.update(self.diagnostics(model, eng, pretraining=True))
         return li["total"], loss_info, {}
 
     def optimizer_step(self, model, world_size: int = 1):
