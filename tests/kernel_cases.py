@@ -428,3 +428,27 @@ def adam_case(lib, dev, n=1000, seed=0):
                                 C.c_float(1e-6), step, C.c_float(1.0), stream(dev)) == 0
     sync(dev)
     assert (pd.cpu() - pr.detach()).abs().max() < 1e-6
+
+
+def conv_fuzz(lib, dev, n, seed):
+    import random
+    rng = random.Random(seed)
+    for i in range(n):
+        ks = rng.choice([1, 3, 3, 3, 7])
+        nseg = 1 if ks == 7 else rng.choice([1, 1, 2, 3])
+        segs = []
+        for s in range(nseg):
+            c = rng.choice([1, 3, 4, 5, 12, 16, 17, 31, 32, 33, 48, 64, 65, 70])
+            bc = 1 if (nseg > 1 and s == 1 and ks == 3) else 0
+            segs.append((rng.choice([1, 5, 9, 12]) if bc else c, bc))             # broadcast inputs are <= 16-wide vectors (AUX_LD)
+        if ks == 7:
+            segs = [(rng.choice([3, 16, 32]), 0)]
+        kw = dict(N=rng.choice([1, 2, 2, 4]), H=rng.choice([1, 2, 3, 5, 8, 9, 13, 16, 33]), W=rng.choice([1, 4, 7, 8, 10, 17, 32, 40]), segs=segs,
+                  Cout=rng.choice([1, 3, 4, 9, 16, 24, 32, 33, 64, 72, 128, 130]) if ks != 7 else rng.choice([3, 16, 32]), KS=ks,
+                  bias=rng.random() < 0.3, act=1 if rng.random() < 0.15 else 0, nw=4 if (nseg == 3 and rng.random() < 0.5) else 1)
+        if kw["nw"] == 4 and kw["Cout"] % 4:
+            kw["Cout"] = 64
+        try:
+            conv_case(lib, dev, **kw)
+        except AssertionError as e:
+            raise AssertionError((i, kw, e))

@@ -76,3 +76,10 @@ def test_misc_pointwise():
 
 def test_adam():
     K.adam_case(load_emu(), "cpu")
+
+
+def test_conv_random_shapes():
+    """seeded random geometry sweep over the conv launchers (forward, dgrad, wgrad, time-batched wgrad): tile overhangs, channel tails,
+    1-pixel maps, every dispatch boundary between the MFMA / narrow / 3-channel / thin kernels (CONV_FUZZ_CASES=n for longer hunts)"""
+    import os
+    K.conv_fuzz(load_emu(), "cpu", int(os.environ.get("CONV_FUZZ_CASES", "100")), seed=1234)

@@ -49,6 +49,11 @@ def test_conv(lib, kw):
     K.conv_case(lib, "cuda", **kw)
 
 
+def test_conv_random_shapes(lib):
+    """the simulator's seeded geometry sweep, on the hardware (real MFMA fragment maps, atomics, LDS)"""
+    K.conv_fuzz(lib, "cuda", 150, seed=4321)
+
+
 def test_thin_conv_without_aux_scratch(lib):
     K.conv_case(lib, "cuda", N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3, use_aux=False)
     K.conv_case(lib, "cuda", N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, use_aux=False)
