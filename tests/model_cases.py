@@ -359,3 +359,20 @@ def full_geometry_grad_case(lib, dev, c):
     for k, (hip, orc) in res.items():
         assert hip <= max(2 * orc, 0.15), (k, hip, orc, res)
     return res
+
+
+def random_config_sweep(lib, dev, n, seed):
+    """seeded random model configurations (variant, K, Da, observation_stacking 1-4, batch, T, geometry, gt, soft/hard Gumbel) vs the oracle:
+    outputs, action indices, frame MSE, loss.  Batch >= 2 and maps >= 4x4 (BatchNorm over 2 elements is not a meaningful comparison)."""
+    import random
+    rng = random.Random(seed)
+    for i in range(n):
+        variant = rng.choice(["main", "reduced"])
+        T = rng.choice([2, 3, 4, 5])
+        c = dict(variant=variant, K=rng.choice([2, 3, 7]), Da=rng.choice([1, 2, 5]), Ch=128 if variant == "main" else 64, S=rng.choice([1, 2, 3, 4]),
+                 B=rng.choice([2, 3]), T=T, H=rng.choice([32, 48]), W=rng.choice([32, 48, 64]), gt=rng.randint(1, max(1, T - 1)),
+                 tau=rng.choice([0.4, 0.9]), hard=rng.random() < 0.3)
+        try:
+            oracle_case(lib, dev, c)
+        except AssertionError as e:
+            raise AssertionError((i, c, e))

@@ -43,3 +43,8 @@ def test_size_independent_properties_small():
 @pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])
 def test_eval_samplers(name):
     M.sampler_case(name, load_emu(), "cpu")
+
+
+def test_random_model_configurations():
+    """two seeded random configurations (observation_stacking 2 / 3, odd batch, ... are not covered by the reference goldens); the GPU suite runs 10"""
+    M.random_config_sweep(load_emu(), "cpu", 2, seed=21)

@@ -117,3 +117,7 @@ def test_bair256_t16_full_geometry_gradients_vs_fp64_oracle(lib):
     res = M.full_geometry_grad_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=1, T=16, H=256, W=256, gt=6, tau=0.4))
     print(res)
     torch.cuda.empty_cache()
+
+
+def test_random_model_configurations(lib):
+    M.random_config_sweep(lib, "cuda", 10, seed=21)
