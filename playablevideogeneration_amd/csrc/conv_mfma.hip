@@ -319,13 +319,15 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 }
 
 // fixed-order sum of the split-K slabs of a forward conv: out[p][c] = sum_z slab_z[p][c]   (deterministic, unlike atomics)
-__global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld) {
+__global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act) {
     const int C4 = ldc >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < P * C4; i += (long)gridDim.x * 256) {
         long p = i / C4; int c = (int)(i - p * C4) * 4;
         const float* q = scr + p * ldc + c;
         float4 v = *reinterpret_cast<const float4*>(q);
         for (int z = 1; z < splits; z++) { float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (bias) { v.x += bias[c < C ? c : 0]; v.y += bias[c + 1 < C ? c + 1 : 0]; v.z += bias[c + 2 < C ? c + 2 : 0]; v.w += bias[c + 3 < C ? c + 3 : 0]; }
+        if (act == 1) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
         long n = p / HW;
         float* o = out + n * out_sn + (p - n * HW) * (long)out_ld + c;
         if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
@@ -708,15 +710,15 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
     // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
     a.split_stride = 0;
-    float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld;
+    float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
-    if (!a.accumulate && a.act == 0 && a.bias == nullptr && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks < 256) {
+    if (!a.accumulate && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks < 256) {   // (bias / tanh are applied by the reduce)
         int want = (int)((384 + blocks - 1) / blocks);
         int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
         int ldc = round_up(a.Cout, 4);
         if (sk > 1 && (long)sk * P * ldc <= a.split_cap) {
             a.splitk = sk; a.split_stride = P * ldc;
-            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc;
+            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0;
         }
     }
     static const int force_prec = getenv("CADDY_PRECISION") ? atoi(getenv("CADDY_PRECISION")) : -1;   // tuning / A-B aid
@@ -747,7 +749,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         int ldc = a.out_ld;
         long items = P * (ldc >> 2);
         hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st,
-                           (const float*)a.split_scratch, a.split_stride, a.splitk, ldc, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld);
+                           (const float*)a.split_scratch, a.split_stride, a.splitk, ldc, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act);
     }
     return 0;
 }

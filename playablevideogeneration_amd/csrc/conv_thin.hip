@@ -252,6 +252,9 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     dim3 grid(cdiv(a.W, TW), cdiv(a.H, TH), a.N);
     // OUT<=4: FinalBlock heads; OUT<=12 only with a narrow input (dgrad of the stem).  The 9-channel broadcast-input dgrad of R
     // (IN up to 1024 channels on 16x16 maps) stays on the MFMA kernel: one thread per pixel would leave the chip empty.
+    // tiny grids (batch-1 roll-out: 16-64 workgroups, each walking all channel chunks serially) are latency-bound here: the MFMA kernel with
+    // its deterministic split-K (bias / tanh applied by the reduce) fills the chip instead
+    if (a.Cout <= 4 && a.KS == 3 && !a.accumulate && a.split_scratch && (long)grid.x * grid.y * grid.z <= 64 && a.src[0].C >= 32) return 0;
     if ((a.Cout <= 4 && a.src[0].C >= 16) || (a.Cout <= 12 && a.src[0].C >= 16 && a.src[0].C <= 32)) {
         const int CO = a.Cout <= 3 ? 3 : (a.Cout <= 4 ? 4 : 12), chunks = cdiv(a.src[0].C, CK);
         const int n4 = chunks * a.KS * a.KS * 4 * CO;
