@@ -712,8 +712,8 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
-    if (!a.accumulate && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks < 256) {   // (bias / tanh are applied by the reduce)
-        int want = (int)((384 + blocks - 1) / blocks);
+    if (!a.accumulate && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
+        int want = (int)((512 + blocks - 1) / blocks);
         int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
         int ldc = round_up(a.Cout, 4);
         if (sk > 1 && (long)sk * P * ldc <= a.split_cap) {
