@@ -1,0 +1,149 @@
+"""Headless counterpart of evaluation/evaluator.py (`config["evaluation"]["evaluator"] = "playablevideogeneration_amd.evaluator"`, train.py:56):
+the same quantities -- per-position observation / state losses of the gt_init = 1 roll-out, action entropies, direction KL, mutual
+information, Hungarian action accuracy and the ground-truth -> model action mapping -- computed from the HIP forward pass, without the
+reference's wandb / image-grid / plotting side effects (and without `sklearn.utils.linear_assignment_`, removed from sklearn >= 0.23:
+`scipy.optimize.linear_sum_assignment` gives the same optimum).  The VGG perceptual sequence loss is omitted (no pretrained weights).
+
+    ev = evaluator(config, dataset, logger, action_sampler=None, logger_prefix="test")
+    log_data = ev.evaluate(model, step)              # dict with the reference's keys: "<prefix>/observations_loss/pos_3", ".../actions_accuracy", ...
+    ev.get_best_action_mappings()                    # {ground-truth action: model action}, feeds GroundTruthActionSampler
+"""
+import sys
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _batch_tuple(batch):
+    return tuple(batch.to_tuple()) if hasattr(batch, "to_tuple") else tuple(batch)
+
+
+def sequence_loss(gt: torch.Tensor, rec: torch.Tensor, loss) -> Tuple[float, List[float]]:
+    """SequenceLossEvaluator (training/losses.py:652-713): loss per sequence position; a reconstruction that is one element shorter is
+    aligned to the right and position 0 counts as 0 (and is excluded from the average)."""
+    T, Tr = gt.shape[1], rec.shape[1]
+    if Tr not in (T, T - 1):
+        raise Exception(f"Received an input batch with sequence length {T}, but got a reconstructed batch of {Tr}")
+    off = T - Tr
+    terms = [0.0] * off + [float(loss(gt[:, t:t + 1], rec[:, t - off:t - off + 1])) for t in range(off, T)]
+    return float(np.mean(terms[off:])), terms
+
+
+def observations_l1(gt: torch.Tensor, rec: torch.Tensor) -> torch.Tensor:
+    """ObservationsLoss (losses.py:61-118) on one position: L1 between the (resized) first 3 channels of the observation and the frame"""
+    g = gt[:, :, :3].flatten(0, 1)
+    r = rec.flatten(0, 1)
+    if g.shape[-2:] != r.shape[-2:]:
+        g = F.interpolate(g, r.shape[-2:], mode="bilinear", align_corners=False)
+    return (g - r).abs().mean()
+
+
+def hungarian_match(predictions: torch.Tensor, ground_truth: torch.Tensor, k: int) -> List[Tuple[int, int]]:
+    """evaluation/evaluator.py:466-494: maximise the number of agreeing samples over one-to-one maps model action -> gt action"""
+    from scipy.optimize import linear_sum_assignment
+    votes = np.zeros((k, k))
+    p, g = predictions.cpu().numpy().astype(np.int64), ground_truth.cpu().numpy().astype(np.int64)
+    for c1 in range(k):
+        for c2 in range(k):
+            votes[c1, c2] = int(((p == c1) & (g == c2)).sum())
+    rows, cols = linear_sum_assignment(len(p) - votes)
+    return [(int(r), int(c)) for r, c in zip(rows, cols)]
+
+
+class Evaluator:
+    def __init__(self, config, dataset, logger, action_sampler=None, logger_prefix="test"):
+        self.config, self.dataset, self.logger, self.logger_prefix = config, dataset, logger, logger_prefix
+        ev = config.get("evaluation", {})
+        self.batch_size = ev.get("batching", {}).get("batch_size", 8)
+        self.max_evaluation_batches = ev.get("max_evaluation_batches", None)
+        self.action_sampler = action_sampler
+        self.best_action_mappings: Optional[Dict[int, int]] = None
+
+    def set_action_sampler(self, action_sampler):
+        self.action_sampler = action_sampler
+
+    def get_best_action_mappings(self) -> Dict[int, int]:
+        if self.best_action_mappings is None:
+            raise Exception("The action mapping can be computed only after a call to evaluate")
+        return self.best_action_mappings
+
+    def _batches(self):
+        ds = self.dataset
+        if hasattr(ds, "__getitem__") and hasattr(ds, "__len__") and not isinstance(ds, (list, tuple)):
+            from torch.utils.data import DataLoader
+            collate = getattr(ds, "collate_fn", None)
+            return DataLoader(ds, batch_size=self.batch_size, shuffle=False, collate_fn=collate)
+        return ds                                              # any iterable of Batch objects / batch tuples
+
+    def compute_actions_accuracy(self, predictions: torch.Tensor, ground_truth: torch.Tensor):
+        k = self.config["data"]["actions_count"]
+        match = hungarian_match(predictions, ground_truth, k)
+        reordered = torch.zeros_like(predictions)
+        for pred_i, target_i in match:
+            reordered[predictions == pred_i] = target_i
+        acc = (reordered == ground_truth.to(reordered.dtype)).sum().item() / max(1, predictions.numel())
+        return acc, {gt_i: int(model_i) for model_i, gt_i in match}
+
+    def evaluate(self, model, step: int) -> Dict[str, float]:
+        sums: Dict[str, float] = {}
+        counts: Dict[str, int] = {}
+
+        def add(d):
+            for k_, v in d.items():
+                sums[k_] = sums.get(k_, 0.0) + float(v)
+                counts[k_] = counts.get(k_, 0) + 1
+
+        def prob_entropy(p):
+            p = p.reshape(-1, p.shape[-1])
+            return (-(p * torch.log(p)).sum() / p.shape[0]).item()
+
+        was_training = model.training
+        model.eval()
+        pred, gts = [], []
+        with torch.no_grad():
+            for i, batch in enumerate(self._batches()):
+                if self.max_evaluation_batches is not None and i >= self.max_evaluation_batches:
+                    break
+                bt = _batch_tuple(batch)
+                r = model(bt, ground_truth_observations_init=1, action_sampler=self.action_sampler)
+                frames, states, rec_states, selected, logits, samples = r[0], r[3], r[2], r[5], r[6], r[7]
+                ddist, r_logits = r[10], r[15]
+                obs = bt[0].to(frames.device)
+                avg, pos = sequence_loss(obs, frames, observations_l1)
+                add({"observations_loss/avg": avg, **{f"observations_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                avg, pos = sequence_loss(states, rec_states, lambda a, b: F.mse_loss(a, b))
+                add({"states_loss/avg": avg, **{f"states_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                fl = logits.reshape(-1, logits.shape[-1])
+                pd = ddist.reshape(-1, 2, ddist.shape[-1])
+                p1, p2 = torch.softmax(fl, -1), torch.softmax(r_logits.reshape(fl.shape), -1)
+                joint = (p1.unsqueeze(2) * p2.unsqueeze(1)).sum(0)            # MutualInformationLoss (losses.py:238-302)
+                joint = (joint + joint.t()) / 2
+                joint = joint / joint.sum()
+                eps = sys.float_info.epsilon
+                pi, pj = joint.sum(1, keepdim=True).expand_as(joint), joint.sum(0, keepdim=True).expand_as(joint)   # marginals before clamping, as in the reference
+                joint, pi, pj = torch.clamp(joint, min=eps), torch.clamp(pi, min=eps), torch.clamp(pj, min=eps)
+                add({"entropy": (-(torch.softmax(fl, 1) * torch.log_softmax(fl, 1)).sum() / fl.shape[0]).item(),
+                     "samples_entropy": prob_entropy(samples), "action_distribution_entropy": prob_entropy(samples.mean(dim=(0, 1)).unsqueeze(0)),
+                     "action_directions_kl_loss": (-0.5 * (1 + torch.log(pd[:, 1]) - pd[:, 0].pow(2) - pd[:, 1]).sum(1)).mean().item(),
+                     "action_mutual_information_loss": (joint * (torch.log(pi) + torch.log(pj) - torch.log(joint))).sum().item()})
+                pred.append(selected.reshape(-1).cpu())
+                if bt[1] is not None:
+                    gts.append(bt[1][:, :-1].reshape(-1).cpu())
+        model.train(was_training)
+        log_data = {"step": step}
+        if gts:
+            acc, mapping = self.compute_actions_accuracy(torch.cat(pred), torch.cat(gts))
+            self.best_action_mappings = mapping
+            log_data[f"{self.logger_prefix}/actions_accuracy"] = acc
+        for k_ in sums:
+            log_data[f"{self.logger_prefix}/{k_}"] = sums[k_] / counts[k_]
+        if self.logger is not None:
+            self.logger.print(f"== Evaluation [{step}][{self.logger_prefix}] == " + " ".join(
+                f"{k_.split('/', 1)[1]}:{v:.3f}" for k_, v in log_data.items() if k_.endswith("/avg") or k_.endswith("accuracy")))
+        return log_data
+
+
+def evaluator(config, dataset, logger, action_sampler=None, logger_prefix="test"):
+    return Evaluator(config, dataset, logger, action_sampler, logger_prefix)
