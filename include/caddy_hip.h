@@ -138,6 +138,8 @@ int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, co
  *             k_conv_thin_in, k_conv_wgrad<2,2,2,2>, k_conv_wgrad<1,2,2,2>, k_conv_wgrad<1,1,1,4>, k_conv_wgrad_small, k_wgrad_thin,
  *             k_conv_wgrad_tile, k_conv_narrow}
  *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
+/* test aid: NaN-fill the not-zero-filled (first-touch) part of the gradient arena before every backward pass */
+int caddy_debug_set_poison(caddy_ctx* ctx, int on);
 int caddy_profile_begin(caddy_ctx* ctx);
 int caddy_profile_end(caddy_ctx* ctx, double* out52);
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each

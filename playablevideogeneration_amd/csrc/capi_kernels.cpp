@@ -17,7 +17,7 @@ int caddy_k_adam(float* p, const float* g, float* m, float* v, long n, float lr,
 }
 int caddy_k_copy(const TV* a, const TV* b, int acc, void* s) { return pw_copy(*a, *b, acc, ST(s)); }
 int caddy_k_pool2(const TV* in, const TV* out, void* s) { return pw_pool2(*in, *out, ST(s)); }
-int caddy_k_pool2_bwd(const TV* dout, const TV* din, void* s) { return pw_pool2_bwd(*dout, *din, ST(s)); }
+int caddy_k_pool2_bwd(const TV* dout, const TV* din, void* s) { return pw_pool2_bwd(*dout, *din, 0, ST(s)); }
 int caddy_k_up2(const TV* in, const TV* out, void* s) { return pw_up2(*in, *out, ST(s)); }
 int caddy_k_up2_bwd(const TV* dout, const TV* din, void* s) { return pw_up2_bwd(*dout, *din, ST(s)); }
 int caddy_k_stats(const TV* x, double* sums, void* s) { return pw_stats(*x, sums, nullptr, ST(s)); }
@@ -36,7 +36,7 @@ int caddy_k_bn_small_fwd(const TV* x, const float* gamma, const float* beta, flo
 }
 int caddy_k_bn_small_bwd(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const TV* dx,
                          float* dgamma, float* dbeta, const TV* dres, void* s) {
-    return pw_bn_small_bwd(*dout, outm, *x, mean, invstd, gamma, *dx, dgamma, dbeta, dres, ST(s));
+    return pw_bn_small_bwd(*dout, outm, *x, mean, invstd, gamma, *dx, dgamma, dbeta, dres, 0, ST(s));
 }
 int caddy_k_bn_apply(const TV* x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV* out, void* s) {
     return pw_bn_apply(*x, scale, shift, x2, scale2, shift2, act, *out, ST(s));
@@ -46,8 +46,17 @@ int caddy_k_bn_bwd_reduce(const TV* dout, const TV* outm, const TV* x, const flo
 }
 int caddy_k_bn_bwd_apply(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const double* sums,
                          const TV* dx, float* dgamma, float* dbeta, void* s) {
-    return pw_bn_bwd_apply(*dout, outm, *x, mean, invstd, gamma, sums, *dx, dgamma, dbeta, ST(s));
+    return pw_bn_bwd_apply(*dout, outm, *x, mean, invstd, gamma, sums, *dx, dgamma, dbeta, 0, ST(s));
 }
+// first-touch variants: the gradient buffer is ASSIGNED (it may hold garbage), see caddy_ctx::alloc_nz
+int caddy_k_bn_bwd_apply_assign(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const double* sums, const TV* dx, void* s) {
+    return pw_bn_bwd_apply(*dout, outm, *x, mean, invstd, gamma, sums, *dx, nullptr, nullptr, 1, ST(s));
+}
+int caddy_k_bn_small_bwd_assign(const TV* dout, const TV* outm, const TV* x, const float* mean, const float* invstd, const float* gamma, const TV* dx,
+                                float* dgamma, float* dbeta, const TV* dres, void* s) {
+    return pw_bn_small_bwd(*dout, outm, *x, mean, invstd, gamma, *dx, dgamma, dbeta, dres, 1, ST(s));
+}
+int caddy_k_pool2_bwd_assign(const TV* dout, const TV* din, void* s) { return pw_pool2_bwd(*dout, *din, 1, ST(s)); }
 int caddy_k_act_bwd_add(const TV* dout, const TV* outm, const TV* dres, void* s) { return pw_act_bwd_add(*dout, *outm, *dres, ST(s)); }
 int caddy_k_lstm_fwd(const TV* gates, const TV* cprev, const TV* h, const TV* cn, void* s) { return pw_lstm_fwd(*gates, *cprev, *h, *cn, ST(s)); }
 int caddy_k_lstm_bwd(const TV* gates, const TV* cprev, const TV* cn, const TV* dh, const TV* dc, const TV* dgates, const TV* dcprev, void* s) {

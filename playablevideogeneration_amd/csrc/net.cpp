@@ -9,6 +9,7 @@
 
 static thread_local std::string g_err;
 static int finish(caddy_ctx* c) {   // surface asynchronous launch errors of this API call
+    if (!c->dry && c->act.overflow() && !c->fail) { c->fail = true; g_err = "activation arena overflow (workspace smaller than caddy_workspace_bytes)"; }
     if (!c->dry) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess && !c->fail) { c->fail = true; g_err = std::string("HIP error: ") + hipGetErrorString(e); }
@@ -225,6 +226,15 @@ T4 caddy_ctx::alloc(int N, int H, int W, int C, int ld) {
     dbg.push_back(t);
     return t;
 }
+T4 caddy_ctx::alloc_nz(int N, int H, int W, int C) {
+    static const bool off = getenv("CADDY_FIRST_TOUCH") && atoi(getenv("CADDY_FIRST_TOUCH")) == 0;      // A/B aid: everything zero-filled + accumulated
+    if (off) return alloc(N, H, W, C);
+    int ld = round_up(C, 4);
+    float* d = (float*)act.alloc_top((size_t)N * H * W * ld * 4);
+    T4 t{d, (float*)((char*)d + grad_delta), N, H, W, C, (long)H * W * ld, ld, true};
+    dbg.push_back(t);
+    return t;
+}
 float* caddy_ctx::falloc(size_t n) { return (float*)act.alloc(n * 4); }
 double* caddy_ctx::dalloc(size_t n) { return (double*)act.alloc(n * 8); }
 static inline float* tw(caddy_ctx* c, float* p) { return (float*)((char*)p + c->grad_delta); }
@@ -326,10 +336,10 @@ int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
     return rc;
 }
 
-T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into) {
+T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into, bool nz_out) {
     int N = 0, H = 0, W = 0;
     for (int s = 0; s < nseg; s++) if (!segs[s].bcast) { N = segs[s].t.N; H = segs[s].t.H; W = segs[s].t.W; break; }
-    T4 out = into ? *into : alloc(N, H, W, L.pd.Cout);
+    T4 out = into ? *into : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout));
     ConvArgs a{};
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
@@ -380,9 +390,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
 }
 
 T4 caddy_ctx::pool2(const T4& x) {
-    T4 o = alloc(x.N, x.H / 2, x.W / 2, x.C);
+    T4 o = x.nz ? alloc_nz(x.N, x.H / 2, x.W / 2, x.C) : alloc(x.N, x.H / 2, x.W / 2, x.C);   // conv -> pool -> BatchNorm chains stay first-touch
     RUN(pw_pool2(dv(x), dv(o), stream));
-    if (recording) tape.push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), stream)); });
+    if (recording) tape.push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), x.nz ? 1 : 0, stream)); });
     return o;
 }
 T4 caddy_ctx::up2(const T4& x) {
@@ -441,14 +451,14 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             const TV* omp = actf ? &om : nullptr;
             if (small) {
                 TV dres{}; if (has2) dres = gv(x2c);
-                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, stream));
+                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, x.nz ? 1 : 0, stream));
                 return;
             }
             RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream));   // sums assigned; param grads fused
-            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, stream));
+            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream));
             if (has2 && b2) {
                 RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, b2->dgamma, b2->dbeta, stream));
-                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, stream));
+                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
             } else if (has2) {
                 if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream));
                 else RUN(pw_copy(gv(out), gv(x2c), 1, stream));
@@ -461,13 +471,13 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
 // ResidualBlock (model/layers/residual_block.py:51-68)
 T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
     Seg sx{x, 0, true};
-    T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr);
+    T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr, true);        // conv -> (pool) -> BatchNorm: single assigning gradient writer
     if (R.ds == 2) c1 = pool2(c1);
     T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr);
     Seg sa{a1, 0, true};
-    T4 c2 = conv(R.conv2, &sa, 1, 0, nullptr);
+    T4 c2 = conv(R.conv2, &sa, 1, 0, nullptr, true);
     if (R.has_down) {
-        T4 idn = conv(R.down, &sx, 1, 0, nullptr);
+        T4 idn = conv(R.down, &sx, 1, 0, nullptr, true);
         if (R.ds == 2) idn = pool2(idn);
         return bn_act(c2, R.bn2, &idn, &R.bnd, true, into);
     }
@@ -477,7 +487,7 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
 // RepresentationNetwork.forward (model/main_model/representation_network.py:32-58); output keeps the 65th (attention) channel
 T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
     Seg so{obs_in, 0, input_grad};
-    T4 x = conv(e_stem, &so, 1, 0, nullptr);
+    T4 x = conv(e_stem, &so, 1, 0, nullptr, true);
     x = pool2(x);
     x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr);
     for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr);
@@ -509,7 +519,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
         }
     } else { hprev = L.h; cprev = L.c; }
     Seg sg[3] = {{x, 0, true}, {aux, 1, true}, {hprev, 0, true}};
-    T4 gates = conv(L.gates, sg, 3, 0, nullptr);
+    T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     T4 hn, cn;
     if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
@@ -522,17 +532,17 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
 T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
     T4 x = lstm_step(0, state, aux);
     Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
-    x = conv(r_c0, s0, 2, 0, nullptr);
+    x = conv(r_c0, s0, 2, 0, nullptr, true);
     x = pool2(x);
     x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr);
     x = lstm_step(1, x, aux);
     Seg s1[2] = {{x, 0, true}, {aux, 1, true}};
-    x = conv(r_c1, s1, 2, 0, nullptr);
+    x = conv(r_c1, s1, 2, 0, nullptr, true);
     x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr);
     x = up2(x);
     x = lstm_step(2, x, aux);
     Seg s2[2] = {{x, 0, true}, {aux, 1, true}};
-    x = conv(r_c2, s2, 2, 0, nullptr);
+    x = conv(r_c2, s2, 2, 0, nullptr, true);
     return bn_act(x, r_bn2, nullptr, nullptr, true, into);
 }
 
@@ -543,7 +553,7 @@ void caddy_ctx::render(const T4& hdn, int slot, int nslots) {
     for (int i = 0; i < 3; i++) {
         T4 u = up2(x);
         Seg su{u, 0, true};
-        T4 c = conv(d_up[i], &su, 1, 0, nullptr);
+        T4 c = conv(d_up[i], &su, 1, 0, nullptr, true);
         x = bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr);
         if (i < 2) x = resblock(d_res[i], x, nullptr);
         T4 dst = tslice(frames[2 - i], B, nslots, slot);
@@ -755,6 +765,8 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     hipStream_t st = c->stream;
     if (!dry) {
         hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);   // (zero-filling on the side stream during the forward pass was measured: no gain, the step is throughput-bound)
+        static const bool poison_env = getenv("CADDY_POISON_NZ") != nullptr;   // test aid: NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
+        if ((poison_env || c->poison_nz) && c->act.top < c->act.cap) hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
             hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
         for (ConvL* L : c->convs) hipMemsetAsync(L->dwp, 0, L->wp_floats * 4, st);
         for (int i = 0; i < 3; i++) { hipMemsetAsync(c->lstm[i].ih.g, 0, c->lstm[i].ih.sn * 4, st); hipMemsetAsync(c->lstm[i].ic.g, 0, c->lstm[i].ic.sn * 4, st); }
@@ -916,6 +928,7 @@ static caddy_ctx* make_ctx(const caddy_config* cfg, float* params, float* grads,
     build_layers(c);
     size_t pbytes = (c->persist.high + 4095) & ~(size_t)4095;
     c->act.base = (char*)ws + pbytes; c->act.cap = act_cap; c->grad_delta = act_cap;
+    c->act.reset();
     return c;
 }
 
@@ -942,7 +955,7 @@ static void dry_sizes(const caddy_config* cfg, size_t* persist, size_t* act) {
     forward_full(c, nullptr, 1, 1.f, nullptr, 1, nullptr, nullptr);
     forward_pretraining(c, nullptr, 1.f, nullptr, 1, nullptr, nullptr);     // Arena::high keeps the maximum of both graphs
     *persist = (c->persist.high + 4095) & ~(size_t)4095;
-    *act = (c->act.high + 4095) & ~(size_t)4095;
+    *act = ((c->act.high + 4095) & ~(size_t)4095) + ((c->act.top_used + 4095) & ~(size_t)4095) + 4096;     // bottom-up part + top-down (first-touch) part
     delete c;
 }
 size_t caddy_workspace_bytes(const caddy_config* cfg) {
@@ -965,6 +978,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }
 int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
     c->samplers = SamplerHooks{};

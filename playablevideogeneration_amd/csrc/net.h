@@ -13,21 +13,32 @@
 struct T4 {            // activation + gradient views with identical geometry
     float* d; float* g;
     int N, H, W, C; long sn; int ld;
+    bool nz = false;   // gradient lives in the NOT-zero-filled part of the arena: its single backward writer assigns (see Arena::alloc_top)
 };
 static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
 static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
 
 struct ParamEntry { std::string name; long offset; int ndim; int shape[4]; int kind; long numel; };
 
+// Two-ended bump allocator.  Bottom-up: ordinary activations; their gradient mirror [0, off) is zero-filled before every backward pass
+// because backward ops accumulate (+=) into it.  Top-down (alloc_top): tensors whose gradient has exactly ONE writer that overwrites it
+// completely before anyone reads it (conv outputs consumed by a BatchNorm, pooled tensors, ConvLSTM gate pre-activations): no zero-fill
+// and no read-modify-write for ~40 % of the gradient bytes.
 struct Arena {
-    char* base = nullptr; size_t cap = 0, off = 0, high = 0;
+    char* base = nullptr; size_t cap = 0, off = 0, high = 0, top = 0, top_used = 0;
     void* alloc(size_t bytes) {
         size_t a = (off + 255) & ~(size_t)255;
         off = a + bytes;
         if (off > high) high = off;
         return base + a;
     }
-    void reset() { off = 0; }
+    void* alloc_top(size_t bytes) {
+        top = (top - bytes) & ~(size_t)255;
+        if (cap - top > top_used) top_used = cap - top;
+        return base + top;
+    }
+    void reset() { off = 0; top = cap & ~(size_t)255; }
+    bool overflow() const { return off > top; }
 };
 
 struct ConvL {
@@ -93,6 +104,7 @@ struct caddy_ctx {
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     bool have_forward = false;
+    bool poison_nz = false;          // caddy_debug_set_poison: NaN-fill the first-touch gradient region before every backward (tests)
     int hs, ws;   // state resolution
 
     // ---- optional per-launch timing of the conv kernels (HIP events on the launch stream; bench.py roofline) ----
@@ -119,9 +131,10 @@ struct caddy_ctx {
 
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);
+    T4 alloc_nz(int N, int H, int W, int C);      // gradient not zero-filled: only for tensors with a single, assigning backward writer
     float* falloc(size_t n);
     double* dalloc(size_t n);
-    T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into);
+    T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false);
     T4 pool2(const T4& x);
     T4 up2(const T4& x);
     T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into);

@@ -84,14 +84,16 @@ struct FPool2 {  // q indexes OUTPUT pixels (F.avg_pool2d(x, 2): residual_block.
         st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, 0.25f * v);
     }
 };
-struct FPool2Bwd {  // q indexes INPUT pixels; din += dout/4
-    TV dout, din;
+struct FPool2Bwd {  // q indexes INPUT pixels; din (+)= dout/4; `assign`: first and only writer of din (no zero-fill, no read)
+    TV dout, din; int assign;
     __device__ void operator()(long q, int c) const {
         int HWi = din.H * din.W;
         long n = q / HWi; int rem = (int)(q - n * HWi); int y = rem / din.W, x = rem - y * din.W;
-        float4 g = ld4(dout.p + n * dout.sn + ((long)(y >> 1) * dout.W + (x >> 1)) * dout.ld + c, c, dout.C);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((y >> 1) < dout.H && (x >> 1) < dout.W)          // odd sizes: the last row / column is not covered by any 2x2 window
+            g = ld4(dout.p + n * dout.sn + ((long)(y >> 1) * dout.W + (x >> 1)) * dout.ld + c, c, dout.C);
         float* o = din.p + n * din.sn + (long)rem * din.ld + c;
-        st4(o, c, din.C, ld4(o, c, din.C) + 0.25f * g);
+        st4(o, c, din.C, assign ? 0.25f * g : ld4(o, c, din.C) + 0.25f * g);
     }
 };
 struct FUp2 {  // bilinear x2, align_corners=False (up_block.py:35,43); q indexes OUTPUT pixels
@@ -144,7 +146,7 @@ struct FBnApply {  // out = act(x*scale+shift + second), second = x2*scale2+shif
     }
 };
 struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*lrelu'(out)
-    TV dout, outm, x, dx; const float *mean, *invstd, *gamma; const double* sums; int HW; int act; float invM;
+    TV dout, outm, x, dx; const float *mean, *invstd, *gamma; const double* sums; int HW; int act; float invM; int assign;
     __device__ void operator()(long q, int c) const {
         float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C);
         if (act) dz = dz * lmask4(ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
@@ -155,7 +157,7 @@ struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*l
         float4 xh = (xv - mu) * is;
         float4 g = ga * is * (dz - make_float4(s1[0], s1[1], s1[2], s1[3]) - xh * make_float4(s2[0], s2[1], s2[2], s2[3]));
         float* o = dx.p + tv_off(dx, HW, q) + c;
-        st4(o, c, dx.C, ld4(o, c, dx.C) + g);
+        st4(o, c, dx.C, assign ? g : ld4(o, c, dx.C) + g);      // assign: dx has no other writer (conv output consumed by this BatchNorm only)
     }
 };
 struct FActBwdAdd {  // dres += dout * lrelu'(out)
@@ -410,7 +412,7 @@ int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
 // registers, the block reduces in fp64 (shuffles + LDS), finalises, and applies from registers -- one launch, one read of x.
 constexpr int BNS_PPT = 32;                  // pixels per thread -> up to 256 * 32 = 8192 pixels
 struct BnSmallFwd { TV x, x2, out; int has2, act; BnFin fin; };
-struct BnSmallBwd { TV dout, outm, x, dx, dres; int act, has_res; const float *mean, *invstd, *gamma; float *dgamma, *dbeta; };
+struct BnSmallBwd { TV dout, outm, x, dx, dres; int act, has_res; const float *mean, *invstd, *gamma; float *dgamma, *dbeta; int assign; };
 
 __device__ __forceinline__ void block_reduce8(double* s, double* sh, int tid) {   // result valid for all threads in sh[0..7]
 #pragma unroll
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(BnSmallBwd a) {
             float4 xh = (ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C) - mu) * is;
             float4 g = ga * is * (dz[i] - s1 - xh * s2);
             float* o = a.dx.p + tv_off(a.dx, HW, q) + c;
-            st4(o, c, C, ld4(o, c, C) + g);
+            st4(o, c, C, a.assign ? g : ld4(o, c, C) + g);
             if (a.has_res) { float* r = a.dres.p + tv_off(a.dres, HW, q) + c; st4(r, c, C, ld4(r, c, C) + dz[i]); }
         }
     }
@@ -608,7 +610,7 @@ int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) {
 }
 int pw_fill(const TV& d, float v, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FFill{d, d.H * d.W, v}, st); }
 int pw_pool2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out}, st); }
-int pw_pool2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din}, st); }
+int pw_pool2_bwd(const TV& dout, const TV& din, int assign, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din, assign}, st); }
 int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
 int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
 int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch; return run_reduce<0>(a, st); }
@@ -644,9 +646,9 @@ int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* r
 }
 // BatchNorm backward in one launch: dx += ..., dgamma/dbeta +=, and (optional) dres += dout * act'(out) for the residual input
 int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
-                    float* dgamma, float* dbeta, const TV* dres, hipStream_t st) {
+                    float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st) {
     if (!pw_bn_small_ok(x)) return -1;
-    BnSmallBwd a{dout, outm ? *outm : dout, x, dx, dres ? *dres : dx, outm ? 1 : 0, dres ? 1 : 0, mean, invstd, gamma, dgamma, dbeta};
+    BnSmallBwd a{dout, outm ? *outm : dout, x, dx, dres ? *dres : dx, outm ? 1 : 0, dres ? 1 : 0, mean, invstd, gamma, dgamma, dbeta, assign};
     hipLaunchKernelGGL(k_bn_small_bwd, dim3(cdiv(x.C, 4)), dim3(256), 0, st, a);
     return 0;
 }
@@ -659,9 +661,9 @@ int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* m
     return run_reduce<1>(a, st);
 }
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                    const TV& dx, float* dgamma, float* dbeta, hipStream_t st) {
+                    const TV& dx, float* dgamma, float* dbeta, int assign, hipStream_t st) {
     long M = (long)x.N * x.H * x.W;
-    FBnBwdApply f{dout, outm ? *outm : dout, x, dx, mean, invstd, gamma, sums, x.H * x.W, outm ? 1 : 0, (float)(1.0 / (double)M)};
+    FBnBwdApply f{dout, outm ? *outm : dout, x, dx, mean, invstd, gamma, sums, x.H * x.W, outm ? 1 : 0, (float)(1.0 / (double)M), assign};
     run_map(M, x.C, f, st);
     if (dgamma) hipLaunchKernelGGL(k_bn_param_grad, dim3(cdiv(x.C, 64)), dim3(64), 0, st, sums, x.C, dgamma, dbeta);
     return 0;

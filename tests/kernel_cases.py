@@ -209,6 +209,10 @@ def pool_up_case(lib, dev, N=2, Cc=6, H=4, W=6, seed=0):
     sync(dev)
     assert (to_nchw(yb, Cc) - y_ref.detach()).abs().max() < 1e-6
     assert (to_nchw(gx, Cc) - 1 - x.grad).abs().max() < 1e-6
+    gx = torch.full_like(xb, float("nan"))                      # first-touch variant: the gradient buffer holds garbage and is assigned
+    assert lib.caddy_k_pool2_bwd_assign(C.byref(tv(nhwc(dy, dev=dev), Cc)), C.byref(tv(gx, Cc)), st) == 0
+    sync(dev)
+    assert (to_nchw(gx, Cc) - x.grad).abs().max() < 1e-6
     # bilinear x2
     x = _rand(g, N, Cc, H, W).requires_grad_(True)
     y_ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
@@ -284,6 +288,12 @@ def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed
         assert (db.cpu() - 1 - bet.grad).abs().max() < 2e-5 * max(1.0, bet.grad.abs().max().item())
         if second == "plain":
             assert (to_nchw(dres, Cc) - 1 - x2.grad).abs().max() < 2e-6
+        dx2 = torch.full_like(xb, float("nan")); dres2 = torch.ones_like(xb); dt2 = tv(dres2, Cc)
+        dg2, db2 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+        assert lib.caddy_k_bn_small_bwd_assign(C.byref(tv(dyb, Cc)), C.byref(tv(out, Cc)) if act else None, C.byref(tv(xb, Cc)), P(mean), P(invstd), P(gmd),
+                                               C.byref(tv(dx2, Cc)), P(dg2), P(db2), C.byref(dt2) if second == "plain" else None, st) == 0
+        sync(dev)
+        assert (to_nchw(dx2, Cc) - x.grad).abs().max() < 5e-6 * max(1.0, x.grad.abs().max().item())
         return
     xb, (mean, invstd, scale, shift), gmd, rmd, rvd = run_bn(x, gam, bet, rm, rv)
     x2b = None
@@ -316,6 +326,10 @@ def bn_case(lib, dev, N=3, Cc=10, H=5, W=4, second="bn", act=1, training=1, seed
         assert (to_nchw(dx, Cc) - 1 - xref.grad).abs().max() < 5e-6 * max(1.0, xref.grad.abs().max().item())
         assert (dg.cpu() - 1 - gref.grad).abs().max() < 2e-5 * max(1.0, gref.grad.abs().max().item())
         assert (db.cpu() - 1 - bref.grad).abs().max() < 2e-5 * max(1.0, bref.grad.abs().max().item())
+        dx2 = torch.full_like(xbuf, float("nan"))               # first-touch variant (dx assigned, not accumulated)
+        assert lib.caddy_k_bn_bwd_apply_assign(C.byref(tv(dyb, Cc)), outm, C.byref(tv(xbuf, Cc)), P(mean_), P(invstd_), P(gmd_), P(sums), C.byref(tv(dx2, Cc)), st) == 0
+        sync(dev)
+        assert (to_nchw(dx2, Cc) - xref.grad).abs().max() < 5e-6 * max(1.0, xref.grad.abs().max().item())
 
     bwd(xb, mean, invstd, gmd, x, gam, bet)
     if second == "bn":

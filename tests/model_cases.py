@@ -1,4 +1,6 @@
 """Whole-path parity cases (HIP engine vs oracle and vs reference golden vectors), shared by simulator and GPU tests."""
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -17,8 +19,13 @@ def noise_dict(rec, B, T, K, Da, gumbel=True):
 
 
 def make_engine(c, lib, dev):
-    return Engine(variant=c["variant"], batch=c["B"], seq_len=c["T"], height=c["H"], width=c["W"], stacking=c["S"], actions=c["K"],
-                  action_dim=c["Da"], hidden=c["Ch"], hard_gumbel=c.get("hard", False), device=dev, lib=lib)
+    eng = Engine(variant=c["variant"], batch=c["B"], seq_len=c["T"], height=c["H"], width=c["W"], stacking=c["S"], actions=c["K"],
+                 action_dim=c["Da"], hidden=c["Ch"], hard_gumbel=c.get("hard", False), device=dev, lib=lib)
+    # every test runs with the first-touch part of the gradient arena NaN-filled before each backward: a gradient that is read before
+    # its single writer assigned it cannot go unnoticed (fresh workspaces are often zero pages, which would mask it)
+    lib.caddy_debug_set_poison.argtypes = [C.c_void_p, C.c_int]
+    lib.caddy_debug_set_poison(eng.ctx, 1)
+    return eng
 
 
 def _cmp(a, b, tol, what):
