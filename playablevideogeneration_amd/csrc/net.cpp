@@ -377,7 +377,12 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
                 d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux;
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
-                if (!sg[s].bcast) { d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = 1; RUN(timed_conv_fwd(d, dfl)); }
+                if (!sg[s].bcast) {
+                    // first-touch inputs (this conv is their only consumer): dgrad assigns -- plain stores, or the deterministic slab split-K when under-filled
+                    d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = sg[s].t.nz ? 0 : 1;
+                    if (sg[s].t.nz) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
+                    RUN(timed_conv_fwd(d, dfl));
+                }
                 else {
                     d.out = tmp[s].d; d.out_sn = tmp[s].sn; d.out_ld = tmp[s].ld; d.accumulate = 0;
                     RUN(timed_conv_fwd(d, dfl));
@@ -428,8 +433,8 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     }
     return s;
 }
-T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into) {
-    T4 out = into ? *into : alloc(x.N, x.H, x.W, x.C);
+T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into, bool nz_out) {
+    T4 out = into ? *into : (nz_out ? alloc_nz(x.N, x.H, x.W, x.C) : alloc(x.N, x.H, x.W, x.C));
     static const bool no_small = getenv("CADDY_BN_SMALL") && atoi(getenv("CADDY_BN_SMALL")) == 0;      // A/B aid
     const bool small = training && !bn2 && !no_small && pw_bn_small_pays(dv(x));      // one-launch path for R's small maps
     TV x2v{}; if (x2) x2v = dv(*x2);
@@ -473,7 +478,7 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
     Seg sx{x, 0, true};
     T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr, true);        // conv -> (pool) -> BatchNorm: single assigning gradient writer
     if (R.ds == 2) c1 = pool2(c1);
-    T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr);
+    T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr, true);      // consumed by conv2 only
     Seg sa{a1, 0, true};
     T4 c2 = conv(R.conv2, &sa, 1, 0, nullptr, true);
     if (R.has_down) {

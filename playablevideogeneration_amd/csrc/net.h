@@ -137,7 +137,7 @@ struct caddy_ctx {
     T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false);
     T4 pool2(const T4& x);
     T4 up2(const T4& x);
-    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into);
+    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false);   // nz_out: the output feeds exactly one conv
     T4 resblock(ResL& R, const T4& x, const T4* into);
     T4 encode(const T4& obs_in, bool input_grad, const T4* into);
     T4 lstm_step(int i, const T4& x, const T4& aux);
