@@ -89,7 +89,7 @@ def rollout_fps(dev, frames=32):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"metric": "rollout frames/sec", "value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / frames * 1e3,
-            "config": {"workload": "tennis256_s4_rollout32", "model": "main", "batch": 1, "frames": frames}}
+            "config": {"workload": "tennis256_s4_rollout32", "variant": "main", "batch": 1, "frames": frames}}
 
 
 def main():
@@ -206,7 +206,7 @@ def run(a, dev, lib=None, backend="nccl"):
     if rank == 0:
         res = {"metric": f"training clips/sec (B x{T}x{H}x{W})", "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": a.workload, "model": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
+               "config": {"workload": a.workload, "variant": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
                           "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
                "loss": losses["total"], "roofline": roof}
