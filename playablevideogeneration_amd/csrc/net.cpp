@@ -204,6 +204,11 @@ void build_layers(caddy_ctx* c) {
             for (auto& e : c->table) if (e.kind == 0 && e.name.rfind(pre[b], 0) == 0) { if (lo < 0 || e.offset < lo) lo = e.offset; long en = e.offset + (e.numel + 3) / 4 * 4; if (en > hi) hi = en; }
             c->bucket_lo[b] = lo < 0 ? 0 : lo; c->bucket_hi[b] = lo < 0 ? 0 : hi;
         }
+        for (auto& e : c->table) if (e.kind == 0 && e.name.rfind("state_to_hidden_state_layer.", 0) == 0) {
+            long en = e.offset + (e.numel + 3) / 4 * 4;
+            if (c->s2h_hi == 0 || e.offset < c->s2h_lo) c->s2h_lo = e.offset;
+            if (en > c->s2h_hi) c->s2h_hi = en;
+        }
         for (int i = 0; i < 3; i++) c->lstm[i].gates.early_bucket = true;
         c->r_c0.early_bucket = c->r_c1.early_bucket = c->r_c2.early_bucket = true;
         for (int i = 0; i < 3; i++) { c->d_up[i].early_bucket = true; c->d_final[i].early_bucket = true; }
@@ -1008,7 +1013,14 @@ int caddy_get_output(caddy_ctx* c, int id, void* dst) { return get_output(c, id,
 int caddy_get_output_grad(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, true); }
 int caddy_loss_backward(caddy_ctx* c, const caddy_loss_cfg* cfg, double* losses_host) { c->fail = false; return loss_backward(c, cfg, losses_host); }
 int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
-    return adam_launch(c->P, c->G, m, v, c->n_train, lr, b1, b2, eps, wd, step, gscale, c->stream);
+    // torch.optim.Adam skips parameters whose .grad is None -- no moment update, no weight decay.  After forward_full_model that is
+    // state_to_hidden_state_layer (only forward_pretraining uses it, model.py:41-43,413): leave its range untouched.
+    long lo = 0, hi = 0;
+    if (!c->pretraining && c->s2h_hi > c->s2h_lo) { lo = c->s2h_lo; hi = c->s2h_hi; }
+    int rc = 0;
+    if (lo > 0) rc = adam_launch(c->P, c->G, m, v, lo, lr, b1, b2, eps, wd, step, gscale, c->stream);
+    if (!rc && hi < c->n_train) rc = adam_launch(c->P + hi, c->G + hi, m + hi, v + hi, c->n_train - hi, lr, b1, b2, eps, wd, step, gscale, c->stream);
+    return rc;
 }
 int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {

@@ -98,6 +98,7 @@ struct caddy_ctx {
     // unpacked on the side stream and handed to the caller while A and E-on-ground-truth-frames still run their backward
     void (*grads_hook)(float* grads, long offset, long count, void* stream, void* user) = nullptr; void* grads_user = nullptr;
     long bucket_lo[2] = {0, 0}, bucket_hi[2] = {0, 0}; bool lstm_early_done = false;
+    long s2h_lo = 0, s2h_hi = 0;     // state_to_hidden_state_layer: unused by forward_full_model -> its .grad is None there and torch's Adam skips it (no weight decay either)
     void early_gradient_buckets();   // data-parallel reductions of the K x K MI matrix / centroid sums
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)

@@ -1,0 +1,82 @@
+"""Golden of the REAL reference training step (build container only): SmoothMITrainer.compute_losses + optimizer.zero_grad / backward /
+step on one seeded batch (training/trainer.py:400-550,575-587; training/smooth_mi_trainer.py), perceptual_loss_lambda = 0 (the VGG stub
+of tools/ref_harness.py runs but contributes nothing).  Stored: the scalar loss_info entries, the schedule values, per-parameter
+post-step summaries and the MI estimator state -> tests/golden/trainer_reduced_s1.npz.     python tools/gen_trainer_golden.py"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_harness as rh  # noqa: E402
+from oracle import caddy_oracle as O  # noqa: E402
+from tests.test_host_api_emu import _config  # noqa: E402   (the mirror's test config: the golden must be produced with the same keys)
+
+PARAM_SEED, OBS_SEED, STEP_SEED, GLOBAL_STEP = 7, 1, 11, 5000
+
+
+PRE_W = {"reconstruction_loss_lambda_pretraining": 1.0, "perceptual_loss_lambda_pretraining": 0.0, "hidden_states_rec_lambda_pretraining": 1.0,
+         "states_rec_lambda_pretraining": 0.2, "entropy_lambda_pretraining": 0.0, "action_directions_kl_lambda_pretraining": 1e-4,
+         "action_mutual_information_lambda_pretraining": 0.15, "action_state_distribution_kl_lambda_pretraining": 0.0}
+
+
+def main():
+    for pre in (False, True):
+        one(pre)
+
+
+def one(pretraining):
+    rh.install()
+    cfg = _config(res=(8, 8))          # 64 x 64 frames: the (stub) VGG19 of the reference's perceptual loss needs >= 16 pixels at the quarter resolution
+    cfg["model"]["architecture"] = "model.reduced_model.model"
+    cfg["model"]["action_network"]["use_variations"] = True
+    tr = cfg["training"]
+    tr["trainer"] = "training.smooth_mi_trainer"
+    tr["batching"].update(batch_size=2, num_workers=0)
+    tr.update(motion_weights_bias=0.1, use_motion_weights=False, action_mutual_information_entropy_lambda=1.0, action_direction_plotting_freq=10 ** 9,
+              max_steps=10 ** 6)
+    tr["loss_weights"]["perceptual_loss_lambda"] = 0.0
+    tr["loss_weights"].update(PRE_W)
+    cfg["logging"] = {"save_root_directory": "/tmp", "output_images_directory": "/tmp"}
+    d = O.Dims.from_config(cfg)
+    P = O.make_params(d, seed=PARAM_SEED)
+    ref = nn.DataParallel(rh.build_reference_model(cfg, P))            # CPU: pass-through, but provides `.module` as the trainer expects
+    import training.smooth_mi_trainer as SM
+    logger = types.SimpleNamespace(print=lambda *a, **k: None, get_wandb=lambda: types.SimpleNamespace(log=lambda *a, **k: None))
+    trainer = SM.SmoothMITrainer(cfg, ref, [0] * 8, logger)
+    trainer.global_step = GLOBAL_STEP
+    obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
+    acts = torch.zeros(2, 4, dtype=torch.int32)
+    batch = types.SimpleNamespace(observations=obs, actions=acts, size=4, to_tuple=lambda cuda=True: (obs, acts, None, None))
+    ref.train()
+    torch.manual_seed(STEP_SEED)
+    random.seed(STEP_SEED)
+    loss, info, _ = (trainer.compute_losses_pretraining if pretraining else trainer.compute_losses)(ref, batch, 4)
+    trainer.optimizer.zero_grad()
+    loss.backward()
+    trainer.optimizer.step()
+    trainer.lr_scheduler.step()
+    data = {"loss": np.array(loss.item()), "global_step": np.array(GLOBAL_STEP), "step_seed": np.array(STEP_SEED)}
+    for k, v in info.items():
+        if isinstance(v, (int, float)):
+            data["info:" + k] = np.array(float(v))
+    names, psum, pabs, first = [], [], [], []
+    for n, p in ref.module.named_parameters():
+        names.append(n); psum.append(p.detach().double().sum().item()); pabs.append(p.detach().double().abs().sum().item())
+        first.append(p.detach().flatten()[:4].tolist() + [0.0] * max(0, 4 - p.numel()))
+    data["param_names"], data["param_sum"], data["param_abs"], data["param_first4"] = np.array(names), np.array(psum), np.array(pabs), np.array(first, dtype=np.float32)
+    data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
+    data["lr"] = np.array(trainer._get_current_lr())
+    out = os.path.join(ROOT, "tests", "golden", "trainer_pre_reduced_s1.npz" if pretraining else "trainer_reduced_s1.npz")
+    np.savez_compressed(out, **data)
+    print("written", out, {k: float(v) for k, v in data.items() if k.startswith("info:")})
+
+
+if __name__ == "__main__":
+    main()
