@@ -91,8 +91,27 @@ class Model(nn.Module):
             k *= s
         return self._flat[off:off + k].view(shape)
 
+    def reference_order(self):
+        """Table entries in the reference's registration order (what state_dict() / parameters() / a positional torch optimizer state see).  The
+        C driver lists a ConvLSTM cell as 4 gate weights then 4 gate biases (one packed convolution); the reference module registers
+        input / forget / output / cell gate as (weight, bias) pairs (convolutional_lstm_cell.py:26-45)."""
+        gates = {"input_gate": 0, "forget_gate": 1, "output_gate": 2, "cell_gate": 3}
+
+        def key(ie):
+            i, e = ie
+            parts = e[0].split(".")
+            if len(parts) >= 3 and parts[-3] == "cell" and parts[-2] in gates:
+                return (self._cell_anchor[".".join(parts[:-2])], gates[parts[-2]] * 2 + (0 if parts[-1] == "weight" else 1))
+            return (i, 0)
+        self._cell_anchor = {}
+        for i, e in enumerate(self.table):
+            parts = e[0].split(".")
+            if len(parts) >= 3 and parts[-3] == "cell" and parts[-2] in gates:
+                self._cell_anchor.setdefault(".".join(parts[:-2]), i)
+        return [e for _, e in sorted(enumerate(self.table), key=key)]
+
     def _register_tree(self):
-        for e in self.table:
+        for e in self.reference_order():
             name, off, shape, kind = e
             parts = name.split(".")
             node = self

@@ -166,16 +166,71 @@ class Trainer:
                 self.logger.print(f"step: {self.global_step} " + " ".join(f"{k}:{v:.3f}" for k, v in loss_info.items()) + f" lr: {self._get_current_lr():.4f}")
         return performed
 
-    # ---- checkpoints: same top-level keys as training/trainer.py:100 / smooth_mi_trainer.py:43-45 ----
+    # ---- checkpoints in the reference's format (training/trainer.py:80-122, smooth_mi_trainer.py:23-68): "model" (state_dict), "optimizer"
+    # (torch.optim.Adam.state_dict layout), "lr_scheduler" (MultiStepLR.state_dict layout), "mi_estimator", "step" -- a checkpoint written
+    # by the reference resumes here and vice versa ----
+    @staticmethod
+    def _optimizer_params(model):
+        """Adam was built on model.parameters(): every nn.Parameter in registration order, trainable or not (kind 0 / 2 of the table)"""
+        out = []
+        for name, off, shape, kind in model.module.reference_order():
+            if kind in (0, 2):
+                n = 1
+                for s_ in shape:
+                    n *= s_
+                out.append((name, off, n, tuple(shape), kind))
+        return out
+
+    def _export_optimizer(self, model):
+        import collections
+        params = self._optimizer_params(model)
+        state = {}
+        if self.adam_m is not None and self.opt_steps > 0:
+            m, v = self.adam_m.cpu(), self.adam_v.cpu()
+            for i, (name, off, n, shape, kind) in enumerate(params):
+                if kind == 0:
+                    state[i] = {"step": torch.tensor(float(self.opt_steps)), "exp_avg": m[off:off + n].view(shape).clone(),
+                                "exp_avg_sq": v[off:off + n].view(shape).clone()}
+        group = {"lr": self._get_current_lr(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "initial_lr": self.lr, "params": list(range(len(params)))}
+        sched = {"milestones": collections.Counter(self.lr_schedule), "gamma": self.lr_gamma, "base_lrs": [self.lr], "last_epoch": self.opt_steps,
+                 "_step_count": self.opt_steps + 1, "_get_lr_called_within_step": False, "_last_lr": [self._get_current_lr()]}
+        return {"state": state, "param_groups": [group]}, sched
+
+    def _import_optimizer(self, model, opt, sched):
+        dev = model.module._flat.device
+        n_train = model.module.n_train
+        if opt.get("fused_adam"):                                     # round-1 checkpoints of this mirror
+            if opt.get("exp_avg") is not None:
+                self.adam_m, self.adam_v, self.opt_steps = opt["exp_avg"].to(dev), opt["exp_avg_sq"].to(dev), opt["steps"]
+            return
+        params = self._optimizer_params(model)
+        ids = opt["param_groups"][0]["params"]
+        if len(ids) != len(params):
+            raise Exception(f"optimizer state has {len(ids)} parameters, the model has {len(params)}")
+        m, v = torch.zeros(n_train), torch.zeros(n_train)
+        steps = 0
+        for pid, (name, off, n, shape, kind) in zip(ids, params):
+            st = opt["state"].get(pid)
+            if st is None or kind != 0:
+                continue
+            m[off:off + n] = st["exp_avg"].reshape(-1).float()
+            v[off:off + n] = st["exp_avg_sq"].reshape(-1).float()
+            steps = max(steps, int(float(st["step"])))
+        self.adam_m, self.adam_v, self.opt_steps = m.to(dev), v.to(dev), steps
+        if sched and "last_epoch" in sched:
+            self.opt_steps = max(self.opt_steps, int(sched["last_epoch"])) if steps == 0 else steps
+
     def save_checkpoint(self, model, name=None):
         root = self.config["logging"]["save_root_directory"]
         filename = os.path.join(root, "latest.pth.tar" if name is None else f"{name}_.pth.tar")
         sd = {k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()}
-        state = {"model": sd, "optimizer": {"fused_adam": True, "steps": self.opt_steps, "exp_avg": None if self.adam_m is None else self.adam_m.cpu(),
-                                            "exp_avg_sq": None if self.adam_v is None else self.adam_v.cpu()},
-                 "lr_scheduler": {"milestones": self.lr_schedule, "gamma": self.lr_gamma, "last_epoch": self.opt_steps}, "step": self.global_step}
+        opt, sched = self._export_optimizer(model)
+        state = {"model": sd, "optimizer": opt, "lr_scheduler": sched, "step": self.global_step}
         if self.SMOOTH_MI:
-            state["mi_estimator"] = {"matrix_estimator.estimated_matrix": None if self.mi_ema is None else self.mi_ema.cpu()}
+            k = self.config["data"]["actions_count"]
+            ema = self.mi_ema.cpu() if self.mi_ema is not None else torch.full((k, k), 1.0 / (k * k))      # FixedMatrixEstimator's initial value
+            state["mi_estimator"] = {"matrix_estimator.estimated_matrix": ema}
         torch.save(state, filename)
 
     def load_checkpoint(self, model, name=None):
@@ -183,15 +238,12 @@ class Trainer:
         filename = os.path.join(root, "latest.pth.tar" if name is None else f"{name}.pth.tar")
         if not os.path.isfile(filename):
             raise Exception(f"Cannot load model: no checkpoint found at '{filename}'")
-        st = torch.load(filename, map_location="cpu")
+        st = torch.load(filename, map_location="cpu", weights_only=False)
         model.module.load_state_dict(st["model"])
-        opt = st.get("optimizer", {})
-        if opt.get("fused_adam") and opt.get("exp_avg") is not None:
-            dev = model.module._flat.device
-            self.adam_m, self.adam_v, self.opt_steps = opt["exp_avg"].to(dev), opt["exp_avg_sq"].to(dev), opt["steps"]
-        mi = st.get("mi_estimator", {}).get("matrix_estimator.estimated_matrix")
+        self._import_optimizer(model, st.get("optimizer", {}) or {}, st.get("lr_scheduler", {}))
+        mi = (st.get("mi_estimator") or {}).get("matrix_estimator.estimated_matrix")
         if mi is not None:
-            self.mi_ema = mi.to(model.module._flat.device)
+            self.mi_ema = mi.to(model.module._flat.device).float()
         self.global_step = st["step"]
 
 
