@@ -143,7 +143,7 @@ def test_device_prefetcher_passthrough_and_batch_objects():
 
 
 def test_training_progress_on_fixed_batch():
-    """12 optimisation steps of the trainer mirror (schedules, fused losses + BPTT, fused Adam) on one fixed batch: reconstruction improves"""
+    """8 optimisation steps of the trainer mirror (schedules, fused losses + BPTT, fused Adam) on one fixed batch: reconstruction improves"""
     from playablevideogeneration_amd import smooth_mi_trainer
     cfg = _config()
     cfg["logging"] = {"save_root_directory": "/tmp"}
@@ -155,7 +155,7 @@ def test_training_progress_on_fixed_batch():
     tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
     tr.global_step = 20000
     rec = []
-    for i in range(12):
+    for i in range(8):
         torch.manual_seed(100 + i)
         _, info, _ = tr.compute_losses(m, (obs, None, None, None), 4)
         tr.optimizer_step(m)

@@ -46,5 +46,5 @@ def test_eval_samplers(name):
 
 
 def test_random_model_configurations():
-    """two seeded random configurations (observation_stacking 2 / 3, odd batch, ... are not covered by the reference goldens); the GPU suite runs 10"""
-    M.random_config_sweep(load_emu(), "cpu", 2, seed=21)
+    """a seeded random configuration (observation_stacking 2 / 3, odd batch, ... are not covered by the reference goldens); the GPU suite runs 10"""
+    M.random_config_sweep(load_emu(), "cpu", 1, seed=21)
