@@ -84,15 +84,13 @@ def test_checkpoint_interchange(tmp_path, direction):
     mtr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
     rtr.global_step = mtr.global_step = 5000
     if direction == "reference_to_mirror":
-        for i in range(2):
-            _ref_step(ref, rtr, obs, 20 + i)
+        _ref_step(ref, rtr, obs, 20)
         rtr.save_checkpoint(ref)                                   # <root>/latest.pth.tar, written by the REAL reference
         mtr.load_checkpoint(m)
-        assert mtr.global_step == rtr.global_step and mtr.opt_steps == 2
+        assert mtr.global_step == rtr.global_step and mtr.opt_steps == 1
         assert np.allclose(mtr.mi_ema.numpy(), rtr.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy(), atol=1e-7)
     else:
-        for i in range(2):
-            _mirror_step(m, mtr, obs, 20 + i)
+        _mirror_step(m, mtr, obs, 20)
         mtr.save_checkpoint(m)
         rtr.load_checkpoint(ref.module)                            # the REAL reference loads the mirror's file (model, optimizer, lr_scheduler, mi_estimator, step); unwrapped module: its state_dict keys carry no "module." prefix
         assert rtr.global_step == mtr.global_step
