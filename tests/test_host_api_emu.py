@@ -124,6 +124,9 @@ def test_model_mirror_eval_samplers_and_interpolation_match_reference_goldens():
     for j, (a1, a2, al) in enumerate(H.INTERP):
         f, _ = m.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
         assert np.abs(f.cpu().numpy() - z["interp_frames"][j]).max() < 2e-4, j
+    torch.manual_seed(H.NOISE_SEED + 1)                    # generate_next(noise=True): same RNG draws, in the reference's order (model.py:590-596)
+    f, _ = m.generate_next(o, 1, noise=True)
+    assert np.abs(f.cpu().numpy() - z["noise_frame"]).max() < 2e-4
 
 
 def test_device_prefetcher_passthrough_and_batch_objects():

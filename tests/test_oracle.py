@@ -78,6 +78,10 @@ def test_oracle_rollout_matches_reference_golden(name):
         for j, (a1, a2, al) in enumerate(H.INTERP):
             f, _ = orc.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
             assert np.allclose(f.numpy(), z["interp_frames"][j], atol=1e-6), j
+        torch.manual_seed(H.NOISE_SEED + 1)                 # generate_next(noise=True): variation ~ N(0, 1), drawn before the (unused) dynamics noise
+        v = torch.randn((1, d.Da))
+        f, _ = orc.generate_next(o, 1, v[0])
+        assert np.allclose(f.numpy(), z["noise_frame"], atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["eval_main_s1_onehot_zero", "eval_reduced_s1_gt"])

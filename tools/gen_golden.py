@@ -125,8 +125,10 @@ def main():
             for (a1, a2, al) in INTERP:
                 f, o2 = ref.generate_next_interpolation(o, a1 % c["K"], a2 % c["K"], al)
                 interp.append(f.numpy())
+            torch.manual_seed(NOISE_SEED + 1)              # generate_next(noise=True): the action variation is drawn from N(0, 1) (model.py:590)
+            fn, _ = ref.generate_next(o, 1, noise=True)
         np.savez_compressed(os.path.join(outdir, name + ".npz"), case=np.array(repr(cc | {"steps": c["steps"]})),
-                            frames=np.stack(frames), last_obs=o.numpy(), interp_frames=np.stack(interp))
+                            frames=np.stack(frames), last_obs=o.numpy(), interp_frames=np.stack(interp), noise_frame=fn.numpy())
         print(name, "written")
 
     # eval-mode forward_full_model with the evaluation samplers (evaluation/evaluator.py:126, evaluation_dataset_builder.py:57-63)
