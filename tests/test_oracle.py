@@ -62,6 +62,46 @@ def test_oracle_pretraining_matches_reference_golden():
     _cmp(out, H.golden_outputs(z), 1e-6, "pre")
 
 
+@pytest.mark.parametrize("name", ["perc_main_s1", "perc_pre_reduced_s1"])
+def test_oracle_perceptual_loss_matches_reference_golden(name):
+    """VGG19 perceptual term: the reference's ParallelPerceptualLoss + Trainer.sum_loss_components on the seeded VGG weights
+    (tools/gen_golden.py) vs oracle.perceptual_terms -- every level x resolution, the total, d(total)/d(rec_r) and parameter gradients."""
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    P = {k: v.clone().requires_grad_(O.is_trainable(k)) for k, v in P.items()}
+    V = O.make_vgg_params()
+    orc = O.Oracle(d, P, training=True)
+    torch.manual_seed(H.NOISE_SEED)
+    out = orc.forward_pretraining(obs, tau=c["tau"]) if c["pre"] else orc.forward_full(obs, c["gt"], tau=c["tau"])
+    _cmp(out, H.golden_outputs(z), 1e-6, name)
+    for m in out[1]:
+        m.retain_grad()
+    w = dict(H.LOSS_W, perceptual=c["perc"])
+    fn = O.pretraining_loss if c["pre"] else O.full_model_loss
+    total, comp, _ = fn(out, obs, w, mi_ema=torch.full((d.K, d.K), 1.0 / (d.K * d.K)), mi_alpha=0.2, vgg=V)
+    assert abs(total.item() - float(z["loss_total"])) < 1e-6
+    for r in range(3):
+        assert abs(comp[f"perceptual_loss_r{r}"].item() - float(z[f"perceptual_loss_r{r}"])) < 1e-6
+        for l in range(5):
+            assert abs(comp[f"perceptual_loss_r{r}_l{l}"].item() - float(z[f"perceptual_loss_r{r}_l{l}"])) < 1e-6, (r, l)
+    assert abs(comp["perceptual"].item() - float(z["loss_perceptual"])) < 1e-6
+    total.backward()
+    for r, m in enumerate(out[1]):
+        g = torch.from_numpy(z[f"dout1_{r}"])
+        assert (m.grad - g).abs().max().item() <= 1e-6 * max(1.0, g.abs().max().item()) + 1e-9, r
+    for n, gs, ga in zip(z["grad_names"], z["grad_sum"], z["grad_abs"]):
+        g = P[str(n)].grad
+        assert abs(g.double().abs().sum().item() - ga) <= 1e-5 * max(1.0, abs(ga)), n
+
+
+def test_vgg_slicing_matches_torchvision_layout():
+    """13 convolutions up to conv5_1, taps after features[1], [6], [11], [20], [29] (model/layers/vgg.py:25-34)"""
+    idx = [l[0] for l in O.VGG_LAYERS if l != "M"]
+    assert idx == [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28] and len(O.vgg_table()) == 26
+    f = O.vgg_features(torch.zeros(1, 3, 32, 32), O.make_vgg_params())
+    assert [tuple(t.shape[1:]) for t in f] == [(64, 32, 32), (128, 16, 16), (256, 8, 8), (512, 4, 4), (512, 2, 2)]
+
+
 @pytest.mark.parametrize("name", ["rollout_main_s4", "rollout_reduced_s1"])
 def test_oracle_rollout_matches_reference_golden(name):
     c, z = H.load_case(name)

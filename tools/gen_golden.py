@@ -25,6 +25,10 @@ CASES = {
     "full_main_s1": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=5, H=32, W=32, gt=3, tau=0.4, hard=False, pre=False),
     "full_main_s4_hard": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=6, H=32, W=48, gt=2, tau=0.9, hard=True, pre=False),
     "pre_main_s4": dict(variant="main", K=7, Da=5, Ch=128, S=4, B=2, T=4, H=32, W=32, gt=0, tau=1.0, hard=False, pre=True),
+    # with the VGG19 perceptual term (ParallelPerceptualLoss on the seeded weights of oracle.make_vgg_params); 64x64 is the smallest frame
+    # whose quarter-resolution output still reaches relu5_1 (four 2x2 max-pools)
+    "perc_main_s1": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=4, H=64, W=64, gt=2, tau=0.6, hard=False, pre=False, perc=1.0),
+    "perc_pre_reduced_s1": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=80, gt=0, tau=1.0, hard=False, pre=True, perc=0.5),
 }
 INTERP = [(1, 2, 0.3), (0, 2, 0.8)]           # (first_action, second_action, interpolation_factor) appended to the roll-out cases
 SAMPLER_CASES = {
@@ -60,7 +64,10 @@ def main():
     import training.losses as RL
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    only = set(sys.argv[1:])           # optional: generate only the named fixtures
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         cfg, d, P, obs = case_inputs(c)
         ref = rh.build_reference_model(cfg, P)
         ref.train()
@@ -70,19 +77,44 @@ def main():
         out = ref((obs, acts, None, None), c["gt"], pretraining=c["pre"], gumbel_temperature=c["tau"])
         data = flat_outputs(out)
         data["case"] = np.array(repr(c))
-        if not c["pre"]:
+        if not c["pre"] or c.get("perc"):
             smi = RL.SmoothMutualInformationLoss(cfg)
             rec = [RL.ObservationsLoss()(obs, m) for m in out[1]]
+            li, lo = (7, 15) if c["pre"] else (6, 15)       # logits / reconstructed logits in the two tuple layouts
             comp = {
                 "rec": (sum(r.double() for r in rec) / 3),
                 "states": RL.StatesLoss()(out[3].detach(), out[2]),
-                "entropy": RL.EntropyLogitLoss()(out[6]),
+                "entropy": RL.EntropyLogitLoss()(out[li]),
                 "dir_kl": RL.KLGaussianDivergenceLoss()(out[10]),
-                "mi": smi(torch.softmax(out[6], -1), torch.softmax(out[15], -1), lamb=LOSS_W["mi_entropy"]),
+                "mi": smi(torch.softmax(out[li], -1), torch.softmax(out[lo], -1), lamb=LOSS_W["mi_entropy"]),
                 "state_kl": RL.KLGeneralGaussianDivergenceLoss()(out[18], out[12].detach()),
             }
+            if c["pre"]:
+                comp["hidden"] = RL.HiddenStatesLoss()(out[5], out[4].detach())      # trainer.py:313
             total = sum(LOSS_W[k] * v for k, v in comp.items())
+            if c.get("perc"):
+                # the perceptual part of Trainer.compute_losses (trainer.py:442-466,494-500) with the reference's own classes
+                from training.trainer import Trainer
+                ppl = RL.ParallelPerceptualLoss()
+                p_acc = torch.zeros((1,), dtype=float)
+                p_term = torch.zeros((1,), dtype=float)
+                for r, m in enumerate(out[1]):
+                    m.retain_grad()
+                    tot, comps = ppl(obs, m, None)
+                    p_acc += tot
+                    p_term += Trainer.sum_loss_components(None, comps, c["perc"])
+                    data[f"perceptual_loss_r{r}"] = np.array(tot.item())
+                    for l, cc in enumerate(comps):
+                        data[f"perceptual_loss_r{r}_l{l}"] = np.array(cc.item())
+                p_acc /= 3
+                p_term /= 3
+                comp["perceptual"] = p_acc
+                data["loss_perceptual_term"] = np.array(p_term.item())
+                total = total + p_term
             total.backward()
+            if c.get("perc"):
+                for r, m in enumerate(out[1]):
+                    data[f"dout1_{r}"] = m.grad.numpy()
             data["loss_total"] = np.array(total.item())
             for k, v in comp.items():
                 data["loss_" + k] = np.array(v.item())
@@ -108,6 +140,8 @@ def main():
     # eval-mode roll-out (play.py path): start_inference + N x generate_next, zero variation
     for name, c in {"rollout_main_s4": dict(variant="main", K=7, Da=5, Ch=128, S=4, H=32, W=32, steps=4),
                     "rollout_reduced_s1": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, H=32, W=48, steps=4)}.items():
+        if only and name not in only:
+            continue
         cc = dict(c, B=1, T=1, hard=False)
         cfg, d, P, obs = case_inputs(cc)
         ref = rh.build_reference_model(cfg, P)
@@ -135,6 +169,8 @@ def main():
     import evaluation.action_sampler as AS
     import evaluation.action_variation_sampler as AVS
     for name, c in SAMPLER_CASES.items():
+        if only and name not in only:
+            continue
         cfg, d, P, obs = case_inputs(c)
         ref = rh.build_reference_model(cfg, P)
         ref.eval()

@@ -1,10 +1,10 @@
 """Build-container-only harness that imports the REAL reference (/root/reference) on CPU.
 
 Never imported by the product, the GPU tests, smoke() or bench.py (the reference does not travel to the GPU
-box).  Used by tools/gen_golden.py (to generate tests/golden/*.npz) and by tests/test_oracle_vs_reference.py
+box).  Used by tools/gen_golden.py (to generate tests/golden/*.npz) and by tests/test_oracle.py
 (skipped when /root/reference is absent).  Shims are the ones listed in SURVEY.md section 8c: .cuda() -> identity,
-collections.Sequence alias, stub `wandb` and `torchvision` modules (random-weight VGG19 -- parity unpinned for
-the perceptual term).
+collections.Sequence alias, stub `wandb` and `torchvision` modules (VGG19 feature stack with the seeded weights of
+oracle.caddy_oracle.make_vgg_params: the pretrained values are not available offline).
 """
 import collections
 import collections.abc
@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 REF = os.environ.get("CADDY_REFERENCE", "/root/reference")
+VGG_SEED = 1234
 
 
 def available() -> bool:
@@ -47,21 +48,24 @@ def install():
         tvt = types.ModuleType("torchvision.transforms")
 
         def vgg19(pretrained=False):
+            # torchvision's VGG-19 "E" feature stack; the pretrained weights cannot be downloaded here, so the 16 conv tensors are
+            # filled from oracle.caddy_oracle.make_vgg_params (seeded; the tests re-derive the same values instead of storing them)
             cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
             layers, c = [], 3
-            g = torch.Generator().manual_seed(1234)
             for v in cfg:
                 if v == "M":
                     layers.append(nn.MaxPool2d(2, 2))
                 else:
-                    conv = nn.Conv2d(c, v, 3, padding=1)
-                    with torch.no_grad():
-                        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (c * 9)) ** 0.5)
-                        conv.bias.zero_()
-                    layers += [conv, nn.ReLU(inplace=True)]
+                    layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(inplace=True)]
                     c = v
             m = types.SimpleNamespace()
             m.features = nn.Sequential(*layers)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from oracle import caddy_oracle as O
+            V = O.make_vgg_params(VGG_SEED)
+            with torch.no_grad():
+                for k, t in m.features.state_dict().items():
+                    t.copy_(V["features." + k])
             return m
 
         tvm.vgg19 = vgg19
