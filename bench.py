@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 from playablevideogeneration_amd import configs  # noqa: E402
 from playablevideogeneration_amd.engine import Engine  # noqa: E402
-from playablevideogeneration_amd.init import init_parameters  # noqa: E402
+from playablevideogeneration_amd.init import init_parameters, random_vgg19_state  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=1)
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--no-perceptual", action="store_true", help="A/B aid: drop the VGG19 perceptual term (the reported step then says so)")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -126,9 +127,14 @@ def run(a, dev, lib=None, backend="nccl"):
 
     wl = configs.WORKLOADS[a.workload]
     B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
-    eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev, lib=lib)
+    perc = not getattr(a, "no_perceptual", False) and H >= 64 and W >= 64
+    eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev, lib=lib,
+                 perceptual=perc)
     log(f"engine created: workspace {eng.ws_bytes / 2**30:.1f} GiB, {eng.n_train} trainable floats")
     init_parameters(eng, seed=0)                            # identical replicas on every rank
+    if perc:
+        eng.load_vgg(random_vgg19_state(0))                 # VGG19 of the perceptual loss: random-init weights of the real architecture (no network)
+    loss_w = dict(configs.LOSS_WEIGHTS, perceptual=configs.LOSS_WEIGHTS["perceptual"] if perc else 0.0)
     log("parameters initialised")
     if world > 1:
         # global-batch centroid sums + MI joint matrix (tiny all-reduces) and the bucketed gradient all-reduce (CADDY_DP_OVERLAP=0: one flat all-reduce)
@@ -140,7 +146,7 @@ def run(a, dev, lib=None, backend="nccl"):
     def step():
         step_no[0] += 1
         eng.forward_full(obs, wl["gt_init"], wl["tau"], make_noise(B, T, K, Da, dev, gen), training=True, fetch_outputs=False)
-        losses = eng.loss_backward(configs.LOSS_WEIGHTS, smooth_mi=True)
+        losses = eng.loss_backward(loss_w, smooth_mi=True)
         if world > 1:
             eng.allreduce_gradients()                       # R / D buckets (91 % of 39.4 MB) were started behind the side stream during the backward; the rest here
         eng.adam_step(step_no[0], lr=4e-4, weight_decay=1e-6, grad_scale=1.0 / world)
@@ -208,7 +214,8 @@ def run(a, dev, lib=None, backend="nccl"):
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": a.workload, "variant": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
-                          "step": "forward_full_model + L1/states/KL/MI losses + BPTT backward + grad all-reduce + Adam (VGG perceptual term excluded: weights unavailable offline)"},
+                          "step": "forward_full_model + L1 / VGG19-perceptual / states / KL / MI losses + BPTT backward + grad all-reduce + Adam"
+                                  + (" (VGG19: random-init weights)" if perc else " (VGG19 perceptual term DISABLED by --no-perceptual)")},
                "loss": losses["total"], "roofline": roof}
         if world == 1 and not a.no_rollout and on_gpu:
             del eng

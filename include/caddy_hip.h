@@ -30,6 +30,9 @@ typedef struct caddy_config {
     int hidden;         /* model.dynamics_network.hidden_state_size (128 main / 64 reduced) */
     int use_gumbel, hard_gumbel, use_variations;   /* model.action_network.* */
     float centroid_alpha;                          /* model.centroid_estimator.alpha */
+    int perceptual;     /* != 0: the context also holds the VGG19 perceptual loss (training/losses.py:379-491): the workspace grows by the
+                           packed VGG19 weights and feature maps, caddy_load_vgg must be called before a caddy_loss_backward with
+                           caddy_loss_cfg.perceptual != 0 */
 } caddy_config;
 
 typedef struct caddy_param_info {
@@ -49,17 +52,25 @@ typedef struct caddy_noise {
     const float* eps_dirs_rec;
 } caddy_noise;
 
-/* Loss weights of Trainer.compute_losses (training/trainer.py:494-500); the VGG perceptual term is not part of this
- * library ("parity unpinned"). mi_ema: SmoothMutualInformationLoss state (K*K floats, device) or NULL. */
+/* Loss weights of Trainer.compute_losses (training/trainer.py:494-500).  mi_ema: SmoothMutualInformationLoss state (K*K floats,
+ * device) or NULL.  perceptual: loss_weights.perceptual_loss_lambda[_pretraining] (training/trainer.py:283,442) -- the VGG19 term of
+ * ParallelPerceptualLoss (training/losses.py:379-491); non-zero requires caddy_config.perceptual and a preceding caddy_load_vgg.
+ * perceptual_log: evaluate and report the perceptual losses even when the weight is 0 (the reference always logs them). */
 typedef struct caddy_loss_cfg {
     double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda;
     float* mi_ema;
     float mi_ema_alpha;
     int update_mi_ema;
+    double perceptual;
+    int perceptual_log;
 } caddy_loss_cfg;
 
+/* losses_host slots.  CADDY_LOSS_PERCEPTUAL = avg_perceptual_loss, _TERM = loss_component_perceptual_loss (trainer.py:505,512);
+ * CADDY_LOSS_PERC_R0 + 6 r = perceptual_loss_r{r}, + 1 + l = perceptual_loss_r{r}_l{l} -- l = 0 equals the resolution's total, exactly as the
+ * reference logs it (in-place aliasing at training/losses.py:483-487, which also makes levels 1..4 count twice in the term). */
 enum { CADDY_LOSS_TOTAL = 0, CADDY_LOSS_REC, CADDY_LOSS_STATES, CADDY_LOSS_ENTROPY, CADDY_LOSS_DIRKL, CADDY_LOSS_MI,
-       CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2, CADDY_LOSS_SLOTS = 16 };
+       CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2,
+       CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12, CADDY_LOSS_PERC_R0 = 16, CADDY_LOSS_SLOTS = 40 };
 
 /* Output ids of caddy_get_output: 0..19 = positions of the 20-tuple returned by Model.forward_full_model
  * (model/main_model/model.py:280-286); 100+r = r-th entry of the multi-resolution list (tuple position 1). */
@@ -72,6 +83,17 @@ int caddy_param_count(const caddy_config* cfg);
 int caddy_param_info_get(const caddy_config* cfg, int index, caddy_param_info* out);
 long caddy_param_floats(const caddy_config* cfg);       /* size of the flat parameter buffer (all kinds) */
 long caddy_trainable_floats(const caddy_config* cfg);   /* kind-0 entries come first: [0, trainable) */
+
+/* --- VGG19 weights of the perceptual loss: replaces torchvision.models.vgg19(pretrained=True).features inside Vgg19.__init__
+ *     (model/layers/vgg.py:16-34).  The 13 convolutions the reference's slices evaluate (features.0 ... features.28; conv5_2..5_4 are
+ *     loaded by torchvision but never run), names / shapes / float offsets per caddy_vgg_param_info_get (kind = 3), OIHW fp32.
+ *     caddy_load_vgg packs them into the workspace (frozen: once, not per step); `vgg_flat` is not referenced afterwards. --- */
+int caddy_vgg_param_count(void);
+int caddy_vgg_param_info_get(int index, caddy_param_info* out);
+long caddy_vgg_param_floats(void);
+int caddy_load_vgg(caddy_ctx* ctx, const float* vgg_flat);
+/* ConvArgs.precision of the VGG convolutions: forward (both branches) and dgrad.  See DESIGN.md "numerics". */
+int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
 
 /* --- context --- */
 size_t caddy_workspace_bytes(const caddy_config* cfg);
@@ -119,7 +141,7 @@ int caddy_get_output(caddy_ctx* ctx, int id, void* dst);      /* copy one output
  * available for ids 0, 100-102, 2, 3, 4, 6, 8, 9, 10, 12, 15, 16, 18. */
 int caddy_get_output_grad(caddy_ctx* ctx, int id, void* dst);
 
-/* --- losses + loss.backward(): training/trainer.py:447-500,585 fused into one pass (L1 multi-resolution, states MSE,
+/* --- losses + loss.backward(): training/trainer.py:447-500,585 fused into one pass (L1 multi-resolution, VGG19 perceptual, states MSE,
  *     entropy, direction KL, (smooth) mutual information, action-state KL) followed by BPTT through D, R, E, A.
  *     Gradients land in the flat gradient buffer (reference layout).  losses_host: CADDY_LOSS_SLOTS doubles (host). --- */
 int caddy_loss_backward(caddy_ctx* ctx, const caddy_loss_cfg* cfg, double* losses_host);
@@ -140,6 +162,9 @@ int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, co
  *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
 /* test aid: NaN-fill the not-zero-filled (first-touch) part of the gradient arena before every backward pass */
 int caddy_debug_set_poison(caddy_ctx* ctx, int on);
+/* test aid: caddy_loss_backward stops after the loss kernels, so caddy_get_output_grad returns the gradient of the DIRECT loss terms only
+ * (what autograd holds in `.grad` of the stacked output tensors, which the D->E feedback does not read) */
+int caddy_debug_set_seeds_only(caddy_ctx* ctx, int on);
 int caddy_profile_begin(caddy_ctx* ctx);
 int caddy_profile_end(caddy_ctx* ctx, double* out52);
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each

@@ -5,8 +5,8 @@ BAIR = dict(variant="main", actions=7, action_dim=2, hidden=128, stacking=1)    
 BREAKOUT = dict(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1)  # configs/02_breakout.yaml
 TENNIS = dict(variant="main", actions=7, action_dim=5, hidden=128, stacking=4)      # configs/03_tennis.yaml
 
-# training/trainer.py:494-500 weights of configs/01_bair.yaml:122-156 (perceptual term excluded)
-LOSS_WEIGHTS = dict(rec=1.0, states=0.2, entropy=0.0, dir_kl=1e-4, mi=0.15, state_kl=0.0, mi_entropy=1.0)
+# training/trainer.py:494-500 weights of configs/01_bair.yaml:122-156 (perceptual_loss_lambda: 1.0 there)
+LOSS_WEIGHTS = dict(rec=1.0, states=0.2, entropy=0.0, dir_kl=1e-4, mi=0.15, state_kl=0.0, mi_entropy=1.0, perceptual=1.0)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the headline metric is quoted on

@@ -47,7 +47,7 @@ struct ConvArgs {
     int Ktot;           // sum of Cpad
     int Cout, Cout_pad; // Cout_pad multiple of the N tile
     const float* bias;  // nullable, [Cout]
-    int act;            // 0 none, 1 tanh
+    int act;            // 0 none, 1 tanh, 2 ReLU
     float* out;
     long out_sn;
     int out_ld;
@@ -58,6 +58,12 @@ struct ConvArgs {
     float* split_scratch;   // optional: deterministic split-K of under-filled NON-accumulating launches (slabs + fixed-order reduce)
     long split_cap;         // capacity of split_scratch in floats
     long split_stride;      // set by the launcher: slab stride in floats (0 = atomics)
+    // dgrad through a ReLU, fused into the epilogue (VGG19 perceptual loss, perceptual.hip): out = result * (mask > 0); with seed_ref also the
+    // L1 feature-loss gradient seed of a tapped feature map: result += seed_w * sign(mask - seed_ref) before masking.  mask / seed_ref have
+    // the geometry of `out` (out_sn, out_ld).
+    const float* mask;
+    const float* seed_ref;
+    float seed_w;
 };
 constexpr int CONV_AUX_BYTES = 128 * 1024;
 

@@ -310,6 +310,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
                 if (off < 0) continue;
                 float v = acc[i][j][r] + bv;
                 if (a.act == 1) v = tanhf(v);
+                else if (a.act == 2) v = fmaxf(v, 0.f);
+                if (a.mask) {
+                    const float m = a.mask[off + col];
+                    if (a.seed_ref) { const float d = m - a.seed_ref[off + col]; v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
+                    v = m > 0.f ? v : 0.f;
+                }
                 float* o = a.out + off + col;
                 if (a.splitk > 1) { if (a.split_stride) o[blockIdx.z * a.split_stride] = v; else atomicAdd(o, v); }
                 else { if (a.accumulate) v += *o; *o = v; }
@@ -687,9 +693,13 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
-    if (conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
-    if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
-    if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)
+    const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
+    if (a.seed_ref && !a.mask) return -1;
+    if (!generic_only) {
+        if (conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
+        if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
+        if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)
+    }
     long P = (long)a.N * a.H * a.W;
     // tile choice: 128-row tiles when they fill the chip (256 CUs x ~3 resident workgroups), otherwise 64x64 tiles; the
     // remaining deficit of accumulating launches (dgrad) is covered by splitting K across blockIdx.z (fp32 atomics).
@@ -702,17 +712,17 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
-    if (a.accumulate && a.act == 0 && a.bias == nullptr && blocks < 384 && niter >= 16 && a.KS == 3) {
+    if (a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && blocks < 384 && niter >= 16 && a.KS == 3) {
         int want = (int)((512 + blocks - 1) / blocks);
         a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
     }
-    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
+    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
     // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
     // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
     a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
-    if (!a.accumulate && a.split_scratch && !no_fsplit && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
+    if (!a.accumulate && a.split_scratch && !no_fsplit && !generic_only && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
         int want = (int)((512 + blocks - 1) / blocks);
         int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
         int ldc = round_up(a.Cout, 4);

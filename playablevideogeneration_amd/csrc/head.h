@@ -3,9 +3,11 @@
 
 #define AUX_LD 16   // per-(b,t) auxiliary input row of R: [action sample (K) | variation (Da) | zero pad]
 
-enum { LOSS_TOTAL = 0, LOSS_REC, LOSS_STATES, LOSS_ENTROPY, LOSS_DIRKL, LOSS_MI, LOSS_STATEKL, LOSS_HIDDEN, LOSS_L1_R0, LOSS_L1_R1, LOSS_L1_R2, LOSS_SLOTS = 16 };
+// LOSS_PERC_R0 + 6 r: perceptual_loss_r{r}; + 1 + l: perceptual_loss_r{r}_l{l} (l = 0 aliases the total, as in the reference -- perceptual.hip)
+enum { LOSS_TOTAL = 0, LOSS_REC, LOSS_STATES, LOSS_ENTROPY, LOSS_DIRKL, LOSS_MI, LOSS_STATEKL, LOSS_HIDDEN, LOSS_L1_R0, LOSS_L1_R1, LOSS_L1_R2,
+       LOSS_PERCEPTUAL = 11, LOSS_PERCEPTUAL_TERM = 12, LOSS_PERC_R0 = 16, LOSS_SLOTS = 40 };
 
-struct LossWeights { double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda; };
+struct LossWeights { double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda, perceptual; };
 
 // linear layers of the action network (boundary layout, straight views into the flat parameter / gradient buffers)
 struct HeadParams {
@@ -55,7 +57,8 @@ int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, h
 int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
 int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, const SamplerHooks* sh, hipStream_t st);
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st);
-int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st);
+int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out /* nullable: resized ground truth (N,H,W,3) pitch 4 */, hipStream_t st);
 int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st);
 int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStream_t st);
-int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, hipStream_t st);
+struct VggLevels;
+int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, const VggLevels* lv /* nullable */, hipStream_t st);

@@ -4,6 +4,7 @@
 // roofline-relevant; the L1 / MSE losses over frames and states are HBM-bound streaming reductions.
 #include "common.h"
 #include "head.h"
+#include "perceptual.h"
 
 namespace {
 
@@ -210,7 +211,7 @@ __global__ void k_head_bwd3(HeadBufs h, HeadParams p, int NBT) {
 // ---- losses ------------------------------------------------------------------------------------------------------------
 // L1 between the resized ground-truth frame and a reconstruction (ObservationsLoss, losses.py:61-118): bilinear with
 // align_corners=False at integer factors 1 / 2 / 4 == identity / 2x2 mean / mean of the central 2x2 of each 4x4 block.
-__global__ __launch_bounds__(256) void k_loss_l1(TV gt, TV rec, TV drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc) {
+__global__ __launch_bounds__(256) void k_loss_l1(TV gt, TV rec, TV drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out) {
     __shared__ double sh[8];
     const int HW = rec.H * rec.W;
     const long npix = (long)rec.N * HW;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_loss_l1(TV gt, TV rec, TV drec, int f, 
                 const float* gp = g + ((long)y0 * gt.W + x0) * gt.ld + ch;
                 gv = 0.5f * (0.5f * gp[0] + 0.5f * gp[gt.ld]) + 0.5f * (0.5f * gp[(long)gt.W * gt.ld] + 0.5f * gp[(long)(gt.W + 1) * gt.ld]);
             }
+            if (gt_out) gt_out[q * 4 + ch] = gv;       // the resized ground truth is also the input of the VGG19 ground-truth branch (perceptual.hip)
             float d = r[ch] - gv;
             s += fabsf(d);
             dr[ch] += gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
@@ -359,7 +361,7 @@ __global__ void k_loss_small(SmallLossArgs a) {
         a.acc[LOSS_STATEKL] = 0.5 * skl / NT;
     }
 }
-__global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1, double n2, double nstates, double nhidden) {
+__global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1, double n2, double nstates, double nhidden, VggLevels lv, int have_vgg) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double r0 = acc[LOSS_L1_R0] / n0, r1 = acc[LOSS_L1_R1] / n1, r2 = acc[LOSS_L1_R2] / n2;
     acc[LOSS_L1_R0] = r0; acc[LOSS_L1_R1] = r1; acc[LOSS_L1_R2] = r2;
@@ -368,6 +370,20 @@ __global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1
     acc[LOSS_HIDDEN] = nhidden > 0 ? acc[LOSS_HIDDEN] / nhidden : 0.0;
     acc[LOSS_TOTAL] = w.rec * acc[LOSS_REC] + w.states * acc[LOSS_STATES] + w.entropy * acc[LOSS_ENTROPY] + w.dir_kl * acc[LOSS_DIRKL] +
                       w.mi * acc[LOSS_MI] + w.state_kl * acc[LOSS_STATEKL] + w.hidden * acc[LOSS_HIDDEN];
+    if (have_vgg) {
+        // trainer.py:447-466: float64 accumulators over the resolutions.  Level 0 handed to sum_loss_components IS the total (in-place
+        // aliasing, losses.py:483-487), hence term_r = lambda * (total_r + l1 + l2 + l3 + l4) and the logged l0 equals the total.
+        double avg = 0.0, term = 0.0;
+        for (int r = 0; r < 3; r++) {
+            double* s = acc + LOSS_PERC_R0 + 6 * r;
+            double tot = 0.0, rest = 0.0;
+            for (int l = 0; l < 5; l++) { s[1 + l] = s[1 + l] / lv.numel[r][l]; tot += s[1 + l]; if (l > 0) rest += s[1 + l]; }
+            s[0] = tot; s[1] = tot;
+            avg += tot; term += w.perceptual * (tot + rest);
+        }
+        acc[LOSS_PERCEPTUAL] = avg / 3.0; acc[LOSS_PERCEPTUAL_TERM] = term / 3.0;
+        acc[LOSS_TOTAL] += term / 3.0;
+    }
 }
 __global__ void k_softmax_rows(const float* logits, float* prob, float* logp, int NS, int K) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,10 +431,10 @@ int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, in
     hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 64)), dim3(64), 0, st, h, p, B * T);
     return 0;
 }
-int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, hipStream_t st) {
+int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out, hipStream_t st) {
     long npix = (long)rec.N * rec.H * rec.W;
     long blocks = (npix + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_loss_l1, dim3((unsigned)blocks), dim3(256), 0, st, gt, rec, drec, f, t_off, Tobs, Trec, gscale, acc);
+    hipLaunchKernelGGL(k_loss_l1, dim3((unsigned)blocks), dim3(256), 0, st, gt, rec, drec, f, t_off, Tobs, Trec, gscale, acc, gt_out);
     return 0;
 }
 int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st) {
@@ -434,7 +450,8 @@ int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStr
     hipLaunchKernelGGL(k_loss_small, dim3(1), dim3(256), 0, st, a);
     return 0;
 }
-int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, hipStream_t st) {
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden);
+int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, const VggLevels* lv, hipStream_t st) {
+    VggLevels l{}; if (lv) l = *lv;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden, l, lv ? 1 : 0);
     return 0;
 }

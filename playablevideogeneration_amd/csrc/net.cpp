@@ -214,6 +214,7 @@ void build_layers(caddy_ctx* c) {
         for (int i = 0; i < 3; i++) { c->d_up[i].early_bucket = true; c->d_final[i].early_bucket = true; }
         for (int i = 0; i < 2; i++) { c->d_res[i].conv1.early_bucket = c->d_res[i].conv2.early_bucket = true; if (c->d_res[i].has_down) c->d_res[i].down.early_bucket = true; }
     }
+    if (g.perceptual) vgg_build(c);
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
@@ -257,7 +258,8 @@ int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     if (!prof) return conv_fwd_launch(a, stream);
     int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
     const double px = (double)a.N * a.H * a.W;   // algorithmic bytes: 4 * (|in| + |out| + |W|)
-    ProfRec r{ev(), ev(), 0, flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, a.accumulate ? 1 : 0, 4.0 * (px * cin + px * a.Cout + (double)a.KS * a.KS * a.Ktot * a.Cout)};
+    ProfRec r{ev(), ev(), 0, flops, a.N * a.H * a.W, a.Ktot, a.Cout, a.KS, prof_kind_override >= 0 ? prof_kind_override : (a.accumulate ? 1 : 0),
+              4.0 * (px * cin + px * a.Cout + (double)a.KS * a.KS * a.Ktot * a.Cout)};
     hipEventRecord(r.a, stream);
     int rc = conv_fwd_launch(a, stream);
     hipEventRecord(r.b, stream);
@@ -703,6 +705,8 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     }
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
+    c->fwd_off = c->act.off;
+    if (dry && g.perceptual) { T4 gi[3]; VggLevels lv; c->alloc_gt_images(gi, T - 1); vgg_perceptual(c, 1.0, gi, &lv); c->act.off = c->fwd_off; }      // workspace sizing
     c->have_forward = true;
     return finish(c);
 }
@@ -763,8 +767,19 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     c->encode(stacked, true, &c->rec_x65);
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
+    c->fwd_off = c->act.off;
+    if (dry && g.perceptual) { T4 gi[3]; VggLevels lv; c->alloc_gt_images(gi, T); vgg_perceptual(c, 1.0, gi, &lv); c->act.off = c->fwd_off; }
     c->have_forward = true;
     return finish(c);
+}
+
+// resized ground-truth frames (N, H >> r, W >> r, 3) pitch 4: input of the VGG19 ground-truth branch, written by loss_l1
+void caddy_ctx::alloc_gt_images(T4* gi, int Trec) {
+    for (int r = 0; r < 3; r++) {
+        const int N = cfg.batch * Trec, H = cfg.height >> r, W = cfg.width >> r;
+        float* d = (float*)act.alloc((size_t)N * H * W * 4 * 4);
+        gi[r] = T4{d, (float*)((char*)d + grad_delta), N, H, W, 3, (long)H * W * 4, 4, true};
+    }
 }
 
 static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_host) {
@@ -773,6 +788,10 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     const int B = g.batch, T = g.seq_len, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
     hipStream_t st = c->stream;
+    const bool perc = c->cfg.perceptual && (lc->perceptual != 0.0 || lc->perceptual_log);
+    if (lc->perceptual != 0.0 && !c->cfg.perceptual) { set_error("caddy_loss_cfg.perceptual != 0 needs a context created with caddy_config.perceptual = 1"); return -2; }
+    if (perc && !c->vgg.loaded) { set_error("perceptual loss requested but no VGG19 weights were loaded (caddy_load_vgg)"); return -2; }
+    c->act.off = c->fwd_off;                  // release what a previous loss_backward allocated past the forward graph
     if (!dry) {
         hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);   // (zero-filling on the side stream during the forward pass was measured: no gain, the step is throughput-bound)
         static const bool poison_env = getenv("CADDY_POISON_NZ") != nullptr;   // test aid: NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
@@ -784,14 +803,18 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     }
     if (!dry) c->ensure_side();
     c->sev_used = 0;
-    LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda};
+    LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda, lc->perceptual};
     double nr[3];
+    const int Trec = c->pretraining ? T : T - 1;      // pretraining reconstructs all T frames (losses.py:83-87)
+    T4 gt_img[3]{};
+    if (perc) c->alloc_gt_images(gt_img, Trec);
     for (int r = 0; r < 3; r++) {
         const T4& f = c->frames[r];
         nr[r] = (double)f.N * 3 * f.H * f.W;
-        const int Trec = c->pretraining ? T : T - 1;      // pretraining reconstructs all T frames (losses.py:83-87)
-        if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, c->pretraining ? 0 : 1, T, Trec, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, st), "loss_l1");
+        if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, c->pretraining ? 0 : 1, T, Trec, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, perc ? gt_img[r].d : nullptr, st), "loss_l1");
     }
+    VggLevels lv{};
+    if (perc) vgg_perceptual(c, lc->perceptual, gt_img, &lv);      // VGG19 features of both branches + d(term)/d(rec_r) added to the L1 seeds
     T4 sa = chan(c->x65_gt, 0, 64), sb = chan(c->rec_x65, 0, 64);
     double nst = (double)sa.N * 64 * sa.H * sa.W;
     if (!dry) c->ck(loss_mse(dv(sa), dv(sb), gv(sb), (float)(w.states / nst), c->loss_acc + LOSS_STATES, st), "loss_mse");
@@ -816,7 +839,11 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     a.Pbuf = c->q_prob + (size_t)B * (T - 1) * K;      // K*K floats allocated behind q_prob
     a.mi_grad_scale = (float)(c->hook ? c->world : 1);
     if (!dry) c->ck(loss_small(a, c->hook, c->hook_user, st), "loss_small");
-    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, st), "loss_finalize");
+    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize");
+    if (c->seeds_only) {      // test aid (caddy_debug_set_seeds_only): stop after the loss kernels -- the gradient arena holds d(loss)/d(output) of the direct loss terms only
+        if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
+        return finish(c);
+    }
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     c->flush_all_wgrad();
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
@@ -928,6 +955,10 @@ static bool check_cfg(const caddy_config* g) {
         set_error("invalid caddy_config (H, W multiples of 16; hidden 128 for main / 64 for reduced; K<=16; Da<=8)");
         return false;
     }
+    if (g->perceptual && (g->height < 64 || g->width < 64)) {      // the quarter-resolution image must survive four 2x2 max-pools (relu5_1)
+        set_error("caddy_config.perceptual needs frames of at least 64x64 (VGG19 relu5_1 at a quarter of the resolution)");
+        return false;
+    }
     return true;
 }
 static caddy_ctx* make_ctx(const caddy_config* cfg, float* params, float* grads, void* ws, size_t act_cap) {
@@ -989,6 +1020,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
+int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }
 int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
     c->samplers = SamplerHooks{};
@@ -1022,6 +1054,15 @@ int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float 
     if (!rc && hi < c->n_train) rc = adam_launch(c->P + hi, c->G + hi, m + hi, v + hi, c->n_train - hi, lr, b1, b2, eps, wd, step, gscale, c->stream);
     return rc;
 }
+int caddy_vgg_param_count(void) { return vgg_param_count(); }
+int caddy_vgg_param_info_get(int index, caddy_param_info* out) { return vgg_param_info(index, out); }
+long caddy_vgg_param_floats(void) { return vgg_param_floats(); }
+int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
+    c->fail = false;
+    if (!vgg_flat) { set_error("null input"); return -2; }
+    return vgg_load(c, vgg_flat);
+}
+int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
 int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     c->fail = false;

@@ -9,6 +9,7 @@
 #include "head.h"
 #include "pack.h"
 #include "pointwise.h"
+#include "perceptual.h"
 
 struct T4 {            // activation + gradient views with identical geometry
     float* d; float* g;
@@ -104,7 +105,12 @@ struct caddy_ctx {
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
+    VggState vgg;                    // VGG19 perceptual loss (perceptual.hip); enabled by caddy_config.perceptual
+    int vgg_precision = 0, vgg_precision_bwd = 0;   // ConvArgs.precision of the VGG convolutions (forward / dgrad)
+    size_t fwd_off = 0;              // act.off at the end of the last forward: loss_backward allocates its VGG buffers past it and releases them
+    int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1
     bool have_forward = false;
+    bool seeds_only = false;         // caddy_debug_set_seeds_only: caddy_loss_backward stops after the loss kernels (tests of the loss gradient seeds)
     bool poison_nz = false;          // caddy_debug_set_poison: NaN-fill the first-touch gradient region before every backward (tests)
     int hs, ws;   // state resolution
 
@@ -147,6 +153,7 @@ struct caddy_ctx {
     void action_net(const T4& x65, HeadState& hs_, const float* eps_s, const float* eps_d, const float* unif, bool first,
                     const float* samples_in, const float* variations_in);
     void copy_op(const T4& src, const T4& dst);
+    void alloc_gt_images(T4* gi, int Trec);
     void pack_all();
     void unpack_all();
     void ck(int rc, const char* what);

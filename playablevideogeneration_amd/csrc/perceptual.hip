@@ -1,0 +1,269 @@
+// VGG19 perceptual loss, forward + input gradient, fused into caddy_loss_backward.
+//
+// Reference: training/losses.py:379-491 (ParallelPerceptualLoss -> UnmeanedPerceptualLoss), model/layers/vgg.py:8-56 (slices of
+// torchvision's vgg19().features up to relu5_1), training/trainer.py:442-466,494-500 (per-resolution sum, sum_loss_components, the
+// term in the total loss).  Per resolution r in {1, 1/2, 1/4}: VGG19 features of the bilinearly resized ground truth (no gradient) and of
+// the reconstruction at relu1_1 .. relu5_1, per level mean |f_gt - f_rec|, and the gradient of the weighted sum w.r.t. the reconstruction
+// (the VGG weights are frozen: dgrad only, no wgrad).  Inputs in [-1, 1] are fed as they are -- the reference applies no ImageNet
+// normalisation.
+//
+// Reference quirk reproduced on purpose (pinned by tests/golden/perc_*.npz): losses.py:483-487 binds `total_loss` to the level-0 tensor
+// and then accumulates the other levels into it IN PLACE, so the "level 0" entry handed to Trainer.sum_loss_components IS the total:
+//   term_r = lambda * (l0 + 2 (l1 + l2 + l3 + l4)),   logged perceptual_loss_r{r}_l0 == perceptual_loss_r{r}.
+//
+// Convolutions run on the conv kernels of this library (13 x conv3x3 + bias + ReLU forward on 2N images per resolution; the dgrad of the
+// reconstruction branch with the ReLU mask and the L1 seed of the tapped feature maps fused into the epilogue: ConvArgs.mask / seed_ref).
+// The kernels here are the 2x2 max-pool (forward; backward fused with the ReLU mask of the layer below) and the feature L1.
+#include "net.h"
+#include "perceptual.h"
+#include <cstdio>
+#include <cstring>
+
+#define RUN_CK(c, expr) do { if (!(c)->dry) (c)->ck((expr), #expr); } while (0)
+
+namespace {
+
+// torchvision vgg19().features: (index, Cin, Cout) of the 13 convolutions the reference evaluates; pool_before: MaxPool2d(2,2) on the input
+struct VggSpec { int idx, cin, cout, pool_before, tap; };
+const VggSpec VGG[VGG_NCONV] = {
+    {0, 3, 64, 0, 0}, {2, 64, 64, 0, -1}, {5, 64, 128, 1, 1}, {7, 128, 128, 0, -1}, {10, 128, 256, 1, 2}, {12, 256, 256, 0, -1}, {14, 256, 256, 0, -1},
+    {16, 256, 256, 0, -1}, {19, 256, 512, 1, 3}, {21, 512, 512, 0, -1}, {23, 512, 512, 0, -1}, {25, 512, 512, 0, -1}, {28, 512, 512, 1, 4}};
+
+// MaxPool2d(2, 2) on dense NHWC maps; odd sizes floor like torch (the last row / column is not covered by any window)
+__global__ __launch_bounds__(256) void k_maxpool2(const float* in, float* out, long n_out4, int Hi, int Wi, int C4) {
+    const int Ho = Hi >> 1, Wo = Wi >> 1;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n_out4; i += (long)gridDim.x * 256) {
+        int c = (int)(i % C4); long q = i / C4; int x = (int)(q % Wo); q /= Wo; int y = (int)(q % Ho); long n = q / Ho;
+        const float4* p = reinterpret_cast<const float4*>(in) + ((n * Hi + 2 * y) * (long)Wi + 2 * x) * C4 + c;
+        float4 a = p[0], b = p[C4], d = p[(long)Wi * C4], e = p[(long)Wi * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x)); m.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+        m.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z)); m.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+        reinterpret_cast<float4*>(out)[i] = m;
+    }
+}
+// gradient of [ReLU -> MaxPool2d(2,2)] in one pass: gz[pos] = g_pooled[window] if pos is the window's first maximum (torch's tie rule: strict >,
+// scan order (0,0),(0,1),(1,0),(1,1)) and a[pos] > 0, else 0.  Every position of gz is ASSIGNED (no zero-fill needed), including the
+// uncovered last row / column of odd-sized maps (zero).
+__device__ __forceinline__ void route4(float a0, float a1, float a2, float a3, float g, float& z0, float& z1, float& z2, float& z3) {
+    int k = 0; float m = a0;
+    if (a1 > m) { m = a1; k = 1; }
+    if (a2 > m) { m = a2; k = 2; }
+    if (a3 > m) { m = a3; k = 3; }
+    const float v = m > 0.f ? g : 0.f;
+    z0 = k == 0 ? v : 0.f; z1 = k == 1 ? v : 0.f; z2 = k == 2 ? v : 0.f; z3 = k == 3 ? v : 0.f;
+}
+__global__ __launch_bounds__(256) void k_maxpool2_bwd_relu(const float* a, const float* gp, float* gz, long n_win4, int Hi, int Wi, int C4) {
+    const int Ho = Hi >> 1, Wo = Wi >> 1, Hc = (Hi + 1) >> 1, Wc = (Wi + 1) >> 1;      // windows incl. the partial ones of odd sizes
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n_win4; i += (long)gridDim.x * 256) {
+        int c = (int)(i % C4); long q = i / C4; int x = (int)(q % Wc); q /= Wc; int y = (int)(q % Hc); long n = q / Hc;
+        const long base = ((n * Hi + 2 * y) * (long)Wi + 2 * x) * C4 + c;
+        const long o1 = C4, o2 = (long)Wi * C4, o3 = o2 + C4;
+        float4* z = reinterpret_cast<float4*>(gz) + base;
+        if (y >= Ho || x >= Wo) {      // partial window: no pooled output reads these positions
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[0] = zero;
+            if (2 * x + 1 < Wi) z[o1] = zero;
+            if (2 * y + 1 < Hi) { z[o2] = zero; if (2 * x + 1 < Wi) z[o3] = zero; }
+            continue;
+        }
+        const float4* p = reinterpret_cast<const float4*>(a) + base;
+        const float4 A = p[0], B = p[o1], D = p[o2], E = p[o3], G = reinterpret_cast<const float4*>(gp)[((n * Ho + y) * (long)Wo + x) * C4 + c];
+        float4 zA, zB, zD, zE;
+        route4(A.x, B.x, D.x, E.x, G.x, zA.x, zB.x, zD.x, zE.x);
+        route4(A.y, B.y, D.y, E.y, G.y, zA.y, zB.y, zD.y, zE.y);
+        route4(A.z, B.z, D.z, E.z, G.z, zA.z, zB.z, zD.z, zE.z);
+        route4(A.w, B.w, D.w, E.w, G.w, zA.w, zB.w, zD.w, zE.w);
+        z[0] = zA; z[o1] = zB; z[o2] = zD; z[o3] = zE;
+    }
+}
+// sum |f_rec - f_gt| over a dense feature map (double atomics per block); optionally the masked L1 seed of the top level:
+// gz = seed_w * sign(f_rec - f_gt) where f_rec > 0 (the ReLU that produced f_rec), else 0
+__global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* gt, long n4, float seed_w, float* gz, double* acc) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 r = reinterpret_cast<const float4*>(rec)[i], g = reinterpret_cast<const float4*>(gt)[i];
+        const float d[4] = {r.x - g.x, r.y - g.y, r.z - g.z, r.w - g.w};
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            s += (double)fabsf(d[e]);
+            z[e] = rv[e] > 0.f ? (d[e] > 0.f ? seed_w : (d[e] < 0.f ? -seed_w : 0.f)) : 0.f;
+        }
+        if (gz) reinterpret_cast<float4*>(gz)[i] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+__global__ void k_copy_f(const float* src, float* dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+inline unsigned grid_for(long items) { long b = (items + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+T4 valloc(caddy_ctx* c, int N, int H, int W, int C) {      // bottom-up allocation past the forward graph (released per resolution); gradient at the mirror
+    const int ld = round_up(C, 4);
+    float* d = (float*)c->act.alloc((size_t)N * H * W * ld * 4);
+    return T4{d, (float*)((char*)d + c->grad_delta), N, H, W, C, (long)H * W * ld, ld, true};
+}
+}  // namespace
+
+int vgg_param_count() { return 2 * VGG_NCONV; }
+long vgg_param_floats() {
+    long n = 0;
+    for (int i = 0; i < VGG_NCONV; i++) n += (long)VGG[i].cout * VGG[i].cin * 9 + round_up(VGG[i].cout, 4);
+    return n;
+}
+int vgg_param_info(int index, caddy_param_info* out) {
+    if (index < 0 || index >= 2 * VGG_NCONV) return -1;
+    long off = 0;
+    for (int i = 0; i < VGG_NCONV; i++) {
+        const long nw = (long)VGG[i].cout * VGG[i].cin * 9;
+        if (index == 2 * i || index == 2 * i + 1) {
+            memset(out, 0, sizeof(*out));
+            const bool w = index == 2 * i;
+            snprintf(out->name, sizeof(out->name), "features.%d.%s", VGG[i].idx, w ? "weight" : "bias");
+            out->offset = w ? off : off + nw; out->kind = 3;
+            if (w) { out->ndim = 4; out->shape[0] = VGG[i].cout; out->shape[1] = VGG[i].cin; out->shape[2] = 3; out->shape[3] = 3; }
+            else { out->ndim = 1; out->shape[0] = VGG[i].cout; out->shape[1] = out->shape[2] = out->shape[3] = 1; }
+            return 0;
+        }
+        off += nw + round_up(VGG[i].cout, 4);
+    }
+    return -1;
+}
+
+// persistent packed weights (forward + dgrad form) and biases: carved out of the caller's workspace when caddy_config.perceptual != 0
+void vgg_build(caddy_ctx* c) {
+    VggState& V = c->vgg;
+    V.enabled = true; V.loaded = false;
+    for (int i = 0; i < VGG_NCONV; i++) {
+        VggLayer& L = V.conv[i];
+        PackDesc& d = L.pd;
+        d = PackDesc{};
+        d.nw = 1; d.Co_each = VGG[i].cout; d.Cin = VGG[i].cin; d.KS = 3; d.nseg = 1;
+        d.seg_off[0] = 0; d.seg_C[0] = VGG[i].cin; d.seg_Cpad[0] = round_up(VGG[i].cin, CONV_BK);
+        d.Cout = VGG[i].cout; d.Cout_pad = round_up(d.Cout, conv_pick_bn(d.Cout)); d.Ktot = d.seg_Cpad[0];
+        L.wp = (float*)c->persist.alloc((size_t)9 * d.Cout_pad * d.Ktot * 4);
+        L.kd = round_up(d.Cout, CONV_BK);
+        L.cd_pad = round_up(VGG[i].cin, conv_pick_bn(VGG[i].cin));
+        L.wpd = (float*)c->persist.alloc((size_t)9 * L.cd_pad * L.kd * 4);
+        L.bias = (float*)c->persist.alloc((size_t)round_up(d.Cout, 4) * 4);
+    }
+}
+
+// caddy_load_vgg: `flat` = device buffer laid out per vgg_param_info (torchvision names features.{idx}.weight / .bias, OIHW fp32)
+int vgg_load(caddy_ctx* c, const float* flat) {
+    VggState& V = c->vgg;
+    if (!V.enabled) { set_error("caddy_load_vgg: the context was created with caddy_config.perceptual = 0"); return -2; }
+    bool dry = c->dry;
+    long off = 0;
+    for (int i = 0; i < VGG_NCONV; i++) {
+        VggLayer& L = V.conv[i];
+        const long nw = (long)VGG[i].cout * VGG[i].cin * 9;
+        L.pd.w[0] = flat + off;
+        RUN_CK(c, pack_fwd(L.pd, L.wp, c->stream));
+        RUN_CK(c, pack_dgrad(L.pd, 0, L.wpd, L.cd_pad, L.kd, c->stream));
+        if (!dry) hipLaunchKernelGGL(k_copy_f, dim3(1), dim3(256), 0, c->stream, flat + off + nw, L.bias, (long)VGG[i].cout);
+        L.pd.w[0] = nullptr;      // the caller's buffer is not referenced after this call
+        off += nw + round_up(VGG[i].cout, 4);
+    }
+    V.loaded = true;
+    return c->fail ? -1 : 0;
+}
+
+namespace {
+struct Branch { T4 a[VGG_NCONV]; T4 p[VGG_NCONV]; };      // a[i]: ReLU output of conv i; p[i]: pooled input of conv i (pool_before)
+
+int conv_call(caddy_ctx* c, const ConvArgs& a, double flops, int kind) {
+    int save = c->prof_kind_override;
+    c->prof_kind_override = kind;
+    int rc = c->timed_conv_fwd(a, flops);
+    c->prof_kind_override = save;
+    return rc;
+}
+// 13 x (conv3x3 + bias + ReLU) with the 2x2 max-pools; taps[] (if given) receive the five tapped feature maps in place
+void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
+    bool dry = c->dry;
+    VggState& V = c->vgg;
+    T4 x = img;
+    for (int i = 0; i < VGG_NCONV; i++) {
+        VggLayer& L = V.conv[i];
+        if (VGG[i].pool_before) {
+            T4 p = valloc(c, x.N, x.H / 2, x.W / 2, x.C);
+            const long n4 = (long)p.N * p.H * p.W * (p.C / 4);
+            if (!dry) hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(n4)), dim3(256), 0, c->stream, (const float*)x.d, p.d, n4, x.H, x.W, p.C / 4);
+            B.p[i] = p; x = p;
+        }
+        T4 out = (taps && VGG[i].tap >= 0) ? taps[VGG[i].tap] : valloc(c, x.N, x.H, x.W, VGG[i].cout);
+        ConvArgs a{};
+        a.src[0] = ConvSrc{x.d, x.sn, x.ld, x.C, round_up(x.C, CONV_BK), 0};
+        a.nsrc = 1; a.N = x.N; a.H = x.H; a.W = x.W; a.KS = 3; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
+        a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.precision = c->vgg_precision;
+        if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
+        B.a[i] = out; x = out;
+    }
+}
+}  // namespace
+
+// Called from loss_backward after the L1 terms (which also wrote the resized ground-truth images gt_img[r]) and before the tape is replayed:
+// accumulates d(perceptual term)/d(rec_r) into the gradients of c->frames[r] and the raw level sums into c->loss_acc.
+void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv) {
+    bool dry = c->dry;
+    VggState& V = c->vgg;
+    hipStream_t st = c->stream;
+    for (int r = 0; r < 3; r++) {
+        const T4& rec = c->frames[r];
+        const size_t mark = c->act.off;
+        // ground-truth branch: keeps only the five tapped maps
+        T4 taps[5];
+        { int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
+          for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; } }      // MaxPool2d floors odd sizes
+        const size_t mark2 = c->act.off;
+        Branch G{}, R{};
+        vgg_forward(c, gt_img[r], G, taps);
+        c->act.off = mark2;                      // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
+        vgg_forward(c, rec, R, nullptr);
+        // per-level sums and weights.  w_l = lambda * (l == 0 ? 1 : 2) / 3 / numel_l   (aliasing of level 0 with the total, see the header)
+        float wl[5];
+        int li[5];
+        for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) li[VGG[i].tap] = i;
+        for (int l = 0; l < 5; l++) {
+            const T4& f = R.a[li[l]];
+            const double numel = (double)f.N * f.H * f.W * f.C;
+            lv->numel[r][l] = numel;
+            wl[l] = (float)(lambda * (l == 0 ? 1.0 : 2.0) / 3.0 / numel);
+            const long n4 = (long)f.N * f.H * f.W * (f.C / 4);
+            if (!dry) hipLaunchKernelGGL(k_feat_l1, dim3(grid_for(n4)), dim3(256), 0, st, (const float*)f.d, (const float*)taps[l].d, n4, wl[l],
+                                         l == 4 ? f.g : (float*)nullptr, c->loss_acc + LOSS_PERC_R0 + 6 * r + 1 + l);
+        }
+        if (lambda != 0.0) {
+            // backward of the reconstruction branch: gz_i = d/d(pre-ReLU output of conv i), stored at the gradient mirror of a[i]
+            for (int i = VGG_NCONV - 1; i >= 0; i--) {
+                VggLayer& L = V.conv[i];
+                const T4& gz = R.a[i];
+                const T4& in = VGG[i].pool_before ? R.p[i] : (i > 0 ? R.a[i - 1] : rec);
+                ConvArgs d{};
+                d.src[0] = ConvSrc{gz.g, gz.sn, gz.ld, L.pd.Cout, L.kd, 0};
+                d.nsrc = 1; d.N = in.N; d.H = in.H; d.W = in.W; d.KS = 3; d.wp = L.wpd; d.Ktot = L.kd;
+                d.Cout = VGG[i].cin; d.Cout_pad = L.cd_pad; d.bias = nullptr; d.act = 0; d.aux = c->conv_aux; d.precision = c->vgg_precision_bwd;
+                d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
+                if (i == 0) d.accumulate = 1;                                 // += into d(rec_r), next to the L1 seed
+                else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue
+                    d.mask = in.d;
+                    if (VGG[i - 1].tap >= 0) { d.seed_ref = taps[VGG[i - 1].tap].d; d.seed_w = wl[VGG[i - 1].tap]; }
+                }
+                if (!dry) c->ck(conv_call(c, d, 2.0 * in.N * in.H * in.W * 9.0 * VGG[i].cin * VGG[i].cout, 4), "vgg dgrad");
+                if (VGG[i].pool_before) {                                     // pooled input: route through the max-pool and the ReLU of a[i-1]
+                    const T4& pre = R.a[i - 1];
+                    const long n4 = (long)pre.N * ((pre.H + 1) / 2) * ((pre.W + 1) / 2) * (pre.C / 4);
+                    if (!dry) hipLaunchKernelGGL(k_maxpool2_bwd_relu, dim3(grid_for(n4)), dim3(256), 0, st, (const float*)pre.d, (const float*)in.g, pre.g, n4, pre.H, pre.W, pre.C / 4);
+                }
+            }
+        }
+        c->act.off = mark;
+    }
+}

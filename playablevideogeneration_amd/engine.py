@@ -12,13 +12,15 @@ import torch
 
 from . import _lib
 
-LOSS_NAMES = ["total", "rec", "states", "entropy", "dir_kl", "mi", "state_kl", "hidden", "l1_r0", "l1_r1", "l1_r2"]
+LOSS_NAMES = ["total", "rec", "states", "entropy", "dir_kl", "mi", "state_kl", "hidden", "l1_r0", "l1_r1", "l1_r2", "perceptual", "perceptual_term"]
+LOSS_SLOTS, LOSS_PERC_R0 = 40, 16          # include/caddy_hip.h: CADDY_LOSS_SLOTS, CADDY_LOSS_PERC_R0
 
 
 class CaddyConfig(C.Structure):
     _fields_ = [("variant", C.c_int), ("batch", C.c_int), ("seq_len", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("stacking", C.c_int), ("actions", C.c_int), ("action_dim", C.c_int), ("hidden", C.c_int),
-                ("use_gumbel", C.c_int), ("hard_gumbel", C.c_int), ("use_variations", C.c_int), ("centroid_alpha", C.c_float)]
+                ("use_gumbel", C.c_int), ("hard_gumbel", C.c_int), ("use_variations", C.c_int), ("centroid_alpha", C.c_float),
+                ("perceptual", C.c_int)]
 
 
 class ParamInfo(C.Structure):
@@ -33,7 +35,8 @@ class Noise(C.Structure):
 class LossCfg(C.Structure):
     _fields_ = [("rec", C.c_double), ("states", C.c_double), ("entropy", C.c_double), ("dir_kl", C.c_double), ("mi", C.c_double),
                 ("state_kl", C.c_double), ("hidden", C.c_double), ("mi_entropy_lambda", C.c_double),
-                ("mi_ema", C.c_void_p), ("mi_ema_alpha", C.c_float), ("update_mi_ema", C.c_int)]
+                ("mi_ema", C.c_void_p), ("mi_ema_alpha", C.c_float), ("update_mi_ema", C.c_int),
+                ("perceptual", C.c_double), ("perceptual_log", C.c_int)]
 
 
 def _bind(lib):
@@ -56,6 +59,10 @@ def _bind(lib):
     lib.caddy_get_output_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.caddy_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
+    lib.caddy_vgg_param_floats.restype = C.c_long
+    lib.caddy_vgg_param_info_get.argtypes = [C.c_int, C.c_void_p]
+    lib.caddy_load_vgg.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_set_vgg_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
     lib.caddy_generate_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_bn_layer_count.argtypes = [C.c_void_p]
@@ -72,11 +79,12 @@ class CaddyError(Exception):
 class Engine:
     def __init__(self, *, variant: str, batch: int, seq_len: int, height: int, width: int, stacking: int, actions: int,
                  action_dim: int, hidden: int, use_gumbel=True, hard_gumbel=False, use_variations=True, centroid_alpha=0.1,
-                 device="cuda", lib=None, params=None, grads=None):
+                 device="cuda", lib=None, params=None, grads=None, perceptual=False):
         self.lib = _bind(lib if lib is not None else _lib.load())
         self.device = torch.device(device)
         self.cfg = CaddyConfig(0 if variant == "main" else 1, batch, seq_len, height, width, stacking, actions, action_dim, hidden,
-                               int(use_gumbel), int(hard_gumbel), int(use_variations), centroid_alpha)
+                               int(use_gumbel), int(hard_gumbel), int(use_variations), centroid_alpha, int(perceptual))
+        self.perceptual, self.vgg_loaded = bool(perceptual), False
         self.B, self.T, self.H, self.W, self.S, self.K, self.Da, self.Ch = batch, seq_len, height, width, stacking, actions, action_dim, hidden
         n = self.lib.caddy_param_floats(C.byref(self.cfg))
         if n <= 0:
@@ -180,6 +188,36 @@ class Engine:
         for _, _, work in early:
             work.wait()
         self._early = []
+
+    # ---- VGG19 weights of the perceptual loss (replaces torchvision.models.vgg19(pretrained=True).features, model/layers/vgg.py:16) ----
+    def vgg_table(self):
+        info, t = ParamInfo(), []
+        for i in range(self.lib.caddy_vgg_param_count()):
+            self.lib.caddy_vgg_param_info_get(i, C.byref(info))
+            t.append((info.name.decode(), info.offset, tuple(info.shape[:info.ndim])))
+        return t
+
+    def load_vgg(self, sd: Dict[str, torch.Tensor]):
+        """`sd`: torchvision naming (`features.{idx}.weight` / `.bias`; a `vgg19().state_dict()` or its `.features` sub-dict without the
+        prefix); only the 13 convolutions up to conv5_1 are read -- the slices of model/layers/vgg.py:25-34 never run the last three."""
+        if not self.perceptual:
+            raise CaddyError("Engine was created with perceptual=False")
+        flat = torch.zeros(self.lib.caddy_vgg_param_floats(), dtype=torch.float32, device=self.device)
+        for name, off, shape in self.vgg_table():
+            key = name if name in sd else name[len("features."):]
+            if key not in sd:
+                raise CaddyError(f"VGG19 state dict lacks {name}")
+            t = sd[key].detach().to(self.device, torch.float32)
+            assert tuple(t.shape) == shape, (name, tuple(t.shape), shape)
+            flat[off:off + t.numel()] = t.reshape(-1)
+        self._stream()
+        self._check(self.lib.caddy_load_vgg(self.ctx, flat.data_ptr()))
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()      # `flat` may be freed: the library does not reference it after the call
+        self.vgg_loaded = True
+
+    def set_vgg_precision(self, forward: int, dgrad: int):
+        self._check(self.lib.caddy_set_vgg_precision(self.ctx, int(forward), int(dgrad)))
 
     def __del__(self):
         if getattr(self, "ctx", None):
@@ -306,16 +344,23 @@ class Engine:
         return g
 
     # ---- losses + backward (Trainer.compute_losses terms + loss.backward()) ----
-    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True) -> Dict[str, float]:
+    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True, perceptual_log=False) -> Dict[str, float]:
         if smooth_mi and self.mi_ema is None:
             self.mi_ema = torch.full((self.K, self.K), 1.0 / (self.K * self.K), dtype=torch.float32, device=self.device)
         lc = LossCfg(weights.get("rec", 0.0), weights.get("states", 0.0), weights.get("entropy", 0.0), weights.get("dir_kl", 0.0),
                      weights.get("mi", 0.0), weights.get("state_kl", 0.0), weights.get("hidden", 0.0), weights.get("mi_entropy", 1.0),
-                     self.mi_ema.data_ptr() if smooth_mi else None, mi_alpha, int(update_mi_ema))
-        host = (C.c_double * 16)()
+                     self.mi_ema.data_ptr() if smooth_mi else None, mi_alpha, int(update_mi_ema),
+                     weights.get("perceptual", 0.0), int(perceptual_log))
+        host = (C.c_double * LOSS_SLOTS)()
         self._stream()
         self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), host))
-        return {n: host[i] for i, n in enumerate(LOSS_NAMES)}
+        res = {n: host[i] for i, n in enumerate(LOSS_NAMES)}
+        if self.perceptual and self.vgg_loaded and (lc.perceptual != 0.0 or perceptual_log):      # loss_info keys of trainer.py:459-462
+            for r in range(3):
+                res[f"perceptual_loss_r{r}"] = host[LOSS_PERC_R0 + 6 * r]
+                for l in range(5):
+                    res[f"perceptual_loss_r{r}_l{l}"] = host[LOSS_PERC_R0 + 6 * r + 1 + l]
+        return res
 
     def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0):
         if self.adam_m is None:

@@ -36,3 +36,20 @@ def init_parameters(engine, seed: int = 0):
             else:                                   # conv / linear bias
                 b = 1.0 / math.sqrt(fan.get(prefix, 1))
                 v.copy_((torch.rand(shape, generator=g) * 2 - 1) * b)
+
+
+def random_vgg19_state(seed: int = 0):
+    """torchvision vgg19().features state-dict SHAPES with random values (kaiming-normal weights, zero biases = torchvision's own
+    `_initialize_weights`): what the synthetic benchmark loads, since the pretrained file cannot be downloaded on an air-gapped box."""
+    g = torch.Generator().manual_seed(seed)
+    sd, cin = {}, 3
+    idx = 0
+    for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]:
+        if v == "M":
+            idx += 1
+            continue
+        sd[f"features.{idx}.weight"] = torch.randn((v, cin, 3, 3), generator=g) * math.sqrt(2.0 / (v * 9))      # fan_out mode
+        sd[f"features.{idx}.bias"] = torch.zeros(v)
+        cin = v
+        idx += 2
+    return sd

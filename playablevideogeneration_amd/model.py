@@ -76,7 +76,10 @@ class Model(nn.Module):
         self._bn_counters: Dict[str, torch.Tensor] = {}
         self._register_tree()
         init_parameters(self, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        if an.get("ensamble_size", 1) != 1:
+            raise Exception("model.action_network.ensamble_size != 1 is not supported (every reference config uses 1; model.py:152 draws the member at random)")
         self._engines: Dict[Tuple[int, int], Engine] = {}
+        self._vgg_state = None           # VGG19 weights of the perceptual loss (set by the trainer: enable_perceptual)
         self._infer: Optional[Engine] = None
         self._bn_seen: Dict[Tuple[int, int], Dict[str, int]] = {}
         self.last_engine: Optional[Engine] = None
@@ -187,14 +190,32 @@ class Model(nn.Module):
         return sd
 
     # ---- engines ------------------------------------------------------------------------------------------------------
+    MAX_ENGINES = 2      # every Engine owns a workspace sized for BPTT (tens of GiB at BAIR): keep the current training shape + one evaluation shape
+
+    def enable_perceptual(self, vgg_state_dict):
+        """VGG19 weights for the perceptual loss (training/losses.py:379-491); engines created from now on carry the VGG19 buffers."""
+        self._vgg_state = vgg_state_dict
+        self._engines.clear()
+
     def engine(self, B: int, T: int) -> Engine:
         key = (B, T)
         if key not in self._engines:
             d = self.dims
-            if self._flat.device.type != "cuda" and not getattr(self._lib, "_caddy_emulated", False):
+            if self._flat.device.type != getattr(self._lib, "_caddy_device_type", "cuda"):
                 raise Exception("playablevideogeneration_amd runs on the MI355X only: call model.cuda() first (no CPU fallback)")
-            self._engines[key] = Engine(batch=B, seq_len=T, device=self._flat.device, lib=self._lib, params=self._flat, grads=self._flat_grad, **d)
+            # the sequence-length curriculum (trainer.py:152-165) and the evaluators keep asking for new (B, T): evict the least recently used
+            while len(self._engines) >= self.MAX_ENGINES:
+                old = next(iter(self._engines))
+                self._engines.pop(old)
+                self._bn_seen.pop(old, None)
+            use_vgg = self._vgg_state is not None and d["height"] >= 64 and d["width"] >= 64
+            eng = Engine(batch=B, seq_len=T, device=self._flat.device, lib=self._lib, params=self._flat, grads=self._flat_grad, perceptual=use_vgg, **d)
+            if use_vgg:
+                eng.load_vgg(self._vgg_state)
+            self._engines[key] = eng
             self._bn_seen[key] = {}
+        else:
+            self._engines[key] = self._engines.pop(key)      # most recently used last
         return self._engines[key]
 
     def _sync_bn_counters(self, eng: Engine, key):

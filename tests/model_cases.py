@@ -18,9 +18,9 @@ def noise_dict(rec, B, T, K, Da, gumbel=True):
             "eps_states_rec": rec[2 + g + n], "eps_dirs_rec": rec[3 + g + n].reshape(B * n, Da)}
 
 
-def make_engine(c, lib, dev):
+def make_engine(c, lib, dev, perceptual=False):
     eng = Engine(variant=c["variant"], batch=c["B"], seq_len=c["T"], height=c["H"], width=c["W"], stacking=c["S"], actions=c["K"],
-                 action_dim=c["Da"], hidden=c["Ch"], hard_gumbel=c.get("hard", False), device=dev, lib=lib)
+                 action_dim=c["Da"], hidden=c["Ch"], hard_gumbel=c.get("hard", False), device=dev, lib=lib, perceptual=perceptual)
     # every test runs with the first-touch part of the gradient arena NaN-filled before each backward: a gradient that is read before
     # its single writer assigned it cannot go unnoticed (fresh workspaces are often zero pages, which would mask it)
     lib.caddy_debug_set_poison.argtypes = [C.c_void_p, C.c_int]
@@ -114,6 +114,129 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
             assert np.allclose(sd[k[4:]].cpu().numpy(), z[k], atol=1e-4), k
     assert np.allclose(sd["centroid_estimator.estimated_centroids"].cpu().numpy(), z["centroids"], atol=1e-5)
     return eng, dict(rel_l2_hip=rel_h, rel_l2_oracle32=rel_o, worst_hip=worst_h, worst_oracle32=worst_o)
+
+
+def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
+    """VGG19 perceptual loss end to end (training/losses.py:379-491, trainer.py:442-466,494-500) against the golden written by the reference's own
+    ParallelPerceptualLoss on the seeded VGG weights: every level x resolution, avg / term / total, d(total)/d(rec_r) for the three
+    resolutions (= the L1 seed + the VGG dgrad chain) and the parameter-gradient summaries."""
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True)
+    with torch.no_grad():
+        oout = orc.forward_pretraining(obs, tau=c["tau"], noise=nz) if c["pre"] else orc.forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+    eng = make_engine(c, lib, dev, perceptual=True)
+    eng.load_state_dict(P)
+    eng.load_vgg(O.make_vgg_params())
+    if prep is not None:
+        prep(eng)
+    nd = noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"])
+    out = eng.forward_pretraining(obs, c["tau"], nd, training=True) if c["pre"] else eng.forward_full(obs, c["gt"], c["tau"], nd, training=True)
+    _cmp(out, list(oout), fwd_tol, name + " vs oracle")
+    _cmp(out, H.golden_outputs(z), fwd_tol, name + " vs reference golden")
+    w = dict(H.LOSS_W, perceptual=c["perc"])
+    losses = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2)
+    for r in range(3):
+        ref = float(z[f"perceptual_loss_r{r}"])
+        assert abs(losses[f"perceptual_loss_r{r}"] - ref) < 1e-4 * ref, (r, losses[f"perceptual_loss_r{r}"], ref)
+        for l in range(5):
+            ref = float(z[f"perceptual_loss_r{r}_l{l}"])
+            assert abs(losses[f"perceptual_loss_r{r}_l{l}"] - ref) < 1e-4 * ref, (r, l, losses[f"perceptual_loss_r{r}_l{l}"], ref)
+    assert abs(losses["perceptual"] - float(z["loss_perceptual"])) < 1e-4 * float(z["loss_perceptual"])
+    assert abs(losses["perceptual_term"] - float(z["loss_perceptual_term"])) < 1e-4 * float(z["loss_perceptual_term"])
+    assert abs(losses["total"] - float(z["loss_total"])) < 1e-4 * abs(float(z["loss_total"])), (losses["total"], float(z["loss_total"]))
+    # parameter gradients after the full backward: the reference's own summaries (sum |g| per tensor).  Same conditioning caveat as full_case.
+    for n, ga in zip(z["grad_names"], z["grad_abs"]):
+        got = eng.grad_view(str(n)).double().abs().sum().item()
+        assert abs(got - ga) <= 5e-2 * max(ga, 1e-4), (n, got, ga)
+    # Gradients w.r.t. the reconstructions.  The perceptual gradient is DISCONTINUOUS in its input (sign() of the feature L1, ReLU masks,
+    # max-pool arg-max): fp32 round-off flips a handful of those decisions, each flip moving one image's gradient by O(1e-2) while all
+    # other images agree to 1e-6.  Criteria: (a) per image, against the ORACLE evaluated at the engine's own reconstructions (identical
+    # inputs): median relative error <= 2e-3 and worst image <= 1e-1; (b) against the reference golden (inputs differ by the forward
+    # tolerance): relative L2 <= 3 x the reference arithmetic's own response to a 1e-5 input perturbation (measured with the oracle), >= 2e-2.
+    V = O.make_vgg_params()
+
+    def oracle_seed(m0):
+        m = m0.clone().requires_grad_(True)
+        tot, comps = O.perceptual_loss(obs, m, V)
+        term = comps[0] * 0.0
+        for cc in comps:
+            term = term + cc * c["perc"]
+        (O.observations_loss(obs, m) * (H.LOSS_W["rec"] / 3) + term / 3).backward()
+        return m.grad
+    info = dict(per_image_median=[], per_image_worst=[], vs_golden=[], reference_sensitivity_1e5=[])
+    if c["pre"]:      # the reference's `.grad` of the folded pretraining outputs includes what E sends back through the re-stacked frames: compare the full backward
+        for r in range(3):
+            ref = torch.from_numpy(z[f"dout1_{r}"])
+            g = eng.output_grad(100 + r, ref.to(dev)).cpu()
+            rel = ((g - ref).double().norm() / ref.double().norm()).item()
+            info["vs_golden"].append(rel)
+            assert rel < 3e-2, ("d(total)/d(rec_r)", r, rel)
+    lib.caddy_debug_set_seeds_only.argtypes = [C.c_void_p, C.c_int]
+    lib.caddy_debug_set_seeds_only(eng.ctx, 1)      # direct loss terms only (what `.grad` of the reference's stacked full-model outputs holds)
+    try:
+        eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+        gen = torch.Generator().manual_seed(3)
+        for r in range(3):
+            mine = out[1][r].cpu()
+            g = eng.output_grad(100 + r, out[1][r]).cpu().flatten(0, 1)
+            go = oracle_seed(mine).flatten(0, 1)
+            per = torch.tensor([((g[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])])
+            info["per_image_median"].append(per.median().item()); info["per_image_worst"].append(per.max().item())
+            assert per.median().item() < 2e-3 and per.max().item() < 1e-1, ("seed d(total)/d(rec_r) per image", r, per.tolist())
+            if not c["pre"]:
+                ref = torch.from_numpy(z[f"dout1_{r}"]).flatten(0, 1)
+                o_r = oout[1][r]
+                g0 = oracle_seed(o_r).flatten(0, 1)
+                assert ((g0 - ref).double().norm() / ref.double().norm()).item() < 1e-5, r       # the oracle reproduces the reference's gradient
+                g1 = oracle_seed(o_r + 1e-5 * torch.randn(o_r.shape, generator=gen)).flatten(0, 1)
+                sens = ((g1 - g0).double().norm() / g0.double().norm()).item()
+                rel = ((g - ref).double().norm() / ref.double().norm()).item()
+                info["vs_golden"].append(rel); info["reference_sensitivity_1e5"].append(sens)
+                assert rel < max(3 * sens, 2e-2), ("seed d(total)/d(rec_r) vs golden", r, rel, sens)
+    finally:
+        lib.caddy_debug_set_seeds_only(eng.ctx, 0)
+    return eng, info
+
+
+def perceptual_oracle_case(lib, dev, c, lam=1.0):
+    """perceptual term vs the oracle on an arbitrary geometry (no golden): losses per level, total, seed gradients per image"""
+    d, P, obs = H.inputs_of(c)
+    V = O.make_vgg_params()
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True)
+    with torch.no_grad():
+        oout = orc.forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+    eng = make_engine(c, lib, dev, perceptual=True)
+    eng.load_state_dict(P)
+    eng.load_vgg(V)
+    out = eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+    _cmp(out, list(oout), 2e-4, "vs oracle")
+    w = dict(H.LOSS_W, perceptual=lam)
+    total, comp, _ = O.full_model_loss(oout, obs, w, mi_ema=torch.full((d.K, d.K), 1.0 / (d.K * d.K)), mi_alpha=0.2, vgg=V)
+    lib.caddy_debug_set_seeds_only.argtypes = [C.c_void_p, C.c_int]
+    lib.caddy_debug_set_seeds_only(eng.ctx, 1)
+    try:
+        losses = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+        assert abs(losses["total"] - total.item()) < 1e-4 * abs(total.item()), (losses["total"], total.item())
+        for r in range(3):
+            for k in [f"perceptual_loss_r{r}"] + [f"perceptual_loss_r{r}_l{l}" for l in range(5)]:
+                assert abs(losses[k] - comp[k].item()) < 1e-4 * comp[k].item(), (k, losses[k], comp[k].item())
+            m = out[1][r].cpu().clone().requires_grad_(True)
+            tot, comps = O.perceptual_loss(obs, m, V)
+            term = comps[0] * 0.0
+            for cc in comps:
+                term = term + cc * lam
+            (O.observations_loss(obs, m) * (w["rec"] / 3) + term / 3).backward()
+            g, go = eng.output_grad(100 + r, out[1][r]).cpu().flatten(0, 1), m.grad.flatten(0, 1)
+            per = torch.tensor([((g[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])])
+            assert per.median().item() < 2e-3 and per.max().item() < 1e-1, (r, per.tolist())
+    finally:
+        lib.caddy_debug_set_seeds_only(eng.ctx, 0)
+    return eng
 
 
 def single_step_grad_case(lib, dev, variant="main", tol_median=5e-3, tol_worst=5e-2):

@@ -167,12 +167,16 @@ def test_training_progress_on_fixed_batch():
 
 
 def test_headless_evaluator_matches_oracle_losses_and_hungarian_accuracy():
+    headless_evaluator_case(_make_model, "cpu")
+
+
+def headless_evaluator_case(make_model, dev):
     """evaluator(config, dataset, logger, action_sampler, prefix).evaluate(model, step): the reference's per-position / entropy / MI / accuracy
     quantities, checked against the oracle's loss functions on the oracle's own eval-mode forward (same seed)."""
     from playablevideogeneration_amd import evaluator as EV
     cfg = _config()
     cfg["evaluation"] = {"evaluator": "playablevideogeneration_amd.evaluator", "batching": {"batch_size": 2}, "max_evaluation_batches": None}
-    m = _make_model(cfg)
+    m = make_model(cfg)
     d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
     P = O.make_params(d, seed=7)
     m.load_state_dict(P)
@@ -209,17 +213,23 @@ PRE_W = {"reconstruction_loss_lambda_pretraining": 1.0, "perceptual_loss_lambda_
          "action_mutual_information_lambda_pretraining": 0.15, "action_state_distribution_kl_lambda_pretraining": 0.0}     # as in tools/gen_trainer_golden.py
 
 
-@pytest.mark.parametrize("pretraining", [False, True])
-def test_trainer_mirror_matches_reference_trainer_golden(pretraining):
-    """One training step of the REAL reference (SmoothMITrainer.compute_losses + Adam step, tools/gen_trainer_golden.py; perceptual weight 0)
-    vs the trainer mirror: schedule values, every shared loss_info entry incl. the logging diagnostics, the MI estimator state, and the
-    parameters after the optimiser step."""
+def trainer_golden_case(name, make_model, with_vgg):
+    """One training step of the REAL reference (SmoothMITrainer.compute_losses[_pretraining] + Adam step, tools/gen_trainer_golden.py) vs the
+    trainer mirror: schedule values, every shared loss_info entry incl. the logging diagnostics (and, with VGG19 weights, the perceptual
+    entries), the MI estimator state, and the parameters after the optimiser step.  Shared by the simulator and the MI355X suites."""
     from playablevideogeneration_amd import smooth_mi_trainer
-    z = np.load(H.GOLDEN + ("/trainer_pre_reduced_s1.npz" if pretraining else "/trainer_reduced_s1.npz"), allow_pickle=False)
+    z = np.load(H.GOLDEN + "/" + name + ".npz", allow_pickle=False)
+    pretraining = "_pre_" in name
+    lam = float(z["perceptual_lambda"]) if "perceptual_lambda" in z.files else 0.0
+    assert with_vgg or lam == 0.0
     cfg = _config(res=(8, 8))
     cfg["training"]["loss_weights"].update(PRE_W)
+    cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = lam
+    cfg["training"]["loss_weights"]["perceptual_loss_lambda_pretraining"] = lam
+    if with_vgg:
+        cfg["training"]["vgg19_weights"] = O.make_vgg_params()
     cfg["logging"] = {"save_root_directory": "/tmp"}
-    m = _make_model(cfg)
+    m = make_model(cfg)
     d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
     m.load_state_dict(O.make_params(d, seed=7))
     m.train()
@@ -228,16 +238,20 @@ def test_trainer_mirror_matches_reference_trainer_golden(pretraining):
     obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
     torch.manual_seed(int(z["step_seed"]))
     loss, info, _ = (tr.compute_losses_pretraining if pretraining else tr.compute_losses)(m, (obs, torch.zeros(2, 4, dtype=torch.int32), None, None), 4)
-    assert abs(loss - float(z["loss"])) < 2e-5 * max(1.0, abs(float(z["loss"])))
-    checked = 0
+    assert abs(loss - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    checked = perc_checked = 0
     for k in z.files:
         if not k.startswith("info:") or k[5:] not in info:
             continue
+        if "perceptual" in k and not with_vgg:
+            continue                                                   # the reference logs the VGG term even at weight 0; needs the weights
         want, got = float(z[k]), float(info[k[5:]])
         tol = 2e-3 if "kl" in k or "variance" in k else 2e-4          # log-variance terms are ill-conditioned
         assert abs(got - want) <= tol * max(1.0, abs(want)), (k, got, want)
         checked += 1
-    assert checked >= (22 if pretraining else 25), checked                                     # schedules, loss components, raw losses, diagnostics
+        perc_checked += "perceptual" in k
+    assert checked - perc_checked >= (22 if pretraining else 25), checked                      # schedules, loss components, raw losses, diagnostics
+    assert not with_vgg or perc_checked == 20, perc_checked                                    # avg + component + 3 x (total + 5 levels)
     assert np.allclose(tr.mi_ema.cpu().numpy(), z["mi_ema"], atol=1e-6)
     tr.optimizer_step(m)
     assert abs(tr._get_current_lr() - float(z["lr"])) < 1e-12
@@ -247,8 +261,146 @@ def test_trainer_mirror_matches_reference_trainer_golden(pretraining):
     sd = dict(m.named_parameters())
     lr = float(z["lr"])
     for n, s_, a_, f4 in zip(z["param_names"], z["param_sum"], z["param_abs"], z["param_first4"]):
-        p = sd[str(n)].detach().double()
+        p = sd[str(n)].detach().double().cpu()
         slack = lr * (6 + 0.02 * p.numel()) + 1e-5 * max(1.0, a_)      # round-off-only gradients step +-lr at random: allow 2 % of a tensor
         assert abs(p.abs().sum().item() - a_) <= slack and abs(p.sum().item() - s_) <= slack + 2e-4 * max(1.0, a_ ** 0.5), (str(n), p.abs().sum().item(), a_, p.sum().item(), s_)
         if str(n).startswith("state_to_hidden_state_layer") and not pretraining:
             assert np.array_equal(p.flatten()[:4].float().numpy(), f4[:min(4, p.numel())])
+
+
+@pytest.mark.parametrize("name", ["trainer_reduced_s1", "trainer_pre_reduced_s1"])
+def test_trainer_mirror_matches_reference_trainer_golden(name):
+    trainer_golden_case(name, _make_model, with_vgg=False)
+
+
+def test_trainer_refuses_objectives_it_does_not_implement():
+    """a reference config must never silently train a different objective"""
+    from playablevideogeneration_amd import smooth_mi_trainer
+    cfg = _config()
+    m = _make_model(cfg)
+    cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = 1.0          # every reference YAML: no VGG19 weights reachable here -> raise
+    with pytest.raises(Exception, match="VGG19"):
+        smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = 0.0
+    cfg["training"]["use_motion_weights"] = True
+    with pytest.raises(Exception, match="use_motion_weights"):
+        smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    cfg["training"]["use_motion_weights"] = False
+    cfg["model"]["action_network"]["ensamble_size"] = 3
+    with pytest.raises(Exception, match="ensamble_size"):
+        _make_model(cfg)
+
+
+def test_multistep_lr_timing_matches_torch():
+    """optimizer.step() runs before lr_scheduler.step() (trainer.py:586-587): with a milestone at m, step m + 1 is the first at the decayed rate"""
+    from playablevideogeneration_amd import smooth_mi_trainer
+    cfg = _config()
+    cfg["training"]["lr_schedule"], cfg["training"]["lr_gamma"] = [2, 10 ** 9], 0.5
+    m = _make_model(cfg)
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    p = torch.nn.Parameter(torch.ones(1))
+    opt = torch.optim.Adam([p], lr=cfg["training"]["learning_rate"])
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [2, 10 ** 9], gamma=0.5)
+    want, got = [], []
+
+    class FakeEngine:
+        grads = torch.zeros(4)
+        adam_m = adam_v = None
+        def adam_step(self, step, lr, weight_decay, grad_scale):
+            got.append(lr)
+    m.last_engine = FakeEngine()
+    for _ in range(4):
+        want.append(opt.param_groups[0]["lr"])
+        p.grad = torch.ones(1); opt.step(); sched.step()
+        tr.optimizer_step(m)
+    assert got == pytest.approx(want) and want[1] != want[2]
+    assert tr._get_current_lr() == pytest.approx(opt.param_groups[0]["lr"])      # what is logged / exported after the step
+
+
+def test_trainer_mirror_with_perceptual_term():
+    """the trainer reads perceptual_loss_lambda, loads the VGG19 weights it is given, and reports the reference's loss_info keys (trainer.py:459-462,505,512)"""
+    from playablevideogeneration_amd import smooth_mi_trainer
+    cfg = _config(res=(8, 10))
+    cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = 0.5
+    cfg["training"]["vgg19_weights"] = O.make_vgg_params()
+    m = _make_model(cfg)
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    P = O.make_params(d, seed=7)
+    m.load_state_dict(P)
+    m.train()
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    tr.global_step = 20000
+    obs = torch.rand(1, 2, 3, 64, 80, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    torch.manual_seed(4)
+    loss, info, _ = tr.compute_losses(m, (obs, None, None, None), 2)
+    torch.manual_seed(4)
+    orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True)
+    with torch.no_grad():
+        out = orc.forward_full(obs, 1, tau=tr.get_gumbel_temperature())
+    w = dict(tr.loss_weights())
+    total, comp, _ = O.full_model_loss(out, obs, w, mi_ema=torch.full((3, 3), 1.0 / 9), mi_alpha=0.2, vgg=cfg["training"]["vgg19_weights"])
+    assert abs(loss - total.item()) < 1e-4 * abs(total.item())
+    assert abs(info["avg_perceptual_loss"] - comp["perceptual"].item()) < 1e-4 * comp["perceptual"].item()
+    for r in range(3):
+        assert info[f"perceptual_loss_r{r}_l0"] == info[f"perceptual_loss_r{r}"]            # the reference's aliasing (losses.py:483-487)
+        assert abs(info[f"perceptual_loss_r{r}_l3"] - comp[f"perceptual_loss_r{r}_l3"].item()) < 1e-4 * comp[f"perceptual_loss_r{r}_l3"].item()
+    parts = sum(info[k] for k in info if k.startswith("loss_component_"))
+    assert abs(parts - loss) < 1e-6 * max(1.0, abs(loss))
+    tr.optimizer_step(m)
+
+
+def test_engines_are_evicted_by_the_sequence_length_curriculum():
+    """one Engine (= one BPTT-sized workspace) per (B, T) must not accumulate over a run"""
+    m = _make_model(_config())
+    m.train()
+    for T in (2, 3, 4, 3):
+        obs = torch.zeros(1, T, 3, 32, 32)
+        m((obs, None, None, None), 1, gumbel_temperature=1.0, fetch_outputs=False)
+        assert len(m._engines) <= m.MAX_ENGINES
+    assert set(m._engines) == {(1, 4), (1, 3)}
+
+
+def test_batching_contract():
+    """Batch / collate / stacking + skip indices / normalisation of the reference's dataset package"""
+    from playablevideogeneration_amd import batching as BT
+    obs, stacks = BT.observation_indices(initial_frame=7, observations_count=3, skip_frames=2, observation_stacking=4)
+    assert obs == [7, 10, 13] and stacks == [[7, 4, 1, 1], [10, 7, 4, 1], [13, 10, 7, 4]]      # clamped at initial % (skip + 1) = 1
+    assert BT.available_samples(frames_count=30, observations_count=3, skip_frames=2) == 24
+    assert BT.accumulated_rewards([1, 2, 3, 4, 5, 6], [0, 3, 5], 2) == [1, 9, 15]
+    x = BT.normalize_frame(torch.tensor([[[0, 255, 127]]], dtype=torch.uint8))
+    assert x.shape == (3, 1, 1) and x[0, 0, 0] == -1.0 and x[1, 0, 0] == 1.0 and abs(x[2, 0, 0].item() - (127 / 255 - 0.5) / 0.5) < 1e-7
+    els = []
+    for b in range(2):
+        frames = [[torch.full((3, 4, 4), float(100 * b + 10 * t + k)) for k in range(2)] for t in range(3)]
+        els.append(BT.BatchElement(frames, [b, 1, 2], [0.0, 1.0, 0.5], [False, False, True], video=f"v{b}", initial_frame_index=5 + b))
+    batch = BT.single_batch_elements_collate_fn(els)
+    o, a, r, dn = batch.to_tuple(cuda=False)
+    assert o.shape == (2, 3, 6, 4, 4) and a.dtype == torch.int32 and batch.size == 3 and batch.initial_frames == [5, 6]
+    assert o[1, 2, 0, 0, 0] == 120.0 and o[1, 2, 3, 0, 0] == 121.0                       # newest frame first in the channel stack
+    assert BT.is_batch_element(els[0]) and not BT.is_batch_element(batch)
+    with pytest.raises(Exception):
+        BT.BatchElement([[torch.zeros(3, 2, 2)]], [0, 1], [0.0], [False])
+    lst = BT.multiple_batch_elements_collate_fn([(els[0], els[1]), (els[1], els[0])])
+    assert len(lst) == 2 and lst[1].observations[0, 0, 0, 0, 0] == 100.0
+
+
+def test_train_epoch_builds_its_dataloader_from_batch_elements():
+    """train.py calls trainer.train_epoch(model) without a dataloader (training/trainer.py:39,563): the mirror builds it"""
+    from playablevideogeneration_amd import smooth_mi_trainer, batching as BT
+    cfg = _config()
+    cfg["training"]["batching"].update({"batch_size": 2, "num_workers": 0, "observations_count": 3, "observations_count_start": 3})
+    cfg["training"]["max_steps_per_epoch"] = 10
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 5
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            frames = [[torch.rand(3, 32, 32, generator=g) * 2 - 1] for _ in range(3)]
+            return BT.BatchElement(frames, [0, 1, 2], [0.0] * 3, [False] * 3, video=None, initial_frame_index=i)
+    m = _make_model(cfg)
+    m.train()
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=DS(), logger=None)
+    assert tr.dataloader is not None
+    tr.global_step = 30000
+    assert tr.train_epoch(m) == 2           # 5 samples, batch 2, drop_last

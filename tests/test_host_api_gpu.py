@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import caddy_oracle as O
-from tests.test_host_api_emu import _config
+from tests.test_host_api_emu import _config, trainer_golden_case
 
 pytestmark = pytest.mark.gpu
 
@@ -50,3 +50,15 @@ def test_plugin_factories_forward_and_training_progress(tmp_path):
     tr2 = getattr(importlib.import_module(cfg["training"]["trainer"]), "trainer")(cfg, m2, dataset=None, logger=None)
     tr2.load_checkpoint(m2)
     assert torch.equal(m2._flat.cpu(), m._flat.cpu())
+
+
+@pytest.mark.parametrize("name", ["trainer_reduced_s1", "trainer_pre_reduced_s1", "trainer_perc_reduced_s1", "trainer_perc_pre_reduced_s1"])
+def test_trainer_mirror_matches_reference_trainer_golden_on_gpu(name):
+    """the REAL reference's training step (loss_info, MI estimator, post-Adam parameters), perceptual weight 0 and 1, on the real library"""
+    trainer_golden_case(name, _build, with_vgg=True)
+
+
+def test_evaluator_mirror_on_gpu():
+    """headless Evaluator (per-position losses, entropies, MI, Hungarian accuracy) on the real kernels, vs the oracle"""
+    from tests import test_host_api_emu as TE
+    TE.headless_evaluator_case(_build, "cuda")

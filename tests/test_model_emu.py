@@ -48,3 +48,9 @@ def test_eval_samplers(name):
 def test_random_model_configurations():
     """a seeded random configuration (observation_stacking 2 / 3, odd batch, ... are not covered by the reference goldens); the GPU suite runs 10"""
     M.random_config_sweep(load_emu(), "cpu", 1, seed=21)
+
+
+def test_perceptual_loss_small():
+    """VGG19 perceptual term (forward, per-level losses, dgrad chain with fused ReLU masks / L1 seeds, odd-sized max-pools) on the smallest
+    geometry the loss accepts; the reference goldens perc_* run on the GPU (the simulator needs minutes for them)"""
+    M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=80, gt=1, tau=0.8), lam=0.7)

@@ -33,6 +33,18 @@ def test_pretraining_parity(lib):
     M.pretraining_case(lib, "cuda")
 
 
+@pytest.mark.parametrize("name", ["perc_main_s1", "perc_pre_reduced_s1"])
+def test_perceptual_loss_parity(lib, name):
+    """VGG19 perceptual loss (L2) end to end vs the golden written by the reference's ParallelPerceptualLoss (full model + pretraining)"""
+    eng, info = M.perceptual_case(name, lib, "cuda")
+    print(info)
+
+
+def test_perceptual_loss_odd_pooling_sizes(lib):
+    """Breakout's 208x160 frames: the quarter resolution 52x40 goes 26x20 -> 13x10 -> 6x5 -> 3x2 through the VGG max-pools (floor)"""
+    M.perceptual_oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=208, W=160, gt=1, tau=0.6), lam=1.0)
+
+
 def test_larger_geometry_vs_oracle(lib):
     """breakout-reduced hyper-parameters at 64x64, T=5 (BASELINE configs[0] geometry, shortened) vs the CPU oracle."""
     M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=5, H=64, W=64, gt=3, tau=0.85))

@@ -1,7 +1,7 @@
 """Golden of the REAL reference training step (build container only): SmoothMITrainer.compute_losses + optimizer.zero_grad / backward /
-step on one seeded batch (training/trainer.py:400-550,575-587; training/smooth_mi_trainer.py), perceptual_loss_lambda = 0 (the VGG stub
-of tools/ref_harness.py runs but contributes nothing).  Stored: the scalar loss_info entries, the schedule values, per-parameter
-post-step summaries and the MI estimator state -> tests/golden/trainer_reduced_s1.npz.     python tools/gen_trainer_golden.py"""
+step on one seeded batch (training/trainer.py:400-550,575-587; training/smooth_mi_trainer.py), once with perceptual_loss_lambda = 0 (the
+seeded VGG19 of tools/ref_harness.py still runs and is logged) and once with 1.0.  Stored: the scalar loss_info entries, the schedule values,
+per-parameter post-step summaries and the MI estimator state -> tests/golden/trainer_[perc_][pre_]reduced_s1.npz.     python tools/gen_trainer_golden.py"""
 import os
 import random
 import sys
@@ -27,11 +27,12 @@ PRE_W = {"reconstruction_loss_lambda_pretraining": 1.0, "perceptual_loss_lambda_
 
 
 def main():
-    for pre in (False, True):
-        one(pre)
+    for perc in (0.0, 1.0):
+        for pre in (False, True):
+            one(pre, perc)
 
 
-def one(pretraining):
+def one(pretraining, perc=0.0):
     rh.install()
     cfg = _config(res=(8, 8))          # 64 x 64 frames: the (stub) VGG19 of the reference's perceptual loss needs >= 16 pixels at the quarter resolution
     cfg["model"]["architecture"] = "model.reduced_model.model"
@@ -41,8 +42,9 @@ def one(pretraining):
     tr["batching"].update(batch_size=2, num_workers=0)
     tr.update(motion_weights_bias=0.1, use_motion_weights=False, action_mutual_information_entropy_lambda=1.0, action_direction_plotting_freq=10 ** 9,
               max_steps=10 ** 6)
-    tr["loss_weights"]["perceptual_loss_lambda"] = 0.0
+    tr["loss_weights"]["perceptual_loss_lambda"] = perc
     tr["loss_weights"].update(PRE_W)
+    tr["loss_weights"]["perceptual_loss_lambda_pretraining"] = perc
     cfg["logging"] = {"save_root_directory": "/tmp", "output_images_directory": "/tmp"}
     d = O.Dims.from_config(cfg)
     P = O.make_params(d, seed=PARAM_SEED)
@@ -73,7 +75,8 @@ def one(pretraining):
     data["param_names"], data["param_sum"], data["param_abs"], data["param_first4"] = np.array(names), np.array(psum), np.array(pabs), np.array(first, dtype=np.float32)
     data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
     data["lr"] = np.array(trainer._get_current_lr())
-    out = os.path.join(ROOT, "tests", "golden", "trainer_pre_reduced_s1.npz" if pretraining else "trainer_reduced_s1.npz")
+    data["perceptual_lambda"] = np.array(perc)
+    out = os.path.join(ROOT, "tests", "golden", ("trainer_perc_" if perc else "trainer_") + ("pre_reduced_s1.npz" if pretraining else "reduced_s1.npz"))
     np.savez_compressed(out, **data)
     print("written", out, {k: float(v) for k, v in data.items() if k.startswith("info:")})
 
