@@ -92,7 +92,11 @@ int caddy_vgg_param_count(void);
 int caddy_vgg_param_info_get(int index, caddy_param_info* out);
 long caddy_vgg_param_floats(void);
 int caddy_load_vgg(caddy_ctx* ctx, const float* vgg_flat);
-/* ConvArgs.precision of the VGG convolutions: forward (both branches) and dgrad.  See DESIGN.md "numerics". */
+/* Arithmetic of the wide 3x3 convolutions (DESIGN.md "numerics"):  0 = exact fp32 (v_mfma_f32_32x32x2_f32);  16 = split f16 (hi + lo operands,
+ * 3 products on the 16-bit matrix pipe, fp32 accumulate: fp32-class, forward default);  17 = split bf16 (3 products, 2^-16 with the full
+ * fp32 exponent range: gradient default);  18 / 19 = single-product f16 / bf16 operands (VGG19 only).  caddy_set_precision: the model's
+ * convolutions (forward: 0 | 16, backward: 0 | 17); caddy_set_vgg_precision: the perceptual loss network (forward 0 | 16 | 18, dgrad 0 | 17 | 19). */
+int caddy_set_precision(caddy_ctx* ctx, int forward, int backward);
 int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
 
 /* --- context --- */
@@ -186,6 +190,10 @@ struct ConvArgs; struct WgradArgs; struct PackDesc; struct TV;
 int caddy_k_conv_fwd(const struct ConvArgs* a, void* stream);
 int caddy_k_conv_wgrad(const struct WgradArgs* a, void* stream);
 int caddy_k_conv_pick_bn(int cout);
+/* split 16-bit operand form of a layer's weights for the 16-bit-MFMA convolution (conv_hx.hip): seg < 0 forward, else dgrad of that segment */
+int caddy_k_hx_pick_bn(int cout);
+long caddy_k_hx_weight_bytes(const struct PackDesc* d, int seg, int rows_pad, int planes);
+int caddy_k_pack_hx(const struct PackDesc* d, void* wq, int rows_pad, int seg, int precision, void* stream);
 int caddy_k_pack_fwd(const struct PackDesc* d, float* wp, void* stream);
 int caddy_k_pack_dgrad(const struct PackDesc* d, int seg, float* wpd, int Cd_pad, int Kd, void* stream);
 int caddy_k_unpack_wgrad(const struct PackDesc* d, const float* dwp, void* stream);

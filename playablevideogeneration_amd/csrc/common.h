@@ -64,7 +64,15 @@ struct ConvArgs {
     const float* mask;
     const float* seed_ref;
     float seed_w;
+    // split 16-bit operands (conv_hx.hip): weights pre-split by pack_hx for `precision` (PREC_*), rows padded to hx_pick_bn(Cout)
+    const void* wq;
+    int Kq;                 // set by the launcher: sum of the input segments padded to HX_KC channels
 };
+// ConvArgs.precision.  0 = exact fp32 MFMA (k_conv_fwd; 2 / 3 = its in-loop split-bf16 variants, kept for A/B runs).  >= 16: conv_hx.hip --
+// split f16 (hi + lo, 3 products: fp32-class accuracy, bounded operands = forward activations / weights), split bf16 (3 products: 2^-16, full
+// exponent range = gradients), or single-product 16-bit operands.
+enum { PREC_FP32 = 0, PREC_F16X3 = 16, PREC_BF16X3 = 17, PREC_F16X1 = 18, PREC_BF16X1 = 19 };
+#define HX_KC 32
 constexpr int CONV_AUX_BYTES = 128 * 1024;
 
 // wgrad: dwp[tap][o][k] += sum_p dY[p][o] * A[p+tap][k]   (A = concatenation of the forward sources)
@@ -89,11 +97,19 @@ struct WgradArgs {
 };
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
-enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW, CK_COUNT };
+enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW,
+       CK_HX_128, CK_HX_64, CK_HX_32, CK_WGRAD_HX, CK_COUNT };
 extern thread_local int g_last_conv_kernel;
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
+struct PackDesc;
+int conv_hx_try(const ConvArgs& a, hipStream_t st);           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
+int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward form, else dgrad form of that input segment */, int precision, hipStream_t st);
+size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
+int hx_kq(const PackDesc& d, int seg);
+int hx_pick_bn(int cout);
+int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act, hipStream_t st);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

@@ -693,6 +693,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
+    { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
     const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
     if (a.seed_ref && !a.mask) return -1;
     if (!generic_only) {
@@ -731,7 +732,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
             a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0;
         }
     }
-    static const int force_prec = getenv("CADDY_PRECISION") ? atoi(getenv("CADDY_PRECISION")) : -1;   // tuning / A-B aid
+    static const int force_prec = getenv("CADDY_FP32_PLANES") ? atoi(getenv("CADDY_FP32_PLANES")) : -1;   // tuning / A-B aid: 2 | 3 = in-loop split-bf16 planes of k_conv_fwd
     if (force_prec >= 0) a.precision = force_prec;
     const int ns = (a.precision == 2 || a.precision == 3) ? a.precision : 0;
     static const int force_cps = getenv("CADDY_CPS") ? atoi(getenv("CADDY_CPS")) : 0;
@@ -755,12 +756,12 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
     }
 #undef LAUNCH_CONV
-    if (a.split_stride) {
-        int ldc = a.out_ld;
-        long items = P * (ldc >> 2);
-        hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st,
-                           (const float*)a.split_scratch, a.split_stride, a.splitk, ldc, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act);
-    }
+    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, st);
+    return 0;
+}
+int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act, hipStream_t st) {
+    long items = P * (ldc >> 2);
+    hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, bias, act);
     return 0;
 }
 

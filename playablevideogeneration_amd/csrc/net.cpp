@@ -128,6 +128,10 @@ void make_conv(caddy_ctx* c, ConvL& L, const std::vector<std::string>& wn, const
         L.wpd[s] = (float*)c->persist.alloc((size_t)KS * KS * L.cd_pad[s] * L.kd * 4);
     }
     if (!bias.empty()) { L.bias = PP(c, bias); L.dbias = GP(c, bias); }
+    // split 16-bit operand forms (conv_hx.hip): wide 3x3 layers only -- narrow ones are HBM-bound on their own kernels
+    if (KS == 3 && d.Cin >= 32 && d.Cout >= 32) L.wq = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2));
+    for (int s = 0; s < d.nseg; s++)
+        if (KS == 3 && segC[s] >= 32 && d.Cout >= 32) L.wqd[s] = c->persist.alloc(hx_weight_bytes(d, s, round_up(segC[s], hx_pick_bn(segC[s])), 2));
     c->convs.push_back(&L);
 }
 void make_bn(caddy_ctx* c, BNL& b, const std::string& p) {
@@ -351,6 +355,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
     a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
+    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; }
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
     if (recording) {
@@ -383,6 +388,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
                 d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux;
+                if (Lp->wqd[s] && prec_bwd != PREC_FP32) { d.wq = Lp->wqd[s]; d.precision = PREC_BF16X3; }
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
                 if (!sg[s].bcast) {
                     // first-touch inputs (this conv is their only consumer): dgrad assigns -- plain stores, or the deterministic slab split-K when under-filled
@@ -623,6 +629,9 @@ void caddy_ctx::pack_all() {
     for (ConvL* L : convs) {
         RUN(pack_fwd(L->pd, L->wp, stream));
         for (int s = 0; s < L->pd.nseg; s++) RUN(pack_dgrad(L->pd, s, L->wpd[s], L->cd_pad[s], L->kd, stream));
+        if (L->wq && prec_fwd != PREC_FP32) RUN(pack_hx(L->pd, L->wq, round_up(L->pd.Cout, hx_pick_bn(L->pd.Cout)), -1, PREC_F16X3, stream));
+        for (int s = 0; s < L->pd.nseg; s++)
+            if (L->wqd[s] && prec_bwd != PREC_FP32 && recording) RUN(pack_hx(L->pd, L->wqd[s], round_up(L->pd.seg_C[s], hx_pick_bn(L->pd.seg_C[s])), s, PREC_BF16X3, stream));
     }
     for (int i = 0; i < 3; i++) {   // learned initial LSTM states: (C,h,w) -> (1,h,w,C)
         RUN(pw_nchw_to_nhwc(lstm[i].init_h, 0, dv(lstm[i].ih), stream));
@@ -1012,6 +1021,10 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { set_error("buffers must be 256-byte (workspace) / 16-byte (params, grads) aligned"); return nullptr; }
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
+    if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
+        if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
+        else if (!strcmp(e, "fwd")) { c->prec_bwd = PREC_FP32; c->vgg_precision_bwd = PREC_FP32; }
+    }
     return c;
 }
 void caddy_ctx_destroy(caddy_ctx* c) {
@@ -1063,6 +1076,10 @@ int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
     return vgg_load(c, vgg_flat);
 }
 int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
+int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
+    if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }
+    c->prec_fwd = forward; c->prec_bwd = backward; return 0;
+}
 int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     c->fail = false;

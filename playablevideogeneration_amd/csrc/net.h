@@ -51,6 +51,9 @@ struct ConvL {
     int kd = 0;
     const float* bias = nullptr; float* dbias = nullptr;
     size_t wp_floats = 0;
+    // split 16-bit operand forms for conv_hx.hip (3x3 layers with >= 32 channels on both sides): forward weights as f16 hi|lo, dgrad weights
+    // (flipped / transposed) as bf16 hi|lo; re-split once per optimiser step by pack_all()
+    void* wq = nullptr; void* wqd[CONV_MAX_SRC] = {nullptr, nullptr, nullptr};
 };
 struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
              float* eval_stash = nullptr; bool eval_valid = false; };   // eval mode: (mean, invstd, scale, shift) from the running statistics, computed once per start_inference / eval forward
@@ -106,7 +109,8 @@ struct caddy_ctx {
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     VggState vgg;                    // VGG19 perceptual loss (perceptual.hip); enabled by caddy_config.perceptual
-    int vgg_precision = 0, vgg_precision_bwd = 0;   // ConvArgs.precision of the VGG convolutions (forward / dgrad)
+    int vgg_precision = PREC_F16X3, vgg_precision_bwd = PREC_BF16X3;   // ConvArgs.precision of the VGG convolutions (forward / dgrad); PREC_FP32 = exact
+    int prec_fwd = PREC_F16X3, prec_bwd = PREC_BF16X3;                 // ... of the model's wide 3x3 convolutions (caddy_set_precision; CADDY_PRECISION=exact)
     size_t fwd_off = 0;              // act.off at the end of the last forward: loss_backward allocates its VGG buffers past it and releases them
     int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1
     bool have_forward = false;

@@ -152,6 +152,10 @@ void vgg_build(caddy_ctx* c) {
         L.cd_pad = round_up(VGG[i].cin, conv_pick_bn(VGG[i].cin));
         L.wpd = (float*)c->persist.alloc((size_t)9 * L.cd_pad * L.kd * 4);
         L.bias = (float*)c->persist.alloc((size_t)round_up(d.Cout, 4) * 4);
+        for (int pl = 0; pl < 2; pl++) {
+            L.wq[pl] = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2 - pl));
+            L.wqd[pl] = VGG[i].cin >= 32 ? c->persist.alloc(hx_weight_bytes(d, 0, round_up(VGG[i].cin, hx_pick_bn(VGG[i].cin)), 2 - pl)) : nullptr;
+        }
     }
 }
 
@@ -167,6 +171,10 @@ int vgg_load(caddy_ctx* c, const float* flat) {
         L.pd.w[0] = flat + off;
         RUN_CK(c, pack_fwd(L.pd, L.wp, c->stream));
         RUN_CK(c, pack_dgrad(L.pd, 0, L.wpd, L.cd_pad, L.kd, c->stream));
+        for (int pl = 0; pl < 2; pl++) {
+            RUN_CK(c, pack_hx(L.pd, L.wq[pl], round_up(L.pd.Cout, hx_pick_bn(L.pd.Cout)), -1, pl == 0 ? PREC_F16X3 : PREC_F16X1, c->stream));
+            if (L.wqd[pl]) RUN_CK(c, pack_hx(L.pd, L.wqd[pl], round_up(VGG[i].cin, hx_pick_bn(VGG[i].cin)), 0, pl == 0 ? PREC_BF16X3 : PREC_BF16X1, c->stream));
+        }
         if (!dry) hipLaunchKernelGGL(k_copy_f, dim3(1), dim3(256), 0, c->stream, flat + off + nw, L.bias, (long)VGG[i].cout);
         L.pd.w[0] = nullptr;      // the caller's buffer is not referenced after this call
         off += nw + round_up(VGG[i].cout, 4);
@@ -202,7 +210,9 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
         ConvArgs a{};
         a.src[0] = ConvSrc{x.d, x.sn, x.ld, x.C, round_up(x.C, CONV_BK), 0};
         a.nsrc = 1; a.N = x.N; a.H = x.H; a.W = x.W; a.KS = 3; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
-        a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.precision = c->vgg_precision;
+        a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld;
+        a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : PREC_F16X3);
+        if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : 0];
         if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
         B.a[i] = out; x = out;
     }
@@ -249,7 +259,9 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 ConvArgs d{};
                 d.src[0] = ConvSrc{gz.g, gz.sn, gz.ld, L.pd.Cout, L.kd, 0};
                 d.nsrc = 1; d.N = in.N; d.H = in.H; d.W = in.W; d.KS = 3; d.wp = L.wpd; d.Ktot = L.kd;
-                d.Cout = VGG[i].cin; d.Cout_pad = L.cd_pad; d.bias = nullptr; d.act = 0; d.aux = c->conv_aux; d.precision = c->vgg_precision_bwd;
+                d.Cout = VGG[i].cin; d.Cout_pad = L.cd_pad; d.bias = nullptr; d.act = 0; d.aux = c->conv_aux;
+                d.precision = c->vgg_precision_bwd == PREC_BF16X1 ? PREC_BF16X1 : (c->vgg_precision_bwd == PREC_FP32 ? PREC_FP32 : PREC_BF16X3);
+                if (d.precision != PREC_FP32 && L.wqd[0]) d.wq = L.wqd[d.precision == PREC_BF16X1 ? 1 : 0];
                 d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
                 if (i == 0) d.accumulate = 1;                                 // += into d(rec_r), next to the L1 seed
                 else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue

@@ -71,6 +71,8 @@ f32x16 mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int);
 f32x4 mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int);
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c, int, int, int);
 void wave_gather_n(const float* mine, int n, float* all);   // all[lane*n + i]
 
 template <typename... KArgs, typename... Args>
@@ -90,6 +92,7 @@ inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t, hipStream_t, Arg
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu::mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
 
 static inline void __syncthreads() { emu::syncthreads(); }
 

@@ -466,3 +466,97 @@ def conv_fuzz(lib, dev, n, seed):
             conv_case(lib, dev, **kw)
         except AssertionError as e:
             raise AssertionError((i, kw, e))
+
+
+PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
+
+
+def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
+                 split=False, seed=0, tol=None):
+    """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
+    dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
+    Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+    g = torch.Generator().manual_seed(seed)
+    Cin = sum(c for c, _ in segs)
+    xs = [torch.randn(N, c, generator=g) if bc else torch.randn(N, c, H, W, generator=g) for c, bc in segs]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    st = stream(dev)
+    w_d = w.contiguous().to(dev)
+    offs, o = [], 0
+    for c, _ in segs:
+        offs.append((o, c)); o += c
+    d = make_pack([w], offs, 3, lib)
+    d.w[0] = w_d.data_ptr()
+    planes = 2 if precision in (PREC_F16X3, PREC_BF16X3) else 1
+    full = torch.cat([x[:, :, None, None].expand(-1, -1, H, W) if bc else x for x, (c, bc) in zip(xs, segs)], dim=1).double()
+    a = ConvArgs()
+    keep = []
+    if dgrad_seg is None:
+        rows_pad = round_up(Cout, lib.caddy_k_hx_pick_bn(Cout))
+        wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), -1, rows_pad, planes), dtype=torch.uint8, device=dev)
+        assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, -1, precision, st) == 0
+        for i, ((c, bc), x) in enumerate(zip(segs, xs)):
+            if bc:
+                bb = torch.full((N, 16), 7.5); bb[:, :c] = x; bb = bb.to(dev)
+                a.src[i] = ConvSrc(bb.data_ptr(), 16, 16, c, round_up(c, CONV_BK), 1)
+            else:
+                bb = nhwc(x, dev=dev)
+                a.src[i] = ConvSrc(bb.data_ptr(), H * W * bb.shape[3], bb.shape[3], c, round_up(c, CONV_BK), 0)
+            keep.append(bb)
+        a.nsrc, out_c = len(segs), Cout
+        ref = F.conv2d(full, w.double(), b.double() if bias else None, padding=1)
+    else:
+        c_s = segs[dgrad_seg][0]
+        rows_pad = round_up(c_s, lib.caddy_k_hx_pick_bn(c_s))
+        wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), dgrad_seg, rows_pad, planes), dtype=torch.uint8, device=dev)
+        assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, dgrad_seg, precision, st) == 0
+        dy = torch.randn(N, Cout, H, W, generator=g) * 1e-6          # gradient-sized values: far below the f16 range, fine for split bf16
+        bb = nhwc(dy, dev=dev)
+        a.src[0] = ConvSrc(bb.data_ptr(), H * W * bb.shape[3], bb.shape[3], Cout, round_up(Cout, CONV_BK), 0)
+        keep.append(bb)
+        a.nsrc, out_c = 1, c_s
+        fr = full.clone().requires_grad_(True)
+        F.conv2d(fr, w.double(), None, padding=1).backward(dy.double())
+        ref = fr.grad[:, offs[dgrad_seg][0]:offs[dgrad_seg][0] + c_s]
+    a.N, a.H, a.W, a.KS = N, H, W, 3
+    a.wp, a.Ktot, a.Cout, a.Cout_pad = None, sum(round_up(a.src[i].C, CONV_BK) for i in range(a.nsrc)), out_c, round_up(out_c, lib.caddy_k_conv_pick_bn(out_c))
+    a.wq, a.precision = wq.data_ptr(), precision
+    b_d = b.to(dev) if bias else None
+    a.bias, a.act = (b_d.data_ptr() if bias else None), act
+    if act == 1:
+        ref = torch.tanh(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    out_ld = round_up(out_c, 4) + 4
+    init = torch.randn(N, H, W, out_ld, generator=g)
+    out = init.clone().to(dev)
+    if mask:
+        mk = torch.randn(N, H, W, out_ld, generator=g)
+        sr = torch.randn(N, H, W, out_ld, generator=g)
+        mk_d, sr_d = mk.to(dev), sr.to(dev)
+        a.mask = mk_d.data_ptr()
+        if seed_w:
+            a.seed_ref, a.seed_w = sr_d.data_ptr(), seed_w
+        m_, s_ = mk[..., :out_c].permute(0, 3, 1, 2).double(), sr[..., :out_c].permute(0, 3, 1, 2).double()
+        if seed_w:
+            ref = ref + seed_w * torch.sign(m_ - s_)
+        ref = torch.where(m_ > 0, ref, torch.zeros_like(ref))
+    if accumulate:
+        a.accumulate = 1
+        ref = ref + init[..., :out_c].permute(0, 3, 1, 2).double()
+    if split:
+        scr = torch.zeros(8 * N * H * W * round_up(out_c, 4), device=dev)
+        a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
+    a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
+    assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    sync(dev)
+    y = to_nchw(out, out_c).double()
+    scale = ref.abs().max().item()
+    err = (y - ref).abs().max().item() / scale
+    if tol is None:
+        tol = {PREC_F16X3: 2e-6, PREC_BF16X3: 1e-4, PREC_F16X1: 4e-3, PREC_BF16X1: 3e-2}[precision]
+    assert err < tol, ("hx conv", err, tol)
+    assert torch.equal(out[..., out_c:].cpu(), init[..., out_c:])           # pad channels untouched
+    return err

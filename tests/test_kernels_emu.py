@@ -83,3 +83,14 @@ def test_conv_random_shapes():
     1-pixel maps, every dispatch boundary between the MFMA / narrow / 3-channel / thin kernels (CONV_FUZZ_CASES=n for longer hunts)"""
     import os
     K.conv_fuzz(load_emu(), "cpu", int(os.environ.get("CONV_FUZZ_CASES", "100")), seed=1234)
+
+
+def test_conv_hx_split_f16_forward_small():
+    """conv_hx.hip on the simulator: partial tiles (10x20), three segments incl. a broadcast vector, bias, Cout not a multiple of the tile"""
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=72, bias=True)
+
+
+def test_conv_hx_dgrad_mask_seed_epilogue_small():
+    """dgrad form on split bf16 with the fused ReLU mask + L1 seed epilogue (VGG19 perceptual loss) and the accumulate / split-K variants"""
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(64, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, mask=True, seed_w=3e-7)
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(160, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True)

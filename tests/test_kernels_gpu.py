@@ -87,3 +87,31 @@ def test_misc_pointwise(lib):
 
 def test_adam(lib):
     K.adam_case(lib, "cuda", n=100003)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=8, H=32, W=32, segs=[(64, False), (9, True), (128, False)], Cout=512, bias=True),            # R: ConvLSTM0 gates
+    dict(N=2, H=16, W=16, segs=[(256, False), (9, True), (256, False)], Cout=1024, bias=True, split=True),   # ConvLSTM1 gates, slab split-K
+    dict(N=3, H=26, W=20, segs=[(128, False), (4, True)], Cout=128),                                   # Breakout state resolution: ragged tiles
+    dict(N=2, H=128, W=128, segs=[(64, False)], Cout=64),                                              # D: 16x16 x 64-channel tiles
+    dict(N=1, H=256, W=256, segs=[(64, False)], Cout=32),                                              # D: last UpBlock conv
+    dict(N=2, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=2),                            # VGG19 conv + bias + ReLU
+    dict(N=2, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=2, precision=18),              # ... single-product f16
+    dict(N=2, H=40, W=52, segs=[(33, False)], Cout=65),                                                # channel tails on both sides
+])
+def test_conv_hx_forward(lib, kw):
+    K.hx_conv_case(lib, "cuda", **kw)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=8, H=32, W=32, segs=[(64, False), (9, True), (128, False)], Cout=512, dgrad_seg=2, accumulate=True),    # dgrad to h_prev (+=), atomics split-K
+    dict(N=8, H=32, W=32, segs=[(64, False), (9, True), (128, False)], Cout=512, dgrad_seg=0),
+    dict(N=2, H=64, W=64, segs=[(256, False)], Cout=256, dgrad_seg=0, mask=True),                                  # VGG19 dgrad + ReLU mask
+    dict(N=2, H=128, W=128, segs=[(64, False)], Cout=128, dgrad_seg=0, mask=True, seed_w=2e-7),                    # ... + L1 seed of a tapped map
+    dict(N=2, H=64, W=64, segs=[(256, False)], Cout=256, dgrad_seg=0, mask=True, precision=19),
+    dict(N=4, H=16, W=16, segs=[(256, False)], Cout=128, dgrad_seg=0, split=True),                                 # assigning dgrad, slab split-K
+])
+def test_conv_hx_dgrad(lib, kw):
+    kw = dict(kw)
+    kw.setdefault("precision", K.PREC_BF16X3)
+    K.hx_conv_case(lib, "cuda", **kw)

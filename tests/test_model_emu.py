@@ -54,3 +54,12 @@ def test_perceptual_loss_small():
     """VGG19 perceptual term (forward, per-level losses, dgrad chain with fused ReLU masks / L1 seeds, odd-sized max-pools) on the smallest
     geometry the loss accepts; the reference goldens perc_* run on the GPU (the simulator needs minutes for them)"""
     M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=80, gt=1, tau=0.8), lam=0.7)
+
+
+def test_full_reduced_s1_split_operand_kernels():
+    """the default arithmetic of the MI355X runs (split-f16 forward, split-bf16 backward on conv_hx.hip) through the whole driver"""
+    M.SIM_SPLIT = True
+    try:
+        M.full_case("full_reduced_s1", load_emu(), "cpu")
+    finally:
+        M.SIM_SPLIT = False
