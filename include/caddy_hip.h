@@ -160,19 +160,19 @@ int caddy_start_inference(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.
- *     out52 = 13 kernels {k_conv_fwd<2,2,2,2,*>, k_conv_fwd<2,1,2,2,*>, k_conv_fwd<1,1,2,2,*>, k_conv_fwd<1,1,4,1,*>, k_conv_thin_out,
- *             k_conv_thin_in, k_conv_wgrad<2,2,2,2>, k_conv_wgrad<1,2,2,2>, k_conv_wgrad<1,1,1,4>, k_conv_wgrad_small, k_wgrad_thin,
- *             k_conv_wgrad_tile, k_conv_narrow}
+ *     out = CADDY_PROFILE_FAMILIES kernel families (csrc/common.h CK_*: the four k_conv_fwd tilings, k_conv_thin_out, k_conv_thin_in, three
+ *             k_conv_wgrad tilings, k_conv_wgrad_small, k_wgrad_thin, k_conv_wgrad_tile, k_conv_narrow, k_conv_hx<128|64|32>, k_wgrad_hx)
  *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
+#define CADDY_PROFILE_FAMILIES 17
 /* test aid: NaN-fill the not-zero-filled (first-touch) part of the gradient arena before every backward pass */
 int caddy_debug_set_poison(caddy_ctx* ctx, int on);
 /* test aid: caddy_loss_backward stops after the loss kernels, so caddy_get_output_grad returns the gradient of the DIRECT loss terms only
  * (what autograd holds in `.grad` of the stacked output tensors, which the D->E feedback does not read) */
 int caddy_debug_set_seeds_only(caddy_ctx* ctx, int on);
 int caddy_profile_begin(caddy_ctx* ctx);
-int caddy_profile_end(caddy_ctx* ctx, double* out52);
+int caddy_profile_end(caddy_ctx* ctx, double* out /* 4 * CADDY_PROFILE_FAMILIES doubles */);
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each
- * {kind 0 fwd / 1 dgrad / 2 wgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
+ * {kind 0 fwd / 1 dgrad / 2 wgrad / 3 VGG19 forward / 4 VGG19 dgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
 int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);
 
 /* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last

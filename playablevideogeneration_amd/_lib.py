@@ -24,13 +24,13 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("wp", C.c_void_p), ("Ktot", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("bias", C.c_void_p), ("act", C.c_int),
                 ("out", C.c_void_p), ("out_sn", C.c_long), ("out_ld", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("splitk", C.c_int), ("aux", C.c_void_p), ("split_scratch", C.c_void_p), ("split_cap", C.c_long), ("split_stride", C.c_long),
-                ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int)]
+                ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
-                ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long)]
+                ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long), ("precision", C.c_int)]
 
 
 class PackDesc(C.Structure):

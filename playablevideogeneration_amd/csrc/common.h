@@ -67,7 +67,12 @@ struct ConvArgs {
     // split 16-bit operands (conv_hx.hip): weights pre-split by pack_hx for `precision` (PREC_*), rows padded to hx_pick_bn(Cout)
     const void* wq;
     int Kq;                 // set by the launcher: sum of the input segments padded to HX_KC channels
+    float out_scale;        // set by the launcher: 1 / HX_WSCALE for split-f16 weights (stored pre-scaled by a power of two, see pack_hx)
 };
+// split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
+// epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
+// keep only ~8 of its 11 bits.  Scaled by 64 the weights are O(1) and carry 22 bits; |w| < 1023 stays finite.
+#define HX_WSCALE 64.0f
 // ConvArgs.precision.  0 = exact fp32 MFMA (k_conv_fwd; 2 / 3 = its in-loop split-bf16 variants, kept for A/B runs).  >= 16: conv_hx.hip --
 // split f16 (hi + lo, 3 products: fp32-class accuracy, bounded operands = forward activations / weights), split bf16 (3 products: 2^-16, full
 // exponent range = gradients), or single-product 16-bit operands.
@@ -94,6 +99,7 @@ struct WgradArgs {
     int group_n;
     long src_gs[CONV_MAX_SRC];
     long dy_gs;
+    int precision;      // PREC_BF16X3: 3x3 layers with >= 32 channels on both sides run on the 16-bit matrix pipe (k_wgrad_hx); 0: exact fp32
 };
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
@@ -104,6 +110,7 @@ int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 struct PackDesc;
+int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_hx_try(const ConvArgs& a, hipStream_t st);           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
 int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward form, else dgrad form of that input segment */, int precision, hipStream_t st);
 size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);

@@ -37,6 +37,9 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 constexpr int KC = HX_KC;      // channels per chunk
+struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; };
+template <typename T> struct is_bf16 { static constexpr bool value = false; };
+template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 
 // T: _Float16 / __bf16.  NPL planes staged (2: hi + lo, 3 products; 1: hi only).  Tile TH x TW pixels x BN output channels, 4 waves as WM x WN.
 template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN>
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
                 const int y = y0 + m / TW, x = x0 + m % TW;
                 if (y >= a.H || x >= a.W) continue;
                 const long off = (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld + col;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] * a.out_scale + bv;
                 if (a.splitk > 1) {
                     if (a.split_stride) a.out[blockIdx.z * a.split_stride + off] = v;      // slabs: bias / activation applied by the reduce
                     else atomicAdd(a.out + off, v);
@@ -230,6 +233,169 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
 #undef HX_STORE_A
 #undef HX_LOAD_B
 #undef HX_STORE_B
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the 16-bit matrix pipe:  dW[tap][o][k] += sum_pixels dY[p][o] * X[p + tap][k]   (3x3, the layers conv_hx runs forward).
+//
+// GEMM-M = output channels, GEMM-N = input channels, reduction = PIXELS -- so both MFMA operands need 8 consecutive pixels per lane for a
+// fixed channel, the transpose of the NHWC layout.  gfx950's ds_read_b64_tr_b16 does that transpose on the way out of LDS: the tiles are
+// staged as [pixel][channel] (a straight copy of the fp32 NHWC rows, split into bf16 hi | lo on the way) and every 16-lane group reads a
+// [4 pixels][16 channels] block, each lane receiving its channel's four pixels (lane -> operand map measured on the MI355X, tools/probes/
+// tr_probe.hip: lane s of a group supplies the address of row s >> 2, columns 4 (s & 3) .. +3; lane j receives column j of rows 0..3).
+// Tap shifts are whole-pixel address offsets into the halo tile, so the nine taps share one staged X tile (as in k_conv_wgrad_tile).
+// A workgroup owns a 64(o) x 64(k) weight tile for all nine taps -- four waves as 2 x 2, nine 32x32 accumulators each -- walks 4 x 16-pixel
+// spatial tiles persistently with a register prefetch of the next tile, and flushes once with fp32 atomics.  Operands are split bf16
+// (gradients have no lower magnitude bound), three products per fp32 product.  Row pitch 320 B: the four pixel rows x two channel halves of
+// one tr-read cycle fall on disjoint bank octets.
+// ------------------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int WG_TH = 4, WG_TW = 16, WG_KC = 64, WG_OC = 64;
+constexpr int WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
+constexpr int WG_PITCH = 2 * 64 + 32;                       // 16-bit elements per pixel row: hi 64 | lo 64 | pad
+constexpr int WG_XLOADS = (WG_HH * WG_HW * 16 + 255) / 256; // float4 per thread for the X halo (16 float4 per pixel)
+constexpr int WG_YLOADS = WG_TH * WG_TW * 16 / 256;
+
+__device__ __forceinline__ SegRefH find_seg16(const ConvSrc* src, int nsrc, int k) {
+    int s = 0;
+    while (s + 1 < nsrc && k >= src[s].Cpad) { k -= src[s].Cpad; s++; }
+    SegRefH r; r.p = src[s].p; r.sn = src[s].sn; r.ld = src[s].ld; r.C = src[s].C; r.bcast = src[s].bcast; r.c0 = k; r.idx = s;
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 tr_frag(const T* base, int off0, int off1) {
+    typedef typename Vec<T>::v8 v8;
+    union { s16x4 s[2]; v8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+    return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int tiles_y) {
+    typedef typename Vec<T>::v8 v8;
+    typedef typename Vec<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) T Xh[WG_HH * WG_HW * WG_PITCH];
+    __shared__ __attribute__((aligned(16))) T Yt[WG_TH * WG_TW * WG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * WG_KC, o0 = blockIdx.y * WG_OC;
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+
+    // loader roles: float4 column q (0..15) fixed per thread; X halo pixel = (tid >> 4) + 16 i, dY pixel = (tid >> 4) + 16 i
+    const int q = tid & 15;
+    const int kx = k0 + (q >> 2) * CONV_BK;
+    const bool kok = kx < a.Ktot;
+    const SegRefH sg = find_seg16(a.src, a.nsrc, kok ? kx : 0);
+    const int cx = sg.c0 + (q & 3) * 4;                       // channel inside the segment
+    const int yc = o0 + q * 4;
+    float4 rx[WG_XLOADS], ry[WG_YLOADS];
+
+#define WG_LOAD(tile_)                                                                                                              \
+    do {                                                                                                                            \
+        int n_ = (int)((tile_) / (tiles_x * tiles_y));                                                                             \
+        const int rem_ = (int)((tile_) - (long)n_ * tiles_x * tiles_y);                                                            \
+        const int ty_ = rem_ / tiles_x;                                                                                            \
+        const int y0_ = ty_ * WG_TH, x0_ = (rem_ - ty_ * tiles_x) * WG_TW;                                                         \
+        const float* xp_ = sg.p;                                                                                                   \
+        const float* dyb_ = a.dy;                                                                                                  \
+        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * a.src_gs[sg.idx]; dyb_ += grp_ * a.dy_gs; } \
+        const bool cok_ = kok && cx < sg.C;                                                                                        \
+        const float* xb_ = xp_ + (long)n_ * sg.sn + (cok_ ? cx : 0);                                                               \
+        const int pl_ = sg.bcast ? 0 : sg.ld;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
+            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
+            const int hy_ = pix_ / WG_HW, hx_ = pix_ - hy_ * WG_HW;                                                                \
+            const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
+            const bool ok_ = cok_ && hy_ < WG_HH && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                    \
+            float4 v_ = *reinterpret_cast<const float4*>(xb_ + (ok_ ? ((long)y_ * a.W + x_) * pl_ : 0L));                          \
+            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && cx + 1 < sg.C) ? v_.y : 0.f;                                                   \
+            v_.z = (ok_ && cx + 2 < sg.C) ? v_.z : 0.f; v_.w = (ok_ && cx + 3 < sg.C) ? v_.w : 0.f;                                \
+            rx[i] = v_;                                                                                                            \
+        }                                                                                                                          \
+        const bool yok_ = yc < a.Cout;                                                                                             \
+        const float* yb_ = dyb_ + (long)n_ * a.dy_sn + (yok_ ? yc : 0);                                                            \
+        _Pragma("unroll") for (int i = 0; i < WG_YLOADS; i++) {                                                                    \
+            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
+            const int y_ = y0_ + pix_ / WG_TW, x_ = x0_ + (pix_ & (WG_TW - 1));                                                    \
+            const bool ok_ = yok_ && y_ < a.H && x_ < a.W;                                                                         \
+            float4 v_ = *reinterpret_cast<const float4*>(yb_ + (ok_ ? ((long)y_ * a.W + x_) * a.dy_ld : 0L));                      \
+            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && yc + 1 < a.Cout) ? v_.y : 0.f;                                                 \
+            v_.z = (ok_ && yc + 2 < a.Cout) ? v_.z : 0.f; v_.w = (ok_ && yc + 3 < a.Cout) ? v_.w : 0.f;                            \
+            ry[i] = v_;                                                                                                            \
+        }                                                                                                                          \
+    } while (0)
+#define WG_SPLIT_STORE(dst_, v_)                                                                                                   \
+    do {                                                                                                                            \
+        v4 hi_, lo_;                                                                                                                \
+        hi_[0] = (T)(v_).x; hi_[1] = (T)(v_).y; hi_[2] = (T)(v_).z; hi_[3] = (T)(v_).w;                                            \
+        lo_[0] = (T)((v_).x - (float)hi_[0]); lo_[1] = (T)((v_).y - (float)hi_[1]);                                                \
+        lo_[2] = (T)((v_).z - (float)hi_[2]); lo_[3] = (T)((v_).w - (float)hi_[3]);                                                \
+        *reinterpret_cast<v4*>(dst_) = hi_;                                                                                        \
+        *reinterpret_cast<v4*>((dst_) + 64) = lo_;                                                                                 \
+    } while (0)
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    // tr-read lane roles: group g = (lane >> 4) & 1 -> channel half; lane & 15 -> (pixel row (lane & 15) >> 2, column quad lane & 3); lane >> 5 -> pixel octet
+    const int prow = (lane >> 5) * 8 + ((lane & 15) >> 2);            // + 4 rr
+    const int ccol = ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    const int yoff = prow * WG_PITCH + wm * 32 + ccol;
+    const int xoff = prow * WG_PITCH + wn * 32 + ccol;
+
+    long tile = blockIdx.z;
+    if (tile < ntiles) WG_LOAD(tile);
+    for (; tile < ntiles; tile += gridDim.z) {
+#pragma unroll
+        for (int i = 0; i < WG_XLOADS; i++) {
+            const int pix = (tid >> 4) + 16 * i;
+            if (pix < WG_HH * WG_HW) WG_SPLIT_STORE(&Xh[pix * WG_PITCH + 4 * q], rx[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WG_YLOADS; i++) {
+            const int pix = (tid >> 4) + 16 * i;
+            WG_SPLIT_STORE(&Yt[pix * WG_PITCH + 4 * q], ry[i]);
+        }
+        __syncthreads();
+        if (tile + gridDim.z < ntiles) WG_LOAD(tile + gridDim.z);
+#pragma unroll 1
+        for (int r = 0; r < WG_TH; r++) {
+            const T* yb = Yt + r * WG_TW * WG_PITCH + yoff;
+            const v8 ah = tr_frag<T>(yb, 0, 4 * WG_PITCH), al = tr_frag<T>(yb, 64, 4 * WG_PITCH + 64);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    const T* xb = Xh + ((r + dy) * WG_HW + dx) * WG_PITCH + xoff;
+                    const v8 bh = tr_frag<T>(xb, 0, 4 * WG_PITCH), bl = tr_frag<T>(xb, 64, 4 * WG_PITCH + 64);
+                    f32x16 c = acc[dy * 3 + dx];
+                    c = mfma16(al, bh, c);
+                    c = mfma16(ah, bl, c);
+                    c = mfma16(ah, bh, c);
+                    acc[dy * 3 + dx] = c;
+                }
+        }
+        __syncthreads();
+    }
+#undef WG_LOAD
+#undef WG_SPLIT_STORE
+
+    const int k = k0 + wn * 32 + (lane & 31);
+    if (k < a.Ktot) {
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
+            }
+        }
+    }
+}
 
 // ---- weight packing: OIHW fp32 (reference state_dict layout) -> split 16-bit tiles [tap][chunk][Cout_pad][hi 32 | lo 32] ----
 template <typename T, int NPL>
@@ -257,6 +423,7 @@ __global__ void k_pack_hx(PackDesc d, T* wq, int Cout_pad, int dgrad_seg) {
         } else {
             if (row < d.seg_C[dgrad_seg] && k < d.Cout) v = d.w[k / d.Co_each][((long)(k % d.Co_each) * d.Cin + d.seg_off[dgrad_seg] + row) * taps + (taps - 1 - tap)];
         }
+        if (sizeof(T) == 2 && !is_bf16<T>::value) v *= HX_WSCALE;      // f16 forms only (see HX_WSCALE)
         const T hi = (T)v;
         T* o = wq + (((long)tap * nch + ch) * Cout_pad + row) * (NPL * KC) + kk;
         o[0] = hi;
@@ -300,6 +467,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     int kq = 0;
     for (int s = 0; s < a.nsrc; s++) { if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return -1; kq += round_up(a.src[s].C, HX_KC); }
     a.Kq = kq;
+    a.out_scale = (a.precision == PREC_F16X3 || a.precision == PREC_F16X1) ? 1.0f / HX_WSCALE : 1.0f;
     const int bn = hx_pick_bn(a.Cout);
     a.Cout_pad = round_up(a.Cout, bn);
     if (a.mask && a.accumulate) return -1;
@@ -342,5 +510,25 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
 #undef HX_LAUNCH
     g_last_conv_kernel = bn == 128 ? CK_HX_128 : (bn == 64 ? CK_HX_64 : CK_HX_32);
     if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, st);
+    return 1;
+}
+
+// 1 = handled: 3x3 weight gradient with >= 32 channels on both sides on the 16-bit matrix pipe (split bf16 operands).  Same packed fp32
+// gradient layout (dwp[tap][Cout_pad][Ktot], segments padded to 16) and (group, sample) time-batched addressing as k_conv_wgrad_tile.
+int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
+    static const bool off = getenv("CADDY_WGRAD_HX") && atoi(getenv("CADDY_WGRAD_HX")) == 0;      // A/B aid
+    if (off || a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return 0;
+    for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0;
+    if ((a.dy_ld & 3) || (a.dy_sn & 3)) return 0;
+    g_last_conv_kernel = CK_WGRAD_HX;
+    if (dry) return 1;
+    const int tx = cdiv(a.W, WG_TW), ty = cdiv(a.H, WG_TH);
+    const long ntiles = (long)a.N * tx * ty;
+    const int kt = cdiv(a.Ktot, WG_KC), ot = cdiv(a.Cout, WG_OC);
+    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 512;      // persistent workgroups (2 per CU)
+    long g = blocks / ((long)kt * ot);
+    if (g < 1) g = 1;
+    if (g > ntiles) g = ntiles;
+    hipLaunchKernelGGL((k_wgrad_hx<__bf16>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
     return 1;
 }

@@ -768,7 +768,7 @@ int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc,
 static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry);   // dry: only report the kernel (g_last_conv_kernel)
 int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (a0.group_n <= 0 || a0.N <= a0.group_n) return conv_wgrad_launch1(a0, st, false);
-    if (conv_wgrad_launch1(a0, st, true) == 0 && g_last_conv_kernel == CK_WGRAD_TILE) return conv_wgrad_launch1(a0, st, false);
+    if (conv_wgrad_launch1(a0, st, true) == 0 && (g_last_conv_kernel == CK_WGRAD_TILE || g_last_conv_kernel == CK_WGRAD_HX)) return conv_wgrad_launch1(a0, st, false);
     // time-batched arguments on a kernel without (group, sample) addressing: one launch per group
     for (int g = 0; g * a0.group_n < a0.N; g++) {
         WgradArgs a = a0;
@@ -786,6 +786,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     if (a.group_n > 0 && a.N <= a.group_n) a.group_n = 0;
+    if (conv_hx_wgrad_try(a, st, dry) == 1) return 0;       // wide 3x3 layers: split bf16 on the 16-bit matrix pipe (conv_hx.hip)
     if (conv_c4_wgrad_try(a, st, dry) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
     if (conv_thin_wgrad_try(a, st, dry) == 1) return 0;
     if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)

@@ -373,6 +373,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             fill_srcs(w.src, sg, nseg);
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
             w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
+            w.precision = (Lp->wq && prec_bwd != PREC_FP32) ? PREC_BF16X3 : PREC_FP32;
             queue_wgrad(Lp, w, px_taps * Lp->pd.Cin * Lp->pd.Cout);
             bool bias_done = !Lp->dbias;
             for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
@@ -1101,7 +1102,8 @@ int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per
     }
     return n;
 }
-int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT (13) kernels x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes) = 52 doubles
+static_assert(CK_COUNT == CADDY_PROFILE_FAMILIES, "caddy_hip.h: CADDY_PROFILE_FAMILIES");
+int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT kernel families x (launches, algorithmic FLOPs, milliseconds, algorithmic bytes)
     hipStreamSynchronize(c->stream);
     if (c->side) hipStreamSynchronize(c->side);
     for (int i = 0; i < 4 * CK_COUNT; i++) out18[i] = 0.0;

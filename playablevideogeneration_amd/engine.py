@@ -394,7 +394,8 @@ class Engine:
 
     CONV_FAMILIES = ["k_conv_fwd<2, 2, 2, 2, 0, 1>", "k_conv_fwd<2, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 4, 1, 0, 1>",
                      "k_conv_thin_out", "k_conv_thin_in", "k_conv_wgrad<2, 2, 2, 2>", "k_conv_wgrad<1, 2, 2, 2>", "k_conv_wgrad<1, 1, 1, 4>",
-                     "k_conv_wgrad_small", "k_wgrad_thin", "k_conv_wgrad_tile", "k_conv_narrow"]      # rocprofv3 kernel names (exact-fp32 build of k_conv_fwd)
+                     "k_conv_wgrad_small", "k_wgrad_thin", "k_conv_wgrad_tile", "k_conv_narrow",
+                     "k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx"]      # csrc/common.h: CK_* (kernel families of the profiling API)
 
     def profile_begin(self):
         self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))
@@ -406,7 +407,7 @@ class Engine:
 
     def profile_end(self):
         """-> {kernel: (launches, algorithmic FLOPs, milliseconds, algorithmic bytes)}, HIP events on the launch stream."""
-        out = (C.c_double * 52)()
+        out = (C.c_double * (4 * len(self.CONV_FAMILIES)))()
         self._check(self.lib.caddy_profile_end(C.c_void_p(self.ctx), out))
         return {n: (int(out[4 * i]), out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]) for i, n in enumerate(self.CONV_FAMILIES)}
 

@@ -94,3 +94,9 @@ def test_conv_hx_dgrad_mask_seed_epilogue_small():
     """dgrad form on split bf16 with the fused ReLU mask + L1 seed epilogue (VGG19 perceptual loss) and the accumulate / split-K variants"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(64, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, mask=True, seed_w=3e-7)
     K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(160, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True)
+
+
+def test_wgrad_hx_split_bf16_small():
+    """k_wgrad_hx on the simulator (ds_read_b64_tr_b16 transposing fragment reads): ragged tiles, three segments incl. a broadcast vector,
+    output-channel tail; the forward / dgrad of the same case run on the exact kernels"""
+    K.conv_case(load_emu(), "cpu", N=2, H=13, W=10, segs=[(64, 0), (9, 1), (40, 0)], Cout=72, KS=3, wgrad_precision=17, wgrad_tol=1e-4)

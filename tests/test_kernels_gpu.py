@@ -115,3 +115,14 @@ def test_conv_hx_dgrad(lib, kw):
     kw = dict(kw)
     kw.setdefault("precision", K.PREC_BF16X3)
     K.hx_conv_case(lib, "cuda", **kw)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=8, H=32, W=32, segs=[(64, 0), (9, 1), (128, 0)], Cout=512, KS=3, nw=4, bias=True),      # ConvLSTM0 gates
+    dict(N=3, H=26, W=20, segs=[(128, 0), (4, 1)], Cout=128, KS=3),                                 # Breakout state resolution
+    dict(N=2, H=64, W=64, segs=[(128, 0)], Cout=128, KS=3),                                         # D residual block
+    dict(N=2, H=128, W=128, segs=[(64, 0)], Cout=32, KS=3),                                         # D last UpBlock conv
+    dict(N=2, H=40, W=52, segs=[(33, 0)], Cout=65, KS=3),                                           # channel tails
+])
+def test_wgrad_hx(lib, kw):
+    K.conv_case(lib, "cuda", wgrad_precision=17, wgrad_tol=1e-4, **kw)

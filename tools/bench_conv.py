@@ -52,6 +52,7 @@ for name, N, H, W, Cin, Cout, KS in SHAPES:
     wa.src[0] = a.src[0]
     wa.nsrc, wa.N, wa.H, wa.W, wa.KS = 1, N, H, W, KS
     wa.dy, wa.dy_sn, wa.dy_ld, wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs = dy.data_ptr(), H * W * dy.shape[3], dy.shape[3], Cout, cp, Kt, dwp.data_ptr(), 0
+    wa.precision = int(os.environ.get("BENCH_WGRAD_PREC", "0"))
     flops = 2.0 * N * H * W * KS * KS * Cin * Cout
     for label, fn in (("fwd", lambda: lib.caddy_k_conv_fwd(C.byref(a), st)), ("wgrad", lambda: lib.caddy_k_conv_wgrad(C.byref(wa), st))):
         if KIND and KIND != label:
