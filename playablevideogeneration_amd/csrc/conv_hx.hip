@@ -481,10 +481,10 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     a.splitk = 1; a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     const long P = (long)a.N * a.H * a.W;
-    if (blocks < 200 && nchunks >= 4 && !a.mask) {
-        int want = (int)((256 + blocks - 1) / blocks);
-        if (want > nchunks / 2) want = nchunks / 2;
-        if (want > 8) want = 8;
+    if (blocks < 200 && nchunks >= 2 && !a.mask) {
+        int want = (int)((512 + blocks - 1) / blocks);         // two workgroups per CU
+        if (want > nchunks) want = nchunks;                     // a slice is at least one chunk (= one staged halo tile) x nine taps
+        if (want > 16) want = 16;
         if (want >= 2) {
             if (a.accumulate && a.act == 0 && !a.bias) a.splitk = want;
             else if (!a.accumulate && a.split_scratch) {

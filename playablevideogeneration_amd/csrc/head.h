@@ -53,6 +53,7 @@ struct SmallLossArgs {
     double* acc;
 };
 
+int head_set_aux(float* aux, int action, const float* variation /* nullable: zeros */, int K, int Da, hipStream_t st);   // [one-hot(action) | variation | 0]
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st);
 int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
 int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, const SamplerHooks* sh, hipStream_t st);

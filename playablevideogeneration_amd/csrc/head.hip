@@ -398,6 +398,14 @@ __global__ void k_softmax_rows(const float* logits, float* prob, float* logp, in
 }
 }  // namespace
 
+__global__ void k_set_aux(float* aux, int action, const float* variation, int K, int Da) {
+    const int i = threadIdx.x;
+    if (i < AUX_LD) aux[i] = i == action ? 1.f : ((variation && i >= K && i < K + Da) ? variation[i - K] : 0.f);
+}
+int head_set_aux(float* aux, int action, const float* variation, int K, int Da, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_aux, dim3(1), dim3(64), 0, st, aux, action, variation, K, Da);
+    return 0;
+}
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st) {
     hipLaunchKernelGGL(k_softmax_rows, dim3(cdiv(NS, 64)), dim3(64), 0, st, logits, prob, logp, NS, K);
     return 0;

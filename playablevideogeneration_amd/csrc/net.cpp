@@ -218,6 +218,13 @@ void build_layers(caddy_ctx* c) {
         for (int i = 0; i < 3; i++) { c->d_up[i].early_bucket = true; c->d_final[i].early_bucket = true; }
         for (int i = 0; i < 2; i++) { c->d_res[i].conv1.early_bucket = c->d_res[i].conv2.early_bucket = true; if (c->d_res[i].has_down) c->d_res[i].down.early_bucket = true; }
     }
+    {   // static roll-out buffers (reference layouts: (3S,H,W) observation, (3,H,W) frame)
+        const size_t px = (size_t)g.height * g.width;
+        c->inf_obs = (float*)c->persist.alloc(px * 3 * g.stacking * 4);
+        c->inf_next = (float*)c->persist.alloc(px * 3 * g.stacking * 4);
+        c->inf_frame = (float*)c->persist.alloc(px * 3 * 4);
+        c->inf_aux = (float*)c->persist.alloc(AUX_LD * 4);
+    }
     if (g.perceptual) vgg_build(c);
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
@@ -866,40 +873,91 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     return finish(c);
 }
 
-// Model.generate_next (model/main_model/model.py:570-607), batch 1, eval mode, persistent ConvLSTM state
+// Model.generate_next (model/main_model/model.py:570-607), batch 1, eval mode, persistent ConvLSTM state.
+// The per-frame kernel sequence reads inf_obs / inf_aux and writes inf_frame / inf_next (static buffers), so that it can be captured once and
+// replayed as one graph launch per frame; observation, action and the outputs move through small stream-ordered copies around it.
+static void rollout_body(caddy_ctx* c) {
+    const caddy_config& g = c->cfg;
+    const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
+    bool dry = c->dry;
+    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false;
+    T4 o = c->alloc(1, H, W, 3 * S);
+    if (!dry) c->ck(pw_nchw_to_nhwc(c->inf_obs, 0, dv(o), c->stream), "obs layout");
+    T4 x65 = c->encode(o, false, nullptr);
+    T4 auxv{c->inf_aux, c->inf_aux, 1, 1, 1, K + Da, AUX_LD, AUX_LD};
+    T4 hdn = c->dynamics(chan(x65, 0, 64), auxv, nullptr);
+    for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(1, H >> r, W >> r, 3);
+    c->render(hdn, 0, 1);
+    if (!dry) {
+        c->ck(pw_nhwc_to_nchw(dv(c->frames[0]), c->inf_frame, (long)3 * H * W, 0, c->stream), "frame out");
+        // obs' = cat[frame, obs[:-3]] (model.py:605) -- copy KERNELS, not memcpy nodes (a captured D2D memcpy costs tens of microseconds per replay)
+        c->ck(pw_copy(TV{c->inf_frame, 1, 1, 3 * H * W / 4, 4, 0, 4}, TV{c->inf_next, 1, 1, 3 * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
+        if (S > 1) c->ck(pw_copy(TV{c->inf_obs, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, TV{c->inf_next + 3 * H * W, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
+    }
+}
+void caddy_ctx::drop_graph() {
+    if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    graph_valid = false;
+}
 static int generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     const caddy_config& g = c->cfg;
     const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
     if (action < 0 || action >= K) { set_error("action out of range"); return -2; }
-    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false;
-    T4 o = c->alloc(1, H, W, 3 * S);
-    if (!dry) c->ck(pw_nchw_to_nhwc(observation, 0, dv(o), c->stream), "obs layout");
-    T4 x65 = c->encode(o, false, nullptr);
-    float* aux = c->falloc(AUX_LD);
-    if (!dry) {
-        hipMemsetAsync(aux, 0, AUX_LD * 4, c->stream);
-        c->ck(pw_fill(TV{aux + action, 1, 1, 1, 1, 4, 4}, 1.f, c->stream), "one-hot action");
-        if (variation) hipMemcpyAsync(aux + K, variation, 4 * Da, hipMemcpyDeviceToDevice, c->stream);
+    static const int graph_env = getenv("CADDY_ROLLOUT_GRAPH") ? atoi(getenv("CADDY_ROLLOUT_GRAPH")) : 1;      // A/B aid: 0 eager on the caller's stream, 2 eager on the internal stream
+    static const bool graph_off = graph_env == 0;
+    if (graph_env == 2) c->graph_failed_soft = true;
+    hipStream_t user = c->stream;
+    const bool try_graph = c->use_graph && !graph_off && !c->graph_failed && !dry;
+    if (try_graph && !c->gstream) {
+        if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { c->graph_failed = true; c->gstream = nullptr; }
+        else { hipEventCreateWithFlags(&c->gev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->gev_out, hipEventDisableTiming); }
     }
-    T4 auxv{aux, aux, 1, 1, 1, K + Da, AUX_LD, AUX_LD};
-    T4 hdn = c->dynamics(chan(x65, 0, 64), auxv, nullptr);
-    for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(1, H >> r, W >> r, 3);
-    c->render(hdn, 0, 1);
+    const bool graphed = try_graph && !c->graph_failed;
+    hipStream_t st = graphed ? c->gstream : user;
+    if (graphed) { hipEventRecord(c->gev_in, user); hipStreamWaitEvent(st, c->gev_in, 0); }      // inputs were produced on the caller's stream
     if (!dry) {
-        c->ck(pw_nhwc_to_nchw(dv(c->frames[0]), frame_out, (long)3 * H * W, 0, c->stream), "frame out");
-        if (obs_out) {
-            hipMemcpyAsync(obs_out, frame_out, sizeof(float) * 3 * H * W, hipMemcpyDeviceToDevice, c->stream);
-            if (S > 1) hipMemcpyAsync(obs_out + 3 * H * W, observation, sizeof(float) * 3 * (S - 1) * H * W, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->inf_obs, observation, sizeof(float) * 3 * S * H * W, hipMemcpyDeviceToDevice, st);
+        c->ck(head_set_aux(c->inf_aux, action, variation, K, Da, st), "one-hot action + variation");
+    }
+    if (graphed) {
+        if (!c->graph_valid && !c->graph_failed_soft) {      // first frame after start_inference: capture the kernel sequence (the capture itself executes nothing)
+            c->stream = st;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                rollout_body(c);
+                ok = hipStreamEndCapture(st, &c->graph) == hipSuccess && c->graph != nullptr && !c->fail;
+                if (ok) ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) == hipSuccess;
+            }
+            c->stream = user;
+            if (ok) c->graph_valid = true;
+            else { c->drop_graph(); c->graph_failed = true; hipGetLastError(); c->fail = false; }
         }
+        if (c->graph_valid) { if (hipGraphLaunch(c->graph_exec, st) != hipSuccess) { c->graph_valid = false; c->graph_failed = true; } }
+        if (!c->graph_valid) { c->stream = st; rollout_body(c); c->stream = user; }      // capture failed: run this frame eagerly (still on the internal stream)
+    } else rollout_body(c);
+    if (!dry) {
+        hipMemcpyAsync(frame_out, c->inf_frame, sizeof(float) * 3 * H * W, hipMemcpyDeviceToDevice, st);
+        if (obs_out) hipMemcpyAsync(obs_out, c->inf_next, sizeof(float) * 3 * S * H * W, hipMemcpyDeviceToDevice, st);
     }
+    if (graphed) { hipEventRecord(c->gev_out, st); hipStreamWaitEvent(user, c->gev_out, 0); }
     return c->fail ? -1 : 0;
 }
 
 static int start_inference(caddy_ctx* c) {
     bool dry = c->dry;
     c->training = false; c->recording = false;
-    for (BNL* b : c->bns) b->eval_valid = false;      // parameters may have changed since the last roll-out
+    c->drop_graph();                                   // weights / state may have changed: re-capture on the next frame
+    if (c->gstream) hipStreamSynchronize(c->gstream);
+    for (BNL* b : c->bns) {                            // eval-mode affine form of every BatchNorm, once per roll-out (not inside the captured frame)
+        b->eval_valid = false;
+        if (!dry) {
+            const int cp = round_up(b->C, 4);
+            c->ck(pw_bn_finalize(nullptr, 1, b->gamma, b->beta, b->rmean, b->rvar, b->C, 0, b->eval_stash, b->eval_stash + cp, b->eval_stash + 2 * cp, b->eval_stash + 3 * cp, c->stream), "bn_finalize");
+            b->eval_valid = true;
+        }
+    }
     c->pack_all();
     for (int i = 0; i < 3; i++) {
         LstmL& L = c->lstm[i];
@@ -1030,6 +1088,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
 }
 void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }

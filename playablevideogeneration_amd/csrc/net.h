@@ -113,6 +113,13 @@ struct caddy_ctx {
     int prec_fwd = PREC_F16X3, prec_bwd = PREC_BF16X3;                 // ... of the model's wide 3x3 convolutions (caddy_set_precision; CADDY_PRECISION=exact)
     size_t fwd_off = 0;              // act.off at the end of the last forward: loss_backward allocates its VGG buffers past it and releases them
     int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1
+    // roll-out (generate_next) as ONE graph launch per frame: static input / output / action buffers, the per-frame kernel sequence captured on
+    // an internal stream after start_inference and replayed afterwards (host cost of ~90 launches -> 1); eager fallback when capture fails
+    float *inf_obs = nullptr, *inf_frame = nullptr, *inf_next = nullptr, *inf_aux = nullptr;
+    hipStream_t gstream = nullptr; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false, graph_failed = false, graph_failed_soft = false, use_graph = true;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;
+    void drop_graph();
     bool have_forward = false;
     bool seeds_only = false;         // caddy_debug_set_seeds_only: caddy_loss_backward stops after the loss kernels (tests of the loss gradient seeds)
     bool poison_nz = false;          // caddy_debug_set_poison: NaN-fill the first-touch gradient region before every backward (tests)

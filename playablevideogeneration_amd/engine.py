@@ -161,7 +161,18 @@ class Engine:
             return
         on_gpu = self.device.type == "cuda"
 
+        self.hook_host_seconds, self.hook_calls = 0.0, 0      # host time spent inside the bucket callback (measured: the GIL / ctypes cost of this path)
+
         def _ready(_grads, offset, count, stream, _user):
+            import time as _time
+            t0 = _time.perf_counter()
+            try:
+                return _ready_inner(offset, count, stream)
+            finally:
+                self.hook_host_seconds += _time.perf_counter() - t0
+                self.hook_calls += 1
+
+        def _ready_inner(offset, count, stream):
             sl = self.grads[offset:offset + count]
             if on_gpu and stream:               # enqueue behind the stream on which this range becomes valid (the driver's side stream)
                 with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):

@@ -71,10 +71,12 @@ class Evaluator:
 
     def _batches(self):
         ds = self.dataset
-        if hasattr(ds, "__getitem__") and hasattr(ds, "__len__") and not isinstance(ds, (list, tuple)):
+        if hasattr(ds, "__getitem__") and hasattr(ds, "__len__") and not isinstance(ds, (list, tuple)) and len(ds) > 0:
             from torch.utils.data import DataLoader
-            collate = getattr(ds, "collate_fn", None)
-            return DataLoader(ds, batch_size=self.batch_size, shuffle=False, collate_fn=collate)
+            from .batching import is_batch_element, single_batch_elements_collate_fn
+            if is_batch_element(ds[0]):                        # evaluation/evaluator.py:51: DataLoader(..., collate_fn=single_batch_elements_collate_fn)
+                return DataLoader(ds, batch_size=self.batch_size, shuffle=False, collate_fn=single_batch_elements_collate_fn)
+            return DataLoader(ds, batch_size=self.batch_size, shuffle=False, collate_fn=getattr(ds, "collate_fn", None))
         return ds                                              # any iterable of Batch objects / batch tuples
 
     def compute_actions_accuracy(self, predictions: torch.Tensor, ground_truth: torch.Tensor):

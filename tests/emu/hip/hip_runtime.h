@@ -155,10 +155,22 @@ hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipDeviceSynchronize();
+// graph API: the simulator has no stream capture -- hipStreamBeginCapture fails and the driver keeps its eager roll-out path
+typedef struct emu_graph_t* hipGraph_t;
+typedef struct emu_graph_exec_t* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorInvalidValue; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { *e = nullptr; return hipErrorInvalidValue; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 hipError_t hipGetLastError();
 hipError_t hipPeekAtLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipEventCreate(hipEvent_t* e);
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipEventSynchronize(hipEvent_t e);

@@ -160,7 +160,8 @@ def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
     # Gradients w.r.t. the reconstructions.  The perceptual gradient is DISCONTINUOUS in its input (sign() of the feature L1, ReLU masks,
     # max-pool arg-max): fp32 round-off flips a handful of those decisions, each flip moving one image's gradient by O(1e-2) while all
     # other images agree to 1e-6.  Criteria: (a) per image, against the ORACLE evaluated at the engine's own reconstructions (identical
-    # inputs): median relative error <= 2e-3 and worst image <= 1e-1; (b) against the reference golden (inputs differ by the forward
+    # inputs): median relative error <= max(2e-3, s) and worst image <= max(1e-1, 4 s), s = the oracle's own per-image response to a 1e-5
+    # perturbation of the reconstruction (larger frames: more decisions per image, every image has a few flips); (b) against the reference golden (inputs differ by the forward
     # tolerance): relative L2 <= 3 x the reference arithmetic's own response to a 1e-5 input perturbation (measured with the oracle), >= 2e-2.
     V = O.make_vgg_params()
 
@@ -191,7 +192,9 @@ def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
             go = oracle_seed(mine).flatten(0, 1)
             per = torch.tensor([((g[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])])
             info["per_image_median"].append(per.median().item()); info["per_image_worst"].append(per.max().item())
-            assert per.median().item() < 2e-3 and per.max().item() < 1e-1, ("seed d(total)/d(rec_r) per image", r, per.tolist())
+            g1p = oracle_seed(mine + 1e-5 * torch.randn(mine.shape, generator=gen)).flatten(0, 1)
+            sens_img = torch.tensor([((g1p[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])]).median().item()
+            assert per.median().item() < max(2e-3, sens_img) and per.max().item() < max(1e-1, 4 * sens_img), ("seed d(total)/d(rec_r) per image", r, per.tolist(), sens_img)
             if not c["pre"]:
                 ref = torch.from_numpy(z[f"dout1_{r}"]).flatten(0, 1)
                 o_r = oout[1][r]
@@ -240,18 +243,28 @@ def perceptual_oracle_case(lib, dev, c, lam=1.0):
             (O.observations_loss(obs, m) * (w["rec"] / 3) + term / 3).backward()
             g, go = eng.output_grad(100 + r, out[1][r]).cpu().flatten(0, 1), m.grad.flatten(0, 1)
             per = torch.tensor([((g[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])])
-            assert per.median().item() < 2e-3 and per.max().item() < 1e-1, (r, per.tolist())
+            # yardstick: the reference arithmetic's own response to a 1e-5 perturbation of the reconstruction (discontinuous gradient, see perceptual_case)
+            m2 = (out[1][r].cpu() + 1e-5 * torch.randn(out[1][r].shape, generator=torch.Generator().manual_seed(r))).requires_grad_(True)
+            tot2, comps2 = O.perceptual_loss(obs, m2, V)
+            term2 = comps2[0] * 0.0
+            for cc in comps2:
+                term2 = term2 + cc * lam
+            (O.observations_loss(obs, m2) * (w["rec"] / 3) + term2 / 3).backward()
+            g2 = m2.grad.flatten(0, 1)
+            sens = torch.tensor([((g2[i] - go[i]).double().norm() / go[i].double().norm()).item() for i in range(g.shape[0])]).median().item()
+            assert per.median().item() < max(2e-3, sens) and per.max().item() < max(1e-1, 4 * sens), (r, per.tolist(), sens)
     finally:
         lib.caddy_debug_set_seeds_only(eng.ctx, 0)
     return eng
 
 
-def single_step_grad_case(lib, dev, variant="main", tol_median=5e-3, tol_worst=5e-2):
+def single_step_grad_case(lib, dev, variant="main", tol_median=5e-3, tol_worst=5e-2, size=32):
     """T=2 (one R/D step + D->E feedback + both A calls): gradient check of every op's backward vs the fp64 oracle.
     Without a LeakyReLU slope flip every parameter agrees to ~2e-5; one flip in D shifts everything upstream by ~1e-3
-    (see full_case), hence median / worst bounds instead of a uniform tight one."""
+    (see full_case), hence median / worst bounds instead of a uniform tight one.  size = 128 reaches the kernels only larger feature maps
+    select (k_conv_narrow, k_conv_c4<7,*>, the tile-resident / split-bf16 weight gradients, 16x16-pixel conv_hx tiles)."""
     K_, Da, Ch = (7, 2, 128) if variant == "main" else (3, 1, 64)
-    c = dict(variant=variant, K=K_, Da=Da, Ch=Ch, S=1, B=2, T=2, H=32, W=32, gt=1, tau=0.7, hard=False)
+    c = dict(variant=variant, K=K_, Da=Da, Ch=Ch, S=1, B=2, T=2, H=size, W=size, gt=1, tau=0.7, hard=False)
     d, P, obs = H.inputs_of(c)
     nz = O.Noise()
     torch.manual_seed(H.NOISE_SEED)
@@ -274,6 +287,35 @@ def single_step_grad_case(lib, dev, variant="main", tol_median=5e-3, tol_worst=5
     errs.sort(reverse=True)
     assert errs[0][0] < tol_worst, errs[:3]
     assert errs[len(errs) // 2][0] < tol_median, errs[len(errs) // 2]
+
+
+def rollout_oracle_case(lib, dev, c, steps):
+    """play.py path at its real size against the CPU oracle: start_inference + `steps` x generate_next (actions i mod K, zero variation),
+    every frame (max error, evaluation/metrics/mse.py:21 frame MSE) and the final stacked observation.  This is the code the roll-out
+    benchmark times: batch-1 launches (split-K slabs, thin kernels with compact tables, eval-mode BatchNorm) replayed from a captured graph."""
+    d, P, obs = H.inputs_of(dict(c, B=1, T=1))
+    orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=False)
+    eng = make_engine(dict(c, B=1, T=2), lib, dev)
+    eng.load_state_dict(P)
+    o_ref = o = obs[0, 0]
+    worst = worst_mse = 0.0
+    with torch.no_grad():
+        orc.start_inference()
+        eng.start_inference()
+        for i in range(steps):
+            fr, o_ref = orc.generate_next(o_ref, i % c["K"])
+            f, o = eng.generate_next(o, i % c["K"])
+            err = f.cpu() - fr
+            worst, worst_mse = max(worst, err.abs().max().item()), max(worst_mse, (err ** 2).mean().item())
+            assert err.abs().max().item() < 2e-3 and (err ** 2).mean().item() < 1e-6, (i, err.abs().max().item(), (err ** 2).mean().item())
+    assert (o.cpu() - o_ref).abs().max().item() < 2e-3
+    # a second roll-out from the same start must reproduce the first one bit for bit (graph replay, persistent ConvLSTM state re-initialised)
+    eng.start_inference()
+    o2 = obs[0, 0]
+    for i in range(steps):
+        f2, o2 = eng.generate_next(o2, i % c["K"])
+    assert torch.equal(o2, o) and torch.equal(f2, f)
+    return dict(worst_abs=worst, worst_mse=worst_mse)
 
 
 def oracle_case(lib, dev, c, fwd_tol=3e-4):

@@ -52,13 +52,19 @@ def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
         _lib.load()
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, gpu=False):
     import torch.distributed as dist
-    from tests.emu.loader import load_emu
     from playablevideogeneration_amd.engine import Engine
     from oracle import caddy_oracle as O
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if gpu:                                           # one process per GPU over RCCL (tests/test_model_gpu.py, needs >= 2 devices)
+        torch.cuda.set_device(rank)
+        dev, lib = f"cuda:{rank}", None
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        from tests.emu.loader import load_emu
+        dev, lib = "cpu", load_emu()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     d = O.Dims(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1, state_res=(2, 2))
     P = O.make_params(d, seed=3)
     g = torch.Generator().manual_seed(100 + rank)
@@ -67,7 +73,7 @@ def _dp_worker(rank, world, port, out):
              "eps_states_rec": torch.randn(3, 1, generator=g), "eps_dirs_rec": torch.randn(2, 1, generator=g)}
 
     def fresh(overlap):
-        e = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device="cpu", lib=load_emu())
+        e = Engine(variant="reduced", batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device=dev, lib=lib)
         e.load_state_dict(P)
         e.enable_data_parallel(overlap=overlap)
         e.forward_full(obs, 1, 0.8, noise, training=True, fetch_outputs=False)
@@ -75,21 +81,31 @@ def _dp_worker(rank, world, port, out):
         return e
 
     eng = fresh(overlap=False)                      # plain path: one flat all-reduce after the backward
+    small = {"logits": eng.output(6), "rec_logits": eng.output(15), "dir_dist": eng.output(10)}      # this rank's shard of the small action tensors
     local = eng.grads.clone()
     dist.all_reduce(eng.grads)
     eng2 = fresh(overlap=True)                      # bench.py's path: R / D buckets start during loss_backward, the rest afterwards
     assert len(eng2._early) == 2 and sum(c for _, c, _ in eng2._early) > 0.5 * eng2.grads.numel()
     eng2.allreduce_gradients()
     eng.adam_step(1, grad_scale=1.0 / world)
-    torch.save({"local": local, "reduced": eng.grads.clone(), "reduced_overlap": eng2.grads.clone(), "params": eng.params[:eng.n_train].clone(),
-                "centroids": eng.view("centroid_estimator.estimated_centroids").clone(), "mi_ema": eng.mi_ema.clone()}, os.path.join(out, f"r{rank}.pt"))
+    if gpu:
+        torch.cuda.synchronize()
+    cpu = lambda t: t.detach().cpu().clone()
+    torch.save({"local": cpu(local), "reduced": cpu(eng.grads), "reduced_overlap": cpu(eng2.grads), "params": cpu(eng.params[:eng.n_train]),
+                "centroids": cpu(eng.view("centroid_estimator.estimated_centroids")), "mi_ema": cpu(eng.mi_ema), "small": {k: cpu(v) for k, v in small.items()},
+                "centroids_before": P["centroid_estimator.estimated_centroids"].clone(),
+                "hook_host_us": 1e6 * eng2.hook_host_seconds / max(1, eng2.hook_calls)}, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
 def test_data_parallel_step_gloo_world2(tmp_path):
+    dp_world2_case(tmp_path, gpu=False)
+
+
+def dp_world2_case(tmp_path, gpu):
     import torch.multiprocessing as mp
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), gpu), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.allclose(r0["reduced"], r0["local"] + r1["local"], atol=1e-6)       # sum over ranks
     assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["params"], r1["params"])   # trainable replicas stay identical (BN running stats are rank-local, as under nn.DataParallel)
@@ -99,6 +115,18 @@ def test_data_parallel_step_gloo_world2(tmp_path):
     assert torch.allclose(r0["reduced_overlap"], r0["reduced"], atol=1e-4 * r0["reduced"].abs().max().item())
     # global-batch semantics of the small reductions: identical centroids and MI estimator state on every rank
     assert torch.equal(r0["centroids"], r1["centroids"]) and torch.equal(r0["mi_ema"], r1["mi_ema"])
+    from oracle import caddy_oracle as O
+    # ... and they EQUAL what one process computes on the concatenated batch, as the reference does on GPU0 over the gathered outputs
+    # (training/losses.py:262-265: joint matrix summed over all B*(T-1) samples before symmetrise / normalise; centroid_estimator.py:61-63)
+    cat = {k: torch.cat([r0["small"][k], r1["small"][k]], 0) for k in r0["small"]}
+    K = cat["logits"].shape[-1]
+    _, ema = O.mutual_information_loss(torch.softmax(cat["logits"], -1), torch.softmax(cat["rec_logits"], -1), lamb=1.0, ema=torch.full((K, K), 1.0 / (K * K)), alpha=0.2)
+    assert torch.allclose(r0["mi_ema"], ema, atol=1e-6), (r0["mi_ema"], ema)
+    d = O.Dims(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1, state_res=(2, 2))
+    orc = O.Oracle(d, {"centroid_estimator.estimated_centroids": r0["centroids_before"].clone()}, training=True)
+    orc.update_centroids(cat["dir_dist"], torch.softmax(cat["logits"], -1))
+    assert torch.allclose(r0["centroids"], orc.P["centroid_estimator.estimated_centroids"], atol=1e-6)
+    return r0["hook_host_us"]
 
 
 def _bench_worker(rank, world, port, out):

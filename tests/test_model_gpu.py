@@ -45,9 +45,19 @@ def test_perceptual_loss_odd_pooling_sizes(lib):
     M.perceptual_oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=208, W=160, gt=1, tau=0.6), lam=1.0)
 
 
-def test_larger_geometry_vs_oracle(lib):
-    """breakout-reduced hyper-parameters at 64x64, T=5 (BASELINE configs[0] geometry, shortened) vs the CPU oracle."""
-    M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=5, H=64, W=64, gt=3, tau=0.85))
+def test_baseline_config0_vs_oracle(lib):
+    """BASELINE.json configs[0] exactly: configs/02_breakout.yaml hyper-parameters (reduced model) at 64x64, seq_len 8, batch 4, vs the CPU oracle."""
+    M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=4, T=8, H=64, W=64, gt=6, tau=0.85))
+
+
+def test_tennis_rollout_256_vs_oracle(lib):
+    """BASELINE.json configs[3]: Tennis hyper-parameters (main model, S=4, Da=5) at 256x256, 32-frame roll-out, every frame vs the oracle"""
+    print(M.rollout_oracle_case(lib, "cuda", dict(variant="main", K=7, Da=5, Ch=128, S=4, H=256, W=256), steps=32))
+
+
+def test_single_step_gradients_tight_128(lib):
+    """tight gradient check at a geometry that reaches the kernels of the large feature maps (fp64 oracle: ~20 s of host time)"""
+    M.single_step_grad_case(lib, "cuda", size=128)
 
 
 def test_non_square_frames(lib):
@@ -78,8 +88,20 @@ def test_allreduce_hook_over_rccl_world1(lib):
         eng.allreduce_gradients()
         torch.cuda.synchronize()
         assert torch.equal(eng.grads, before) and not eng._early          # world size 1: the sum over ranks is the identity
+        # host cost of the Python bucket callback (ctypes + GIL + ExternalStream + async all-reduce enqueue), two calls per step
+        per_call_us = 1e6 * eng.hook_host_seconds / max(1, eng.hook_calls)
+        print("bucket hook host cost per call [us]:", per_call_us)
+        assert eng.hook_calls == 2 and per_call_us < 5000
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the gpurun box has one; the same case runs over gloo in the CPU suite)")
+def test_data_parallel_step_rccl_world2(lib, tmp_path):
+    """one process per GPU over RCCL: gradient buckets behind the side stream, the small global-batch all-reduces, identical replicas,
+    MI estimator / centroids equal to a single-process evaluation of the concatenated batch"""
+    from tests.test_cabi_and_dp import dp_world2_case
+    print("bucket hook host cost per call [us]:", dp_world2_case(tmp_path, gpu=True))
 
 
 def test_baseline_geometry_properties(lib):
