@@ -5,9 +5,11 @@ all-reduce for N>1, Adam) on synthetic BAIR-shaped clips -- BASELINE.json config
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `value` = clips/s over all GPUs with inputs resident in HBM.  `roofline` is for the
-dominant kernel family (fp32-MFMA implicit-GEMM conv), timed with HIP events on the launch stream during extra profiled
-steps; `cpu_baseline` is the CPU oracle (port of the reference arithmetic) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `value` = clips/s over all GPUs with inputs resident in HBM (observations never cross PCIe inside
+the step).  The step is the reference's real one: forward_full_model + L1 / VGG19-perceptual / states / KL / MI losses + BPTT + Adam.
+`roofline` is for the dominant kernel family (conv_hx: 3x3 convolutions on the 16-bit matrix pipe with split fp32 operands), timed
+with HIP events on the launch stream during extra profiled steps; `cpu_baseline` is the CPU oracle (port of the reference arithmetic)
+on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -25,9 +27,30 @@ from playablevideogeneration_amd.engine import Engine  # noqa: E402
 from playablevideogeneration_amd.init import init_parameters, random_vgg19_state  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+MFMA16_DENSE_PEAK_TFLOPS = 2500.0 # same guide: bf16 / f16 dense MFMA (v_mfma_f32_32x32x16_{f16,bf16})
+SPLIT_PRODUCTS = 3                # conv_hx: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the 16-bit pipe -> 3 MFMA FLOPs per algorithmic FLOP
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = "profiles/r02_pmc_traffic.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh)
+HX_FAMILIES = ("k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx")
+VGG_CONVS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2), (256, 256, 2), (256, 512, 3),
+             (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]      # (Cin, Cout, number of 2x2 max-pools before): conv1_1 .. conv5_1
+
+
+def vgg_work(n_images, H, W):
+    """Algorithmic work of the perceptual loss per step (SURVEY 8d definitions): two forward passes (ground truth + reconstruction) and
+    one dgrad pass of the 13 VGG19 convolutions at the three resolutions.  -> (FLOPs, bytes)"""
+    fl = by = 0.0
+    for r in range(3):
+        for cin, cout, pools in VGG_CONVS:
+            h, w = (H >> r) >> pools, (W >> r) >> pools
+            px = n_images * h * w
+            fl += 3 * 2.0 * px * 9 * cin * cout
+            by += 3 * 4.0 * (px * cin + px * cout + 9 * cin * cout)
+    return fl, by
 # SURVEY.md 8(d) / BASELINE.md section 3, BAIR 256^2 T=16 gt=6: per clip forward 336.08 GFLOP, 2.2374 GB activations, 0.5159 GB weights/call
-ALGO = {"bair256_t16_b8": dict(gflop_clip_fwd=336.08, act_gb_clip_fwd=2.2374, w_gb_fwd=0.5159)}
+ALGO = {"bair256_t16_b8": dict(gflop_clip_fwd=336.08, act_gb_clip_fwd=2.2374, w_gb_fwd=0.5159),
+        "breakout160_t9_b8": dict(gflop_clip_fwd=24.48, act_gb_clip_fwd=0.2943, w_gb_fwd=0.0772),
+        "breakout64_t8_b4": dict(gflop_clip_fwd=3.40, act_gb_clip_fwd=0.0405, w_gb_fwd=0.0676)}
 
 
 T_START = time.time()
@@ -45,30 +68,39 @@ def make_noise(B, T, K, Da, dev, gen):
             "eps_states_rec": torch.randn(B * T, Da, device=dev, generator=gen), "eps_dirs_rec": torch.randn(B * n, Da, device=dev, generator=gen)}
 
 
-def cpu_baseline(wl):
-    """Oracle (CPU port of the reference arithmetic) on a bounded sample: 1 clip of the same geometry, forward + losses +
-    backward, 1 warm-up + 1 timed iteration on the host cores."""
+def cpu_baseline(wl, perceptual=True):
+    """Oracle (CPU port of the reference arithmetic, oracle/caddy_oracle.py) on a bounded sample: ONE clip of the same geometry, forward +
+    all losses (VGG19 perceptual term included, random-init weights) + backward, 1 warm-up + 2 timed iterations on the host cores."""
     from oracle import caddy_oracle as O
     d = O.Dims(variant=wl["variant"], actions=wl["actions"], action_dim=wl["action_dim"], hidden=wl["hidden"], stacking=wl["stacking"],
                state_res=(wl["height"] // 8, wl["width"] // 8))
     P = {k: v.clone().requires_grad_(O.is_trainable(k)) for k, v in O.make_params(d, seed=0).items()}
-    cores = min(os.cpu_count() or 1, 32)     # oneDNN degrades badly beyond ~32 threads on the 256-core GPU host (measured: >25 min at 256)
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    cores = min(physical, 32)     # oneDNN degrades badly beyond ~32 threads on the many-core GPU host (measured in round 1: > 25 min at 256 threads)
     torch.set_num_threads(cores)
     obs = torch.rand(1, wl["seq_len"], 3 * wl["stacking"], wl["height"], wl["width"]) * 2 - 1
-    w = dict(O.DEFAULT_LOSS_WEIGHTS)
-    dt = None
-    for it in range(2):
+    V = O.make_vgg_params() if perceptual else None
+    w = dict(O.DEFAULT_LOSS_WEIGHTS, perceptual=1.0 if perceptual else 0.0)
+    times = []
+    for it in range(3):
         t0 = time.time()
         orc = O.Oracle(d, P, training=True)
         out = orc.forward_full(obs, wl["gt_init"], tau=wl["tau"])
-        total, _, _ = O.full_model_loss(out, obs, w, mi_ema=torch.full((d.K, d.K), 1.0 / d.K ** 2))
+        total, _, _ = O.full_model_loss(out, obs, w, mi_ema=torch.full((d.K, d.K), 1.0 / d.K ** 2), vgg=V)
         total.backward()
-        dt = time.time() - t0
+        times.append(time.time() - t0)
         for p in P.values():
             p.grad = None
         P["centroid_estimator.estimated_centroids"] = P["centroid_estimator.estimated_centroids"].detach()
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}), oracle forward+losses+backward, 1 warm-up + 1 timed iteration"}
+    dt = sum(times[1:]) / len(times[1:])
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port", "host_physical_cores": physical, "host_logical_cpus": logical,
+            "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}): oracle forward + losses"
+                      + (" incl. VGG19 perceptual" if perceptual else "") + f" + backward; 1 warm-up + 2 timed iterations ({times[1]:.1f} s, {times[2]:.1f} s)"}
 
 
 def rollout_fps(dev, frames=32):
@@ -78,18 +110,25 @@ def rollout_fps(dev, frames=32):
     eng = Engine(variant=c["variant"], batch=1, seq_len=2, height=256, width=256, stacking=c["stacking"], actions=c["actions"],
                  action_dim=c["action_dim"], hidden=c["hidden"], device=dev)
     init_parameters(eng, seed=0)
-    obs = torch.rand(3 * c["stacking"], 256, 256, device=dev) * 2 - 1
-    eng.start_inference()
-    for i in range(4):
-        _, obs = eng.generate_next(obs, i % c["actions"])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(frames):
-        _, obs = eng.generate_next(obs, i % c["actions"])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"metric": "rollout frames/sec", "value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / frames * 1e3,
-            "config": {"workload": "tennis256_s4_rollout32", "variant": "main", "batch": 1, "frames": frames}}
+    obs0 = torch.rand(3 * c["stacking"], 256, 256, device=dev) * 2 - 1
+    runs = []
+    for rep in range(4):                                     # first repetition = warm-up (graph capture, caches); three timed roll-outs
+        obs = obs0
+        eng.start_inference()
+        for i in range(4):
+            _, obs = eng.generate_next(obs, i % c["actions"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            _, obs = eng.generate_next(obs, i % c["actions"])
+        torch.cuda.synchronize()
+        if rep:
+            runs.append(frames / (time.perf_counter() - t0))
+    runs.sort()
+    med = runs[len(runs) // 2]
+    return {"metric": "rollout frames/sec", "value": med, "unit": "frames/s", "ms_per_frame": 1e3 / med, "runs": runs, "spread": (runs[-1] - runs[0]) / med,
+            "config": {"workload": "tennis256_s4_rollout32", "variant": "main", "batch": 1, "frames": frames,
+                       "path": "start_inference + generate_next, one captured HIP graph launch per frame"}}
 
 
 def main():
@@ -184,34 +223,59 @@ def run(a, dev, lib=None, backend="nccl"):
         eng.profile_begin()
         for _ in range(a.profile_steps):
             step()
+        recs = eng.profile_records()                         # per launch: (kind, pixels, K, Cout, KS, algorithmic FLOPs, ms)
         fam = eng.profile_end()
         name, (n, fl, ms, by) = max(fam.items(), key=lambda kv: kv[1][2])
         ms = max(ms, 1e-9)                                   # (the simulator's events report 0)
         tot_ms = sum(v[2] for v in fam.values())
-        traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
+        split = name in HX_FAMILIES                          # the dominant family runs split operands on the 16-bit matrix pipe
+        peak = MFMA16_DENSE_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MATRIX_PEAK_TFLOPS
+        traffic, traffic_src = None, None                    # HBM bytes per launch: only from a PMC file of THIS round; never a stale number
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
-        except OSError:
+            with open(os.path.join(ROOT, PMC_FILE)) as f:
+                pm = json.load(f)
+            if pm.get("workload") == a.workload and pm.get("perceptual") == bool(perc):
+                traffic = pm["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+                traffic_src = PMC_FILE
+        except (OSError, ValueError):
             pass
-        roof = {"kernel": name, "bound": "mfma", "achieved": fl / ms / 1e9, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+        achieved = fl / ms / 1e9
+        roof = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "peak_note": ("fp32-class products on the 16-bit matrix pipe: 3 MFMA products (hi*hi + hi*lo + lo*hi) per algorithmic product, so the "
+                              "algorithmic peak is the dense f16/bf16 MFMA peak 2500 TFLOP/s / 3" if split else "exact-fp32 MFMA peak"),
+                "mfma_flops_issued_frac_of_16bit_dense_peak": (SPLIT_PRODUCTS * achieved / MFMA16_DENSE_PEAK_TFLOPS) if split else None,
                 "launches_per_step": n // a.profile_steps, "avg_launch_us": ms / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "algorithmic_bytes_per_launch": by / n, "all_conv_kernels_ms_per_step": tot_ms / a.profile_steps,
-                "note": "wgrad kernels run on a side stream concurrently with the main stream, so per-launch durations measured inside the step include that sharing",
+                "note": "weight-gradient kernels run on a side stream concurrently with the main stream: per-launch durations measured inside the step include that sharing",
                 "kernels": {k: {"launches": v[0] // a.profile_steps, "tflops": (v[1] / v[2] / 1e9 if v[2] > 0 else 0.0), "ms": v[2] / a.profile_steps,
-                                "avg_us": (v[2] / v[0] * 1e3 if v[0] else 0.0)} for k, v in fam.items()}}
+                                "avg_us": (v[2] / v[0] * 1e3 if v[0] else 0.0)} for k, v in fam.items() if v[0]}}
+        kinds = {0: "model_forward", 1: "model_dgrad", 2: "model_wgrad", 3: "vgg19_forward", 4: "vgg19_dgrad"}
+        grp = {}
+        for kind, _px, _k, _co, _ks, flops, kms in recs:
+            g = grp.setdefault(kinds.get(int(kind), "other"), [0, 0.0, 0.0])
+            g[0] += 1; g[1] += flops; g[2] += kms
+        roof["conv_groups"] = {k: {"launches": v[0] // a.profile_steps, "algorithmic_tflop_per_step": v[1] / a.profile_steps / 1e12, "ms_per_step": v[2] / a.profile_steps,
+                                   "tflops": (v[1] / v[2] / 1e9 if v[2] > 0 else 0.0)} for k, v in grp.items()}
         alg = ALGO.get(a.workload)
-        if alg:   # whole-step figures on SURVEY 8(d)'s algorithmic work: bytes = 3*(B*act + W), flops = 3*B*fwd
+        if alg:   # whole-step figures on SURVEY 8(d)'s algorithmic work: model bytes = 3*(B*act + W), flops = 3*B*fwd; + the VGG19 loss network
             step_bytes = 3 * (B * alg["act_gb_clip_fwd"] + alg["w_gb_fwd"]) * 1e9
             step_flops = 3 * B * alg["gflop_clip_fwd"] * 1e9
+            roof["erad_algorithmic"] = {"gbytes": step_bytes / 1e9, "tflop": step_flops / 1e12}
+            if perc:
+                vfl, vby = vgg_work(B * (T - 1), H, W)
+                roof["vgg19_algorithmic"] = {"gbytes": vby / 1e9, "tflop": vfl / 1e12}
+                step_bytes += vby; step_flops += vfl
             roof["step_hbm_roofline_frac"] = step_bytes / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
-            roof["step_fp32_matrix_frac"] = step_flops / (ms_step * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * 1e12)
+            roof["step_algorithmic_tflops"] = step_flops / (ms_step * 1e-3) / 1e12
+            roof["step_frac_of_split_mfma_peak"] = step_flops / (ms_step * 1e-3) / (MFMA16_DENSE_PEAK_TFLOPS / SPLIT_PRODUCTS * 1e12)
     if world > 1:
         dist.barrier()
     if rank == 0:
         res = {"metric": f"training clips/sec (B x{T}x{H}x{W})", "value": clips_s, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "arithmetic": "fp32 results; wide 3x3 convolutions as split-f16 (forward) / split-bf16 (gradients) operands on the 16-bit MFMA with fp32 accumulation, everything else fp32",
+               "data": "synthetic",
                "config": {"workload": a.workload, "variant": wl["variant"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": T, "frame": [H, W],
                           "gt_init": wl["gt_init"], "parallelism": f"dp{world}",
                           "step": "forward_full_model + L1 / VGG19-perceptual / states / KL / MI losses + BPTT backward + grad all-reduce + Adam"
@@ -224,7 +288,7 @@ def run(a, dev, lib=None, backend="nccl"):
             log(f"roll-out: {res['rollout']['value']:.1f} frames/s")
         if world == 1 and not a.no_cpu_baseline and on_gpu:
             log("cpu baseline (oracle, 1 clip) ...")
-            res["cpu_baseline"] = cpu_baseline(wl)
+            res["cpu_baseline"] = cpu_baseline(wl, perceptual=perc)
             log("cpu baseline done")
         print(json.dumps(res))
     if world > 1 and on_gpu:

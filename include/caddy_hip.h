@@ -192,6 +192,7 @@ int caddy_k_conv_wgrad(const struct WgradArgs* a, void* stream);
 int caddy_k_conv_pick_bn(int cout);
 /* split 16-bit operand form of a layer's weights for the 16-bit-MFMA convolution (conv_hx.hip): seg < 0 forward, else dgrad of that segment */
 int caddy_k_hx_pick_bn(int cout);
+int caddy_k_hx_force_big(int v);      /* tests: 1 / 0 force / forbid the 8-wave 16x16x128 tile variant, -1 automatic */
 long caddy_k_hx_weight_bytes(const struct PackDesc* d, int seg, int rows_pad, int planes);
 int caddy_k_pack_hx(const struct PackDesc* d, void* wq, int rows_pad, int seg, int precision, void* stream);
 int caddy_k_pack_fwd(const struct PackDesc* d, float* wp, void* stream);

@@ -116,6 +116,7 @@ int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward f
 size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
+extern int g_hx_big_override;
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act, hipStream_t st);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);

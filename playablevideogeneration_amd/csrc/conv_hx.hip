@@ -36,25 +36,36 @@ template <> struct Vec<__bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
+#ifndef HX_EXPERIMENT
+#define HX_EXPERIMENT 0      // timing experiments only (tools/gpu_hx_experiments.sh): 1 = no weight-tile traffic in the K loop, 2 = no activation staging, 4 = no per-tap barrier
+#endif
 constexpr int KC = HX_KC;      // channels per chunk
 struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; };
 template <typename T> struct is_bf16 { static constexpr bool value = false; };
 template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 
-// T: _Float16 / __bf16.  NPL planes staged (2: hi + lo, 3 products; 1: hi only).  Tile TH x TW pixels x BN output channels, 4 waves as WM x WN.
-template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
+// T: _Float16 / __bf16.  NPL planes staged (2: hi + lo, 3 products; 1: hi only).  Tile TH x TW pixels x BN output channels, WM x WN waves
+// (4 or 8), each owning a (BM / WM) x (BN / WN) sub-tile.  D = depth of the register ring of weight tiles: the tile of step s + D is
+// requested while step s computes (D = 1: next step only; D = 3: ~1.9 us of latency tolerance at 8 waves -- the weights of a 512-channel
+// layer (9.4 MB split) do not stay in the 4 MB L2 of an XCD, and one step of MFMA work (0.3 - 0.6 us) cannot hide that round trip).
+// Measured on the MI355X (tools/gpu_hx_experiments.sh, VGG 512 -> 512 @32x32 x 60): of 864 us at D = 1 / 4 waves, 46 % was the weight-tile
+// path and 32 % the activation staging (its global loads were also waited for by the in-order vmcnt of the next weight tile).
+template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
+    constexpr int NT = 64 * WM * WN;                         // threads
     constexpr int BM = TH * TW;
     constexpr int HW_ = TW + 2, HH_ = TH + 2, HPX = HW_ * HH_;
     constexpr int PITCH = NPL * KC + 8;                      // LDS row pitch in 16-bit elements: 72 (144 B) or 40 (80 B)
-    constexpr int NA = (HPX + 31) / 32;                      // halo pixels per thread (8 threads x float4 cover one pixel's 32-channel chunk)
+    constexpr int APP = NT / 8;                              // halo pixels staged per pass (8 threads x float4 cover one pixel's 32-channel chunk)
+    constexpr int NA = (HPX + APP - 1) / APP;
     constexpr int BROW16 = NPL * KC * 2 / 16;                // 16-byte pieces per weight row
-    constexpr int NB = (BN * BROW16 + 255) / 256;
+    constexpr int NB = (BN * BROW16 + NT - 1) / NT;
     constexpr int TMt = BM / WM / 32, TNt = BN / WN / 32;
-    static_assert(WM * WN == 4 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave layout");
+    static_assert((WM * WN == 4 || WM * WN == 8) && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave layout");
     static_assert(TW == 16, "row <-> pixel map assumes 16-pixel tile rows");
+    static_assert(D == 1 || D == 3, "9 taps per chunk: the ring depth must divide 9");
     __shared__ __attribute__((aligned(16))) T As[HPX * PITCH];
     __shared__ __attribute__((aligned(16))) T Bs[2][BN * PITCH];
 
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
     int pixoff[NA];                                           // (y * W + x) of the halo pixel, -1: outside the image / beyond the halo
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-        const int p = (tid >> 3) + 32 * i;
+        const int p = (tid >> 3) + APP * i;
         const int hy = p / HW_, hx = p - hy * HW_;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         pixoff[i] = (p < HPX && y >= 0 && y < a.H && x >= 0 && x < a.W) ? y * a.W + x : -1;
@@ -80,34 +91,36 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
     float4 ra[NA];
-#define HX_LOAD_A(chunk_)                                                                                                          \
-    do {                                                                                                                           \
+#define HX_SEG_OF(chunk_)                                                                                                          \
         int s_ = 0, c0_ = (chunk_) * KC;                                                                                          \
         while (s_ + 1 < a.nsrc && c0_ >= (a.src[s_].C + KC - 1) / KC * KC) { c0_ -= (a.src[s_].C + KC - 1) / KC * KC; s_++; }     \
         const ConvSrc sg_ = a.src[s_];                          /* wave-uniform */                                                \
         const int c_ = c0_ + 4 * q;                                                                                               \
-        const bool cok_ = c_ < sg_.C;                            /* branch-free: clamped addresses + selects */                     \
+        const bool cok_ = c_ < sg_.C;
+    // loads only (clamped addresses, no use of the loaded values: the zero-padding / channel-tail selects happen in HX_STORE_A, one chunk
+    // later, so that nothing waits for these loads while the taps of the current chunk run)
+#define HX_LOAD_A(chunk_)                                                                                                          \
+    do {                                                                                                                           \
+        HX_SEG_OF(chunk_)                                                                                                          \
         const float* base_ = sg_.p + (long)n * sg_.sn + (cok_ ? c_ : 0);                                                          \
         const int pl_ = sg_.bcast ? 0 : sg_.ld;                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                                          \
-            const bool ok_ = cok_ && pixoff[i] >= 0;                                                                               \
-            float4 v_ = *reinterpret_cast<const float4*>(base_ + (long)(ok_ ? pixoff[i] : 0) * pl_);                              \
-            v_.x = ok_ ? v_.x : 0.f;                                                                                               \
-            v_.y = (ok_ && c_ + 1 < sg_.C) ? v_.y : 0.f;                                                                           \
-            v_.z = (ok_ && c_ + 2 < sg_.C) ? v_.z : 0.f;                                                                           \
-            v_.w = (ok_ && c_ + 3 < sg_.C) ? v_.w : 0.f;                                                                           \
-            ra[i] = v_;                                                                                                            \
-        }                                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NA; i++)                                                                            \
+            ra[i] = *reinterpret_cast<const float4*>(base_ + (long)((cok_ && pixoff[i] >= 0) ? pixoff[i] : 0) * pl_);             \
     } while (0)
-#define HX_STORE_A()                                                                                                               \
+#define HX_STORE_A(chunk_)                                                                                                         \
     do {                                                                                                                           \
+        HX_SEG_OF(chunk_)                                                                                                          \
+        const bool m1_ = c_ + 1 < sg_.C, m2_ = c_ + 2 < sg_.C, m3_ = c_ + 3 < sg_.C;                                              \
         _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                                          \
-            const int p_ = (tid >> 3) + 32 * i;                                                                                   \
-            if (HPX % 32 == 0 || p_ < HPX) {                                                                                       \
+            const int p_ = (tid >> 3) + APP * i;                                                                                  \
+            if (HPX % APP == 0 || p_ < HPX) {                                                                                      \
+                const bool ok_ = cok_ && pixoff[i] >= 0;                                                                           \
+                const float x0_ = ok_ ? ra[i].x : 0.f, x1_ = (ok_ && m1_) ? ra[i].y : 0.f;                                         \
+                const float x2_ = (ok_ && m2_) ? ra[i].z : 0.f, x3_ = (ok_ && m3_) ? ra[i].w : 0.f;                                \
                 v4 hi_, lo_;                                                                                                       \
-                hi_[0] = (T)ra[i].x; hi_[1] = (T)ra[i].y; hi_[2] = (T)ra[i].z; hi_[3] = (T)ra[i].w;                                \
-                lo_[0] = (T)(ra[i].x - (float)hi_[0]); lo_[1] = (T)(ra[i].y - (float)hi_[1]);                                     \
-                lo_[2] = (T)(ra[i].z - (float)hi_[2]); lo_[3] = (T)(ra[i].w - (float)hi_[3]);                                     \
+                hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
+                lo_[0] = (T)(x0_ - (float)hi_[0]); lo_[1] = (T)(x1_ - (float)hi_[1]);                                             \
+                lo_[2] = (T)(x2_ - (float)hi_[2]); lo_[3] = (T)(x3_ - (float)hi_[3]);                                             \
                 *reinterpret_cast<v4*>(&As[p_ * PITCH + 4 * q]) = hi_;                                                            \
                 if (NPL == 2) *reinterpret_cast<v4*>(&As[p_ * PITCH + KC + 4 * q]) = lo_;                                         \
             }                                                                                                                      \
@@ -116,23 +129,27 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
     // ---- B staging: the (tap, chunk) tile of this workgroup is BN rows x (NPL * 64) bytes, contiguous in global memory ----
     const T* wq = reinterpret_cast<const T*>(a.wq);
     const long wrow = (long)a.Cout_pad * (NPL * KC);
-    u32x4 rb[NB];
-#define HX_LOAD_B(tap_, chunk_)                                                                                                    \
+    u32x4 rb[D][NB];
+#define HX_LOAD_B(set_, tap_, chunk_)                                                                                              \
     do {                                                                                                                           \
         const u32x4* g_ = reinterpret_cast<const u32x4*>(wq + ((long)(tap_) * nchunks + (chunk_)) * wrow + (long)n0 * (NPL * KC)); \
         _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                                          \
-            const int idx_ = tid + 256 * i;                                                                                       \
-            if ((BN * BROW16) % 256 == 0 || idx_ < BN * BROW16) rb[i] = g_[idx_];                                                                             \
+            const int idx_ = tid + NT * i;                                                                                        \
+            if ((BN * BROW16) % NT == 0 || idx_ < BN * BROW16) rb[set_][i] = g_[idx_];                                            \
         }                                                                                                                          \
     } while (0)
-#define HX_STORE_B(buf_)                                                                                                           \
+#define HX_STORE_B(set_, buf_)                                                                                                     \
     do {                                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                                          \
-            const int idx_ = tid + 256 * i;                                                                                       \
-            if ((BN * BROW16) % 256 == 0 || idx_ < BN * BROW16) { const int row_ = idx_ / BROW16, c16_ = idx_ - row_ * BROW16;                                \
-                                      *reinterpret_cast<u32x4*>(&Bs[buf_][row_ * PITCH + c16_ * 8]) = rb[i]; }                    \
+            const int idx_ = tid + NT * i;                                                                                        \
+            if ((BN * BROW16) % NT == 0 || idx_ < BN * BROW16) { const int row_ = idx_ / BROW16, c16_ = idx_ - row_ * BROW16;     \
+                                      *reinterpret_cast<u32x4*>(&Bs[buf_][row_ * PITCH + c16_ * 8]) = rb[set_][i]; }              \
         }                                                                                                                          \
     } while (0)
+    // weight tile of the flattened step index st_ = (chunk - ch0) * 9 + tap, if it exists
+    // (unconditional: past the end the last tile is requested again -- a branch around the loads makes hipcc fall back to vmcnt(0) waits)
+#define HX_LOAD_B_STEP(set_, st_)                                                                                                  \
+    do { int s__ = (st_); s__ = s__ < nsteps ? s__ : nsteps - 1; const int c__ = s__ / 9; HX_LOAD_B(set_, s__ - 9 * c__, ch0 + c__); } while (0)
 
     // ---- fragment addresses ----
     int abase[TMt], bbase[TNt];
@@ -155,43 +172,63 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
     // split-K over channel chunks (blockIdx.z): partial sums combined with atomics (accumulating dgrads) or slabs (a.split_stride)
     const int cper = (nchunks + a.splitk - 1) / a.splitk;
     const int ch0 = blockIdx.z * cper, ch1 = ch0 + cper < nchunks ? ch0 + cper : nchunks;
-    if (ch0 < ch1) { HX_LOAD_A(ch0); HX_LOAD_B(0, ch0); }
-    int bbuf = 0;
+    const int nsteps = ch0 < ch1 ? (ch1 - ch0) * 9 : 0;
+    if (ch0 < ch1) {
+        HX_LOAD_A(ch0);
+#pragma unroll
+        for (int d = 0; d < D; d++) HX_LOAD_B_STEP(d, d);
+    }
+    if (nsteps == 0) { /* empty K slice of a split launch: nothing to add */ }
+    int bbuf = 0, step = 0;
     for (int chunk = ch0; chunk < ch1; chunk++) {
         __syncthreads();                                      // every wave is done reading As (previous chunk)
-        HX_STORE_A();
-        if (chunk + 1 < ch1) HX_LOAD_A(chunk + 1);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-            HX_STORE_B(bbuf);
-            __syncthreads();
-            if (tap < 8) HX_LOAD_B(tap + 1, chunk);
-            else if (chunk + 1 < ch1) HX_LOAD_B(0, chunk + 1);
-            const int toff = ((tap / 3) * HW_ + tap % 3) * PITCH;
-            const T* Bt = Bs[bbuf];
+#if !(HX_EXPERIMENT & 2)
+        HX_STORE_A(chunk);
+#endif
+        // (D = 3: fully unrolled -- hipcc drains vmcnt to 0 at every loop back-edge, which would cut the ring back to depth 1 every third step)
 #pragma unroll
-            for (int s = 0; s < KC / 16; s++) {
-                v8 fa[TMt][NPL], fb[TNt][NPL];
+        for (int tap0 = 0; tap0 < 9; tap0 += D) {
 #pragma unroll
-                for (int i = 0; i < TMt; i++)
+            for (int d = 0; d < D; d++, step++) {
+                const int tap = tap0 + d;
+#if !(HX_EXPERIMENT & 1)
+                HX_STORE_B(d, bbuf);
+#endif
+#if !(HX_EXPERIMENT & 4)
+                __syncthreads();
+#endif
+#if !(HX_EXPERIMENT & 1)
+                HX_LOAD_B_STEP(d, step + D);                  // refill the register set just drained
+#endif
+#if !(HX_EXPERIMENT & 2)
+                if (tap == (D == 1 ? 0 : 3)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile: consumed >= 6 steps later (last chunk: re-requested, unused)
+#endif
+                const int toff = ((tap / 3) * HW_ + tap % 3) * PITCH;
+                const T* Bt = Bs[bbuf];
 #pragma unroll
-                    for (int pl = 0; pl < NPL; pl++) fa[i][pl] = *reinterpret_cast<const v8*>(&As[abase[i] + toff + pl * KC + s * 16]);
+                for (int s = 0; s < KC / 16; s++) {
+                    v8 fa[TMt][NPL], fb[TNt][NPL];
 #pragma unroll
-                for (int j = 0; j < TNt; j++)
+                    for (int i = 0; i < TMt; i++)
 #pragma unroll
-                    for (int pl = 0; pl < NPL; pl++) fb[j][pl] = *reinterpret_cast<const v8*>(&Bt[bbase[j] + pl * KC + s * 16]);
+                        for (int pl = 0; pl < NPL; pl++) fa[i][pl] = *reinterpret_cast<const v8*>(&As[abase[i] + toff + pl * KC + s * 16]);
 #pragma unroll
-                for (int i = 0; i < TMt; i++)
+                    for (int j = 0; j < TNt; j++)
 #pragma unroll
-                    for (int j = 0; j < TNt; j++) {
-                        if (NPL == 2) {                       // small terms first
-                            acc[i][j] = mfma16(fa[i][NPL - 1], fb[j][0], acc[i][j]);
-                            acc[i][j] = mfma16(fa[i][0], fb[j][NPL - 1], acc[i][j]);
+                        for (int pl = 0; pl < NPL; pl++) fb[j][pl] = *reinterpret_cast<const v8*>(&Bt[bbase[j] + pl * KC + s * 16]);
+#pragma unroll
+                    for (int i = 0; i < TMt; i++)
+#pragma unroll
+                        for (int j = 0; j < TNt; j++) {
+                            if (NPL == 2) {                   // small terms first
+                                acc[i][j] = mfma16(fa[i][NPL - 1], fb[j][0], acc[i][j]);
+                                acc[i][j] = mfma16(fa[i][0], fb[j][NPL - 1], acc[i][j]);
+                            }
+                            acc[i][j] = mfma16(fa[i][0], fb[j][0], acc[i][j]);
                         }
-                        acc[i][j] = mfma16(fa[i][0], fb[j][0], acc[i][j]);
-                    }
+                }
+                bbuf ^= 1;
             }
-            bbuf ^= 1;
         }
     }
 
@@ -229,10 +266,12 @@ __global__ __launch_bounds__(256) void k_conv_hx(ConvArgs a, int tiles_x, int ti
     }
 }
 
+#undef HX_SEG_OF
 #undef HX_LOAD_A
 #undef HX_STORE_A
 #undef HX_LOAD_B
 #undef HX_STORE_B
+#undef HX_LOAD_B_STEP
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient on the 16-bit matrix pipe:  dW[tap][o][k] += sum_pixels dY[p][o] * X[p + tap][k]   (3x3, the layers conv_hx runs forward).
@@ -291,16 +330,21 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
     const int yc = o0 + q * 4;
     float4 rx[WG_XLOADS], ry[WG_YLOADS];
 
-#define WG_LOAD(tile_)                                                                                                              \
-    do {                                                                                                                            \
+#define WG_GEOM(tile_)                                                                                                              \
         int n_ = (int)((tile_) / (tiles_x * tiles_y));                                                                             \
         const int rem_ = (int)((tile_) - (long)n_ * tiles_x * tiles_y);                                                            \
         const int ty_ = rem_ / tiles_x;                                                                                            \
         const int y0_ = ty_ * WG_TH, x0_ = (rem_ - ty_ * tiles_x) * WG_TW;                                                         \
+        const bool cok_ = kok && cx < sg.C;                                                                                        \
+        const bool yok_ = yc < a.Cout;
+    // loads only (clamped addresses): the zero-padding / tail selects are applied by WG_STORE one tile later, so that nothing waits for these
+    // loads while the current tile's MFMAs run
+#define WG_LOAD(tile_)                                                                                                              \
+    do {                                                                                                                            \
+        WG_GEOM(tile_)                                                                                                              \
         const float* xp_ = sg.p;                                                                                                   \
         const float* dyb_ = a.dy;                                                                                                  \
         if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * a.src_gs[sg.idx]; dyb_ += grp_ * a.dy_gs; } \
-        const bool cok_ = kok && cx < sg.C;                                                                                        \
         const float* xb_ = xp_ + (long)n_ * sg.sn + (cok_ ? cx : 0);                                                               \
         const int pl_ = sg.bcast ? 0 : sg.ld;                                                                                      \
         _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
@@ -308,21 +352,14 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
             const int hy_ = pix_ / WG_HW, hx_ = pix_ - hy_ * WG_HW;                                                                \
             const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
             const bool ok_ = cok_ && hy_ < WG_HH && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                    \
-            float4 v_ = *reinterpret_cast<const float4*>(xb_ + (ok_ ? ((long)y_ * a.W + x_) * pl_ : 0L));                          \
-            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && cx + 1 < sg.C) ? v_.y : 0.f;                                                   \
-            v_.z = (ok_ && cx + 2 < sg.C) ? v_.z : 0.f; v_.w = (ok_ && cx + 3 < sg.C) ? v_.w : 0.f;                                \
-            rx[i] = v_;                                                                                                            \
+            rx[i] = *reinterpret_cast<const float4*>(xb_ + (ok_ ? ((long)y_ * a.W + x_) * pl_ : 0L));                              \
         }                                                                                                                          \
-        const bool yok_ = yc < a.Cout;                                                                                             \
         const float* yb_ = dyb_ + (long)n_ * a.dy_sn + (yok_ ? yc : 0);                                                            \
         _Pragma("unroll") for (int i = 0; i < WG_YLOADS; i++) {                                                                    \
             const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
             const int y_ = y0_ + pix_ / WG_TW, x_ = x0_ + (pix_ & (WG_TW - 1));                                                    \
             const bool ok_ = yok_ && y_ < a.H && x_ < a.W;                                                                         \
-            float4 v_ = *reinterpret_cast<const float4*>(yb_ + (ok_ ? ((long)y_ * a.W + x_) * a.dy_ld : 0L));                      \
-            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && yc + 1 < a.Cout) ? v_.y : 0.f;                                                 \
-            v_.z = (ok_ && yc + 2 < a.Cout) ? v_.z : 0.f; v_.w = (ok_ && yc + 3 < a.Cout) ? v_.w : 0.f;                            \
-            ry[i] = v_;                                                                                                            \
+            ry[i] = *reinterpret_cast<const float4*>(yb_ + (ok_ ? ((long)y_ * a.W + x_) * a.dy_ld : 0L));                          \
         }                                                                                                                          \
     } while (0)
 #define WG_SPLIT_STORE(dst_, v_)                                                                                                   \
@@ -333,6 +370,30 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
         lo_[2] = (T)((v_).z - (float)hi_[2]); lo_[3] = (T)((v_).w - (float)hi_[3]);                                                \
         *reinterpret_cast<v4*>(dst_) = hi_;                                                                                        \
         *reinterpret_cast<v4*>((dst_) + 64) = lo_;                                                                                 \
+    } while (0)
+#define WG_STORE(tile_)                                                                                                             \
+    do {                                                                                                                            \
+        WG_GEOM(tile_)                                                                                                              \
+        (void)n_;                                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
+            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
+            const int hy_ = pix_ / WG_HW, hx_ = pix_ - hy_ * WG_HW;                                                                \
+            const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
+            const bool ok_ = cok_ && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                                   \
+            float4 v_ = rx[i];                                                                                                     \
+            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && cx + 1 < sg.C) ? v_.y : 0.f;                                                   \
+            v_.z = (ok_ && cx + 2 < sg.C) ? v_.z : 0.f; v_.w = (ok_ && cx + 3 < sg.C) ? v_.w : 0.f;                                \
+            if (pix_ < WG_HH * WG_HW) WG_SPLIT_STORE(&Xh[pix_ * WG_PITCH + 4 * q], v_);                                           \
+        }                                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < WG_YLOADS; i++) {                                                                    \
+            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
+            const int y_ = y0_ + pix_ / WG_TW, x_ = x0_ + (pix_ & (WG_TW - 1));                                                    \
+            const bool ok_ = yok_ && y_ < a.H && x_ < a.W;                                                                         \
+            float4 v_ = ry[i];                                                                                                     \
+            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && yc + 1 < a.Cout) ? v_.y : 0.f;                                                 \
+            v_.z = (ok_ && yc + 2 < a.Cout) ? v_.z : 0.f; v_.w = (ok_ && yc + 3 < a.Cout) ? v_.w : 0.f;                            \
+            WG_SPLIT_STORE(&Yt[pix_ * WG_PITCH + 4 * q], v_);                                                                     \
+        }                                                                                                                          \
     } while (0)
 
     f32x16 acc[9];
@@ -350,16 +411,7 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
     long tile = blockIdx.z;
     if (tile < ntiles) WG_LOAD(tile);
     for (; tile < ntiles; tile += gridDim.z) {
-#pragma unroll
-        for (int i = 0; i < WG_XLOADS; i++) {
-            const int pix = (tid >> 4) + 16 * i;
-            if (pix < WG_HH * WG_HW) WG_SPLIT_STORE(&Xh[pix * WG_PITCH + 4 * q], rx[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < WG_YLOADS; i++) {
-            const int pix = (tid >> 4) + 16 * i;
-            WG_SPLIT_STORE(&Yt[pix * WG_PITCH + 4 * q], ry[i]);
-        }
+        WG_STORE(tile);
         __syncthreads();
         if (tile + gridDim.z < ntiles) WG_LOAD(tile + gridDim.z);
 #pragma unroll 1
@@ -381,7 +433,9 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
         }
         __syncthreads();
     }
+#undef WG_GEOM
 #undef WG_LOAD
+#undef WG_STORE
 #undef WG_SPLIT_STORE
 
     const int k = k0 + wn * 32 + (lane & 31);
@@ -459,6 +513,7 @@ int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg, int precision, h
     return 0;
 }
 int hx_pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+int g_hx_big_override = -1;      // tests: force (1) / forbid (0) the 8-wave 16x16x128 tile variant regardless of the grid size
 
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
@@ -472,8 +527,13 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     a.Cout_pad = round_up(a.Cout, bn);
     if (a.mask && a.accumulate) return -1;
     const int nchunks = kq / HX_KC;
-    // tiles: 8x16 pixels x 128 channels, or 16x16 x 64 / 32
-    const int th = bn == 128 ? 8 : 16;
+    // tiles: 128-channel layers -> 16x16 pixels x 128 channels on 8 waves with the 3-deep weight-tile ring when that fills the chip, else
+    // 8x16 pixels on 4 waves (R's small feature maps); 16x16 x 64 / 32 channels for the narrower layers
+    static const int env_big = getenv("CADDY_HX_BIG") ? atoi(getenv("CADDY_HX_BIG")) : -1;      // A/B aid: 0 never, 1 always (128-channel layers)
+    const int force_big = g_hx_big_override >= 0 ? g_hx_big_override : env_big;
+    bool big = bn == 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) >= 384;
+    if (force_big >= 0) big = bn == 128 && force_big == 1;
+    const int th = (bn == 128 && !big) ? 8 : 16;
     const int tx = cdiv(a.W, 16), ty = cdiv(a.H, th);
     const long blocks = (long)a.N * tx * ty * (a.Cout_pad / bn);
     // under-filled launches: split the channel chunks across blockIdx.z.  Accumulating launches (dgrad +=) combine with fp32 atomics; assigning
@@ -497,9 +557,10 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
 #define HX_LAUNCH(T_, NPL_)                                                                                                       \
     do {                                                                                                                          \
-        if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2>), grid, dim3(256), 0, st, a, tx, ty);            \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1>), grid, dim3(256), 0, st, a, tx, ty);        \
-        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1>), grid, dim3(256), 0, st, a, tx, ty);                      \
+        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3>), grid, dim3(512), 0, st, a, tx, ty);              \
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, 1>), grid, dim3(256), 0, st, a, tx, ty);    \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);     \
+        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);                   \
     } while (0)
     switch (a.precision) {
         case PREC_F16X3: HX_LAUNCH(_Float16, 2); break;

@@ -473,7 +473,7 @@ PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
 
 
 def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
-                 split=False, seed=0, tol=None):
+                 split=False, seed=0, tol=None, big=-1):
     """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
     dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
     Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
@@ -551,7 +551,11 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
         scr = torch.zeros(8 * N * H * W * round_up(out_c, 4), device=dev)
         a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
-    assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    lib.caddy_k_hx_force_big(big)          # 1: the 8-wave 16x16x128 variant with the 3-deep weight-tile ring even on a small grid
+    try:
+        assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    finally:
+        lib.caddy_k_hx_force_big(-1)
     sync(dev)
     y = to_nchw(out, out_c).double()
     scale = ref.abs().max().item()

@@ -146,7 +146,7 @@ def test_device_prefetcher_passthrough_and_batch_objects():
 
 
 def test_training_progress_on_fixed_batch():
-    """8 optimisation steps of the trainer mirror (schedules, fused losses + BPTT, fused Adam) on one fixed batch: reconstruction improves"""
+    """5 optimisation steps of the trainer mirror (schedules, fused losses + BPTT, fused Adam) on one fixed batch: reconstruction improves"""
     from playablevideogeneration_amd import smooth_mi_trainer
     cfg = _config()
     cfg["logging"] = {"save_root_directory": "/tmp"}
@@ -158,7 +158,7 @@ def test_training_progress_on_fixed_batch():
     tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
     tr.global_step = 20000
     rec = []
-    for i in range(8):
+    for i in range(5):
         torch.manual_seed(100 + i)
         _, info, _ = tr.compute_losses(m, (obs, None, None, None), 4)
         tr.optimizer_step(m)
@@ -268,14 +268,15 @@ def trainer_golden_case(name, make_model, with_vgg):
             assert np.array_equal(p.flatten()[:4].float().numpy(), f4[:min(4, p.numel())])
 
 
-@pytest.mark.parametrize("name", ["trainer_reduced_s1", "trainer_pre_reduced_s1"])
-def test_trainer_mirror_matches_reference_trainer_golden(name):
-    trainer_golden_case(name, _make_model, with_vgg=False)
+def test_trainer_mirror_matches_reference_trainer_golden():
+    """(the pretraining golden and the two goldens with the perceptual term run on the MI355X: tests/test_host_api_gpu.py)"""
+    trainer_golden_case("trainer_reduced_s1", _make_model, with_vgg=False)
 
 
-def test_trainer_refuses_objectives_it_does_not_implement():
+def test_trainer_refuses_objectives_it_does_not_implement(monkeypatch):
     """a reference config must never silently train a different objective"""
     from playablevideogeneration_amd import smooth_mi_trainer
+    monkeypatch.setitem(sys.modules, "torchvision", None)      # (tools/ref_harness.py may have installed its stub torchvision earlier in this process)
     cfg = _config()
     m = _make_model(cfg)
     cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = 1.0          # every reference YAML: no VGG19 weights reachable here -> raise

@@ -90,6 +90,11 @@ def test_conv_hx_split_f16_forward_small():
     K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=72, bias=True)
 
 
+def test_conv_hx_8wave_pipelined_variant_small():
+    """the 16x16x128 tile on 8 waves with the 3-deep weight-tile register ring: ragged 20x18 map, K tail (2 chunks + segment padding), Cout tail"""
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=20, W=18, segs=[(40, False), (5, True)], Cout=130, bias=True, act=2, big=1)
+
+
 def test_conv_hx_dgrad_mask_seed_epilogue_small():
     """dgrad form on split bf16 with the fused ReLU mask + L1 seed epilogue (VGG19 perceptual loss) and the accumulate / split-K variants"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(64, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, mask=True, seed_w=3e-7)

@@ -98,6 +98,9 @@ def test_adam(lib):
     dict(N=2, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=2),                            # VGG19 conv + bias + ReLU
     dict(N=2, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=2, precision=18),              # ... single-product f16
     dict(N=2, H=40, W=52, segs=[(33, False)], Cout=65),                                                # channel tails on both sides
+    dict(N=60, H=32, W=32, segs=[(512, False)], Cout=512, bias=True, act=2),                           # VGG19 conv4_x: 8-wave variant, 16 chunks
+    dict(N=3, H=40, W=52, segs=[(128, False), (9, True)], Cout=130, big=1),                            # 8-wave variant, ragged tiles, tails
+    dict(N=8, H=64, W=64, segs=[(128, False)], Cout=128, big=1),
 ])
 def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)

@@ -1,11 +1,13 @@
 #!/bin/bash
-# HBM-traffic counters (separate passes, --kernel-trace only, as the MI355X guide prescribes) -> gpurun_out/pmc_traffic.json
+# HBM-traffic counters (separate passes, --kernel-trace only, as the MI355X guide prescribes) -> gpurun_out/pmc_traffic_<workload>.json
+#   bash tools/gpu_pmc.sh [workload]      (default bair256_t16_b8)
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
+WL=${1:-bair256_t16_b8}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o bair -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout > gpurun_out/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o run -- python bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout > gpurun_out/pmc_$c.log 2>&1
 done
-python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/bair_results.db gpurun_out/pmc_WRITE_SIZE/bair_results.db > gpurun_out/pmc_traffic.json
+python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/run_results.db gpurun_out/pmc_WRITE_SIZE/run_results.db $WL 1 > gpurun_out/pmc_traffic_$WL.json
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
-head -c 600 gpurun_out/pmc_traffic.json
+head -c 400 gpurun_out/pmc_traffic_$WL.json

@@ -1,5 +1,5 @@
 """HBM traffic per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only):
-    python tools/pmc_traffic.py <fetch.db> <write.db> > profiles/<round>_pmc_traffic.json
+    python tools/pmc_traffic.py <fetch.db> <write.db> [workload perceptual(0|1)] > profiles/<round>_pmc_traffic.json
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md: on gfx950 the
 counter expression tallies 128-byte read requests of wide coalesced streams at 64 bytes; WRITE_SIZE used as reported)."""
 import collections
@@ -10,6 +10,11 @@ import sys
 
 
 def short(name):
+    m = re.search(r"k_conv_hxI\w+?Li\d+ELi\d+ELi\d+ELi(\d+)ELi", name)          # hipcc leaves these template kernels mangled in the trace
+    if m:
+        return f"k_conv_hx<{m.group(1)}>"
+    if "k_wgrad_hx" in name:
+        return "k_wgrad_hx"
     n = re.sub(r"\(anonymous namespace\)::", "", name)
     n = re.sub(r"^void ", "", n)
     m = re.match(r"k_map<(\w+)>", n)
@@ -31,7 +36,8 @@ def collect(db, counter):
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {"_doc": __doc__.strip().replace("\n", " "), "kernels": {}}
+out = {"_doc": __doc__.strip().replace("\n", " "), "workload": sys.argv[3] if len(sys.argv) > 3 else None,
+       "perceptual": (sys.argv[4] == "1") if len(sys.argv) > 4 else None, "kernels": {}}
 for k in sorted(fetch):
     n, f = fetch[k]
     w = write.get(k, [n, 0.0])[1]
