@@ -121,7 +121,7 @@ void make_conv(caddy_ctx* c, ConvL& L, const std::vector<std::string>& wn, const
     d.Cout = d.nw * d.Co_each; d.Cout_pad = round_up(d.Cout, conv_pick_bn(d.Cout)); d.Ktot = kt;
     L.wp_floats = (size_t)KS * KS * d.Cout_pad * d.Ktot;
     L.wp = (float*)c->persist.alloc(L.wp_floats * 4);
-    L.dwp = (float*)c->persist.alloc(L.wp_floats * 4);
+    L.dwp = nullptr;      // carved out of ONE contiguous pool at the end of build_layers (one memset per backward instead of one per layer)
     L.kd = round_up(d.Cout, CONV_BK);
     for (int s = 0; s < d.nseg; s++) {
         L.cd_pad[s] = round_up(segC[s], conv_pick_bn(segC[s]));
@@ -200,7 +200,6 @@ void build_layers(caddy_ctx* c) {
         make_conv(c, c->d_final[i], {f + ".weight"}, f + ".bias", i == 2 ? 7 : 3, {w[i + 1]});
     }
     c->centroids = PP(c, "centroid_estimator.estimated_centroids");
-    c->loss_acc = (double*)c->persist.alloc(sizeof(double) * LOSS_SLOTS);
     {   // gradient buckets: trainable parameters of dynamics_network (R) and rendering_network (D) are contiguous ranges of the flat buffer
         const char* pre[2] = {"dynamics_network.", "rendering_network."};
         for (int b = 0; b < 2; b++) {
@@ -226,6 +225,21 @@ void build_layers(caddy_ctx* c) {
         c->inf_aux = (float*)c->persist.alloc(AUX_LD * 4);
     }
     if (g.perceptual) vgg_build(c);
+    {   // zero pool: packed weight gradients of every layer + the (1,h,w,C) gradients of the learned ConvLSTM initial states + the loss accumulators,
+        // contiguous so that loss_backward clears them with a single memset
+        size_t bytes = 0;
+        auto take = [&](size_t n) { size_t o = bytes; bytes += (n + 255) & ~(size_t)255; return o; };
+        std::vector<size_t> offs;
+        for (ConvL* L : c->convs) offs.push_back(take(L->wp_floats * 4));
+        size_t lo[3][2];
+        for (int i = 0; i < 3; i++) { lo[i][0] = take(c->lstm[i].ih.sn * 4); lo[i][1] = take(c->lstm[i].ic.sn * 4); }
+        const size_t acc_off = take(sizeof(double) * LOSS_SLOTS);
+        char* pool = (char*)c->persist.alloc(bytes);
+        c->zero_pool = pool; c->zero_pool_bytes = bytes;
+        for (size_t i = 0; i < c->convs.size(); i++) c->convs[i]->dwp = (float*)(pool + offs[i]);
+        for (int i = 0; i < 3; i++) { c->lstm[i].ih.g = (float*)(pool + lo[i][0]); c->lstm[i].ic.g = (float*)(pool + lo[i][1]); }
+        c->loss_acc = (double*)(pool + acc_off);
+    }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
@@ -814,9 +828,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         static const bool poison_env = getenv("CADDY_POISON_NZ") != nullptr;   // test aid: NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
         if ((poison_env || c->poison_nz) && c->act.top < c->act.cap) hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
             hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
-        for (ConvL* L : c->convs) hipMemsetAsync(L->dwp, 0, L->wp_floats * 4, st);
-        for (int i = 0; i < 3; i++) { hipMemsetAsync(c->lstm[i].ih.g, 0, c->lstm[i].ih.sn * 4, st); hipMemsetAsync(c->lstm[i].ic.g, 0, c->lstm[i].ic.sn * 4, st); }
-        hipMemsetAsync(c->loss_acc, 0, sizeof(double) * LOSS_SLOTS, st);
+        hipMemsetAsync(c->zero_pool, 0, c->zero_pool_bytes, st);      // every layer's packed weight gradient, the ConvLSTM initial-state gradients, the loss accumulators
     }
     if (!dry) c->ensure_side();
     c->sev_used = 0;

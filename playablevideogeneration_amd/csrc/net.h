@@ -97,6 +97,7 @@ struct caddy_ctx {
     HeadState head1, head2;
     float *q_prob = nullptr;
     double* loss_acc = nullptr;
+    char* zero_pool = nullptr; size_t zero_pool_bytes = 0;      // see build_layers
     allreduce_hook_t hook = nullptr; void* hook_user = nullptr; int world = 1;
     // bucketed gradient all-reduce: R's and D's parameter ranges are final once the time loop's backward is done; they are
     // unpacked on the side stream and handed to the caller while A and E-on-ground-truth-frames still run their backward
