@@ -97,6 +97,10 @@ int caddy_load_vgg(caddy_ctx* ctx, const float* vgg_flat);
  * fp32 exponent range: gradient default);  18 / 19 = single-product f16 / bf16 operands (VGG19 only).  caddy_set_precision: the model's
  * convolutions (forward: 0 | 16, backward: 0 | 17); caddy_set_vgg_precision: the perceptual loss network (forward 0 | 16 | 18, dgrad 0 | 17 | 19). */
 int caddy_set_precision(caddy_ctx* ctx, int forward, int backward);
+/* on (default): with caddy_config.perceptual and loaded VGG19 weights, a TRAINING-mode forward also runs the ground-truth branch of the
+ * perceptual loss (resize + VGG19 features of the observations: independent of the model) on the driver's side stream, concurrently with
+ * the model's forward pass; caddy_loss_backward then only runs the reconstruction branch.  off: everything inside caddy_loss_backward. */
+int caddy_set_perceptual_prefetch(caddy_ctx* ctx, int on);
 int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
 
 /* --- context --- */

@@ -533,7 +533,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     const int force_big = g_hx_big_override >= 0 ? g_hx_big_override : env_big;
     bool big = bn == 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) >= 384;
     if (force_big >= 0) big = bn == 128 && force_big == 1;
-    const int th = (bn == 128 && !big) ? 8 : 16;
+    // narrower layers: 16x16-pixel tiles, or 8x16 when those would leave CUs idle (E / A on one time step's frames, R's side branches)
+    const bool small_tiles = bn < 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) < 384;
+    const int th = ((bn == 128 && !big) || small_tiles) ? 8 : 16;
     const int tx = cdiv(a.W, 16), ty = cdiv(a.H, th);
     const long blocks = (long)a.N * tx * ty * (a.Cout_pad / bn);
     // under-filled launches: split the channel chunks across blockIdx.z.  Accumulating launches (dgrad +=) combine with fp32 atomics; assigning
@@ -559,7 +561,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     do {                                                                                                                          \
         if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3>), grid, dim3(512), 0, st, a, tx, ty);              \
         else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, 1>), grid, dim3(256), 0, st, a, tx, ty);    \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, 1>), grid, dim3(256), 0, st, a, tx, ty);   \
         else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);     \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);  \
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);                   \
     } while (0)
     switch (a.precision) {

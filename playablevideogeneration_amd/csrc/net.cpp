@@ -303,6 +303,7 @@ void caddy_ctx::ensure_side() {
     hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (prio) hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
     else hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    if (!gt_done) hipEventCreateWithFlags(&gt_done, hipEventDisableTiming);
 }
 hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the main stream
     if (!use_side || !side) return stream;
@@ -692,6 +693,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
+    if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);      // a forward without a backward in between: the side stream may still read the old observations
     c->act.reset(); c->tape.clear(); c->dbg.clear();
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
@@ -701,6 +703,8 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     // observations -> NHWC
     c->obs = c->alloc(B * T, H, W, 3 * S);
     if (!dry) c->ck(pw_nchw_to_nhwc(obs, (long)3 * S * H * W, dv(c->obs), c->stream), "obs layout");
+    if (g.perceptual && training) vgg_gt_prefetch(c, T - 1, 1);      // VGG19 features of the ground-truth frames: side stream, beside the forward pass
+    else c->gt_prefetched = false;
     c->x65_gt = c->encode(c->obs, false, nullptr);
     c->action_net(c->x65_gt, c->head1, z.eps_states, z.eps_dirs, z.gumbel_uniform, true, samples_in, variations_in);
     c->rec_x65 = c->alloc(B * T, c->hs, c->ws, 65, 68);
@@ -751,6 +755,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     const caddy_config& g = c->cfg;
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
+    if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);
     c->act.reset(); c->tape.clear(); c->dbg.clear();
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
@@ -759,6 +764,8 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     caddy_noise z{}; if (nz) z = *nz;
     c->obs = c->alloc(B * T, H, W, 3 * S);
     if (!dry) c->ck(pw_nchw_to_nhwc(obs, (long)3 * S * H * W, dv(c->obs), c->stream), "obs layout");
+    if (g.perceptual && training) vgg_gt_prefetch(c, T, 0);
+    else c->gt_prefetched = false;
     c->x65_gt = c->encode(c->obs, false, nullptr);
     c->action_net(c->x65_gt, c->head1, z.eps_states, z.eps_dirs, z.gumbel_uniform, true, samples_in, variations_in);
     // state_to_hidden_state_layer (model.py:41-43,413) then D on all B*T frames at once
@@ -1147,6 +1154,7 @@ int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
     if (!vgg_flat) { set_error("null input"); return -2; }
     return vgg_load(c, vgg_flat);
 }
+int caddy_set_perceptual_prefetch(caddy_ctx* c, int on) { c->perc_prefetch = on != 0; return 0; }
 int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
 int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }

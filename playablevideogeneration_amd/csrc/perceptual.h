@@ -19,3 +19,4 @@ int vgg_param_info(int index, caddy_param_info* out);
 void vgg_build(caddy_ctx* c);
 int vgg_load(caddy_ctx* c, const float* flat);
 void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv);
+void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off);

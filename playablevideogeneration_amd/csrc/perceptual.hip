@@ -99,6 +99,26 @@ __global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* 
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
+// ground-truth frames for the VGG19 branch: first 3 channels of observation t + t_off, bilinearly resized like F.interpolate(align_corners=False)
+// does for exact factors (losses.py:450): f = 2 -> 2x2 mean, f = 4 -> mean of the central 2x2 of each 4x4 block (same arithmetic as k_loss_l1)
+__global__ __launch_bounds__(256) void k_gt_resize(TV gt, float* out, int Ho, int Wo, long npix, int f, int t_off, int Tobs, int Trec) {
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < npix; q += (long)gridDim.x * 256) {
+        const long fr = q / ((long)Ho * Wo); const int rem = (int)(q - fr * Ho * Wo); const int y = rem / Wo, x = rem - y * Wo;
+        const long b = fr / Trec, t = fr - b * Trec;
+        const float* g = gt.p + (b * Tobs + t + t_off) * gt.sn;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* ov = &o.x;
+        for (int ch = 0; ch < 3; ch++) {
+            if (f == 1) ov[ch] = g[((long)y * gt.W + x) * gt.ld + ch];
+            else {
+                const int y0 = f == 2 ? 2 * y : 4 * y + 1, x0 = f == 2 ? 2 * x : 4 * x + 1;
+                const float* gp = g + ((long)y0 * gt.W + x0) * gt.ld + ch;
+                ov[ch] = 0.5f * (0.5f * gp[0] + 0.5f * gp[gt.ld]) + 0.5f * (0.5f * gp[(long)gt.W * gt.ld] + 0.5f * gp[(long)(gt.W + 1) * gt.ld]);
+            }
+        }
+        reinterpret_cast<float4*>(out)[q] = o;
+    }
+}
 __global__ void k_copy_f(const float* src, float* dst, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
@@ -219,23 +239,75 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
 }
 }  // namespace
 
+// Ground-truth branch ahead of time: called from the forward pass right after the observations are in NHWC, it runs the resize + the 13
+// convolutions of the ground-truth frames at the three resolutions on the driver's SIDE stream, concurrently with the model's forward pass
+// (whose recurrent convolutions on 16x16 / 32x32 maps leave most of the chip idle).  The five tapped maps per resolution stay in the
+// activation arena until caddy_loss_backward; the other feature maps go through one scratch region reused by the three resolutions.
+void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
+    bool dry = c->dry;
+    const caddy_config& g = c->cfg;
+    const int N = g.batch * Trec;
+    const int tc[5] = {64, 128, 256, 512, 512};
+    size_t scratch_bytes = 0;
+    for (int r = 0; r < 3; r++) {
+        int h = g.height >> r, w = g.width >> r;
+        c->gt_img[r] = valloc(c, N, h, w, 3);                  // (ld 4)
+        for (int l = 0; l < 5; l++) { c->gt_taps[r][l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; }
+    }
+    {   // scratch for the non-tapped maps of the largest resolution (allocation pattern of vgg_forward at r = 0)
+        const size_t m0 = c->act.off;
+        Branch G{};
+        const bool was_dry = c->dry; c->dry = true;
+        vgg_forward(c, c->gt_img[0], G, c->gt_taps[0]);
+        c->dry = was_dry;
+        scratch_bytes = c->act.off - m0;
+        // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every resolution
+        c->gt_scratch_off = m0; c->gt_scratch_end = c->act.off;
+    }
+    c->gt_prefetched = false;
+    if (dry || !c->vgg.loaded || !c->perc_prefetch || !c->training) return;
+    c->ensure_side();
+    if (!c->use_side || !c->side) return;
+    hipStream_t main_st = c->stream, side = c->wgrad_stream();      // ordered after everything enqueued so far (the NHWC observations)
+    c->stream = side;
+    for (int r = 0; r < 3; r++) {
+        const T4& gi = c->gt_img[r];
+        const long npix = (long)gi.N * gi.H * gi.W;
+        hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, side, dv(c->obs), gi.d, gi.H, gi.W, npix, 1 << r, t_off, g.seq_len, Trec);
+        const size_t keep = c->act.off;
+        c->act.off = c->gt_scratch_off;                        // (host-side bump pointer only: the region is private to the side stream)
+        Branch G{};
+        vgg_forward(c, gi, G, c->gt_taps[r]);
+        c->act.off = keep;
+    }
+    c->stream = main_st;
+    hipEventRecord(c->gt_done, side);
+    c->gt_prefetched = true;
+    (void)scratch_bytes;
+}
+
 // Called from loss_backward after the L1 terms (which also wrote the resized ground-truth images gt_img[r]) and before the tape is replayed:
 // accumulates d(perceptual term)/d(rec_r) into the gradients of c->frames[r] and the raw level sums into c->loss_acc.
 void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv) {
     bool dry = c->dry;
     VggState& V = c->vgg;
     hipStream_t st = c->stream;
+    const bool pre = c->gt_prefetched && !dry;      // the ground-truth branch already ran beside the forward pass (vgg_gt_prefetch)
+    if (pre) hipStreamWaitEvent(st, c->gt_done, 0);
     for (int r = 0; r < 3; r++) {
         const T4& rec = c->frames[r];
         const size_t mark = c->act.off;
         // ground-truth branch: keeps only the five tapped maps
         T4 taps[5];
-        { int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
-          for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; } }      // MaxPool2d floors odd sizes
-        const size_t mark2 = c->act.off;
         Branch G{}, R{};
-        vgg_forward(c, gt_img[r], G, taps);
-        c->act.off = mark2;                      // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
+        if (pre) { for (int l = 0; l < 5; l++) taps[l] = c->gt_taps[r][l]; }
+        else {
+            int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
+            for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; }      // MaxPool2d floors odd sizes
+            const size_t mark2 = c->act.off;
+            vgg_forward(c, gt_img[r], G, taps);
+            c->act.off = mark2;                  // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
+        }
         vgg_forward(c, rec, R, nullptr);
         // per-level sums and weights.  w_l = lambda * (l == 0 ? 1 : 2) / 3 / numel_l   (aliasing of level 0 with the total, see the header)
         float wl[5];

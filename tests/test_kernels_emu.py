@@ -90,6 +90,13 @@ def test_conv_hx_split_f16_forward_small():
     K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=72, bias=True)
 
 
+def test_conv_hx_narrow_output_tiles_small():
+    """64- and 32-channel output tiles on 8x16-pixel tiles (under-filled launches) and their dgrad forms"""
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True)
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=9, W=17, segs=[(64, False)], Cout=32, act=2)
+    K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(40, False)], Cout=64, precision=K.PREC_BF16X3, dgrad_seg=0)
+
+
 def test_conv_hx_8wave_pipelined_variant_small():
     """the 16x16x128 tile on 8 waves with the 3-deep weight-tile register ring: ragged 20x18 map, K tail (2 chunks + segment padding), Cout tail"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=20, W=18, segs=[(40, False), (5, True)], Cout=130, bias=True, act=2, big=1)

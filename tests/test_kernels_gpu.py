@@ -101,6 +101,9 @@ def test_adam(lib):
     dict(N=60, H=32, W=32, segs=[(512, False)], Cout=512, bias=True, act=2),                           # VGG19 conv4_x: 8-wave variant, 16 chunks
     dict(N=3, H=40, W=52, segs=[(128, False), (9, True)], Cout=130, big=1),                            # 8-wave variant, ragged tiles, tails
     dict(N=8, H=64, W=64, segs=[(128, False)], Cout=128, big=1),
+    dict(N=8, H=32, W=32, segs=[(64, False)], Cout=64),                                                # E / A on one time step: 8x16 x 64-channel tiles
+    dict(N=8, H=64, W=64, segs=[(32, False)], Cout=32, bias=True),                                     # 8x16 x 32-channel tiles
+    dict(N=8, H=32, W=32, segs=[(64, False)], Cout=65),
 ])
 def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)

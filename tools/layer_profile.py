@@ -16,7 +16,7 @@ gen = torch.Generator(device=dev).manual_seed(1)
 obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1
 def step():
     eng.forward_full(obs, wl["gt_init"], wl["tau"], bench.make_noise(B, T, K, Da, dev, gen), training=True, fetch_outputs=False)
-    eng.loss_backward(configs.LOSS_WEIGHTS)
+    eng.loss_backward(dict(configs.LOSS_WEIGHTS, perceptual=0.0))      # model layers only (the VGG19 groups are reported by bench.py)
 step(); step()
 eng.profile_begin(); step()
 recs = eng.profile_records(); eng.profile_end()
@@ -26,6 +26,6 @@ for kind, P, Kc, Cout, KS, fl, ms in recs:
     a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += ms
 tot = sum(a[2] for a in agg.values())
 print(f"total conv ms (sum of launches, side stream overlaps not subtracted): {tot:.1f}")
-names = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+names = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "vggf", 4: "vggd"}
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
     print(f"{names[k[0]]:5s} P={k[1]:8d} K={k[2]:5d} Cout={k[3]:5d} k{k[4]}  n={a[0]:4d}  {a[2]:7.2f} ms  {a[2]/a[0]*1e3:8.1f} us/launch  {a[1]/a[2]/1e9 if a[2] else 0:6.1f} TF")

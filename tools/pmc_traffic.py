@@ -10,9 +10,12 @@ import sys
 
 
 def short(name):
-    m = re.search(r"k_conv_hxI\w+?Li\d+ELi\d+ELi\d+ELi(\d+)ELi", name)          # hipcc leaves these template kernels mangled in the trace
-    if m:
-        return f"k_conv_hx<{m.group(1)}>"
+    if "k_conv_hx" in name:      # hipcc leaves these template kernels mangled in the trace (and rocprofv3 half-demangles some of them)
+        nums = [int(x) for x in re.findall(r"Li(\d+)E", name)]
+        if "k_conv_hxI" in name and len(nums) >= 4:
+            return f"k_conv_hx<{nums[3]}>"                      # <T, NPL, TH, TW, BN, WM, WN, D>
+        m = re.search(r"ELi16ELi(\d+)ELi", name)
+        return f"k_conv_hx<{m.group(1)}>" if m else "k_conv_hx<?>"
     if "k_wgrad_hx" in name:
         return "k_wgrad_hx"
     n = re.sub(r"\(anonymous namespace\)::", "", name)
