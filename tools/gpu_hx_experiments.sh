@@ -3,7 +3,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 cd playablevideogeneration_amd/csrc
 cp libcaddy_hip.so /tmp/libcaddy_hip.so.orig
-for e in 0 1 2 4 7; do
+for e in ${HX_EXPS:-0 1 2 4 7}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -x hip -I . -I ../../include -DHX_EXPERIMENT=$e -c conv_hx.hip -o /tmp/conv_hx_$e.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libcaddy_hip.so $(ls build/*.o | grep -v conv_hx) /tmp/conv_hx_$e.o
   echo "== HX_EXPERIMENT=$e"
