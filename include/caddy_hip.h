@@ -102,6 +102,11 @@ int caddy_set_precision(caddy_ctx* ctx, int forward, int backward);
  * the model's forward pass; caddy_loss_backward then only runs the reconstruction branch.  off: everything inside caddy_loss_backward. */
 int caddy_set_perceptual_prefetch(caddy_ctx* ctx, int on);
 int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
+/* on (default): caddy_start_inference folds every eval-mode BatchNorm of the roll-out path (E, R's non-recurrent blocks, D) into the packed
+ * weights / bias of the convolution in front of it, and caddy_generate_next runs the folded graph (LeakyReLU and the residual add in the conv
+ * epilogues, the ConvLSTM cells' BatchNorm as a second output of the gate kernel): ~35 fewer launches per frame.  off: one BatchNorm launch per
+ * nn.BatchNorm2d as in the training graph.  Only caddy_generate_next is affected (model.py:570-607, eval mode). */
+int caddy_set_rollout_fold(caddy_ctx* ctx, int on);
 
 /* --- context --- */
 size_t caddy_workspace_bytes(const caddy_config* cfg);

@@ -24,7 +24,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("wp", C.c_void_p), ("Ktot", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("bias", C.c_void_p), ("act", C.c_int),
                 ("out", C.c_void_p), ("out_sn", C.c_long), ("out_ld", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("splitk", C.c_int), ("aux", C.c_void_p), ("split_scratch", C.c_void_p), ("split_cap", C.c_long), ("split_stride", C.c_long),
-                ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float)]
+                ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float),
+                ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int)]
 
 
 class WgradArgs(C.Structure):
@@ -36,7 +37,7 @@ class WgradArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("w", C.c_void_p * 4), ("gw", C.c_void_p * 4), ("nw", C.c_int), ("Co_each", C.c_int), ("Cin", C.c_int), ("KS", C.c_int),
                 ("nseg", C.c_int), ("seg_off", C.c_int * CONV_MAX_SRC), ("seg_C", C.c_int * CONV_MAX_SRC), ("seg_Cpad", C.c_int * CONV_MAX_SRC),
-                ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int)]
+                ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int), ("oscale", C.c_void_p)]
 
 
 def round_up(a, b):

@@ -47,7 +47,7 @@ struct ConvArgs {
     int Ktot;           // sum of Cpad
     int Cout, Cout_pad; // Cout_pad multiple of the N tile
     const float* bias;  // nullable, [Cout]
-    int act;            // 0 none, 1 tanh, 2 ReLU
+    int act;            // 0 none, 1 tanh, 2 ReLU, 3 LeakyReLU(0.2) (BatchNorm-folded inference convolutions)
     float* out;
     long out_sn;
     int out_ld;
@@ -68,6 +68,11 @@ struct ConvArgs {
     const void* wq;
     int Kq;                 // set by the launcher: sum of the input segments padded to HX_KC channels
     float out_scale;        // set by the launcher: 1 / HX_WSCALE for split-f16 weights (stored pre-scaled by a power of two, see pack_hx)
+    // residual input added before the activation (inference with folded BatchNorm: act(conv2'(a) + identity), residual_block.py:57-68);
+    // geometry of `out` except for its own strides.  Supported by k_conv_fwd, k_conv_hx, k_conv_narrow and the split-K reduce.
+    const float* res;
+    long res_sn;
+    int res_ld;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
@@ -117,7 +122,8 @@ size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
 extern int g_hx_big_override;
-int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act, hipStream_t st);
+int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
+                             const float* res, long res_sn, int res_ld, hipStream_t st);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

@@ -252,8 +252,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     else atomicAdd(a.out + off, v);
                     continue;
                 }
+                if (a.res) v += a.res[(long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + col];
                 if (a.act == 1) v = tanhf(v);
                 else if (a.act == 2) v = fmaxf(v, 0.f);
+                else if (a.act == 3) v = v > 0.f ? v : 0.2f * v;
                 if (a.mask) {
                     const float mk = a.mask[off];
                     if (a.seed_ref) { const float d = mk - a.seed_ref[off]; v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
@@ -473,7 +475,7 @@ __global__ void k_pack_hx(PackDesc d, T* wq, int Cout_pad, int dgrad_seg) {
                 if (k < base + pad) { if (k - base < d.seg_C[s]) cin = d.seg_off[s] + k - base; break; }
                 base += pad;
             }
-            if (row < d.Cout && cin >= 0) v = d.w[row / d.Co_each][((long)(row % d.Co_each) * d.Cin + cin) * taps + tap];
+            if (row < d.Cout && cin >= 0) v = d.w[row / d.Co_each][((long)(row % d.Co_each) * d.Cin + cin) * taps + tap] * (d.oscale ? d.oscale[row] : 1.f);
         } else {
             if (row < d.seg_C[dgrad_seg] && k < d.Cout) v = d.w[k / d.Co_each][((long)(k % d.Co_each) * d.Cin + d.seg_off[dgrad_seg] + row) * taps + (taps - 1 - tap)];
         }
@@ -542,21 +544,34 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     // launches use the caller's slab scratch + the fixed-order k_split_reduce (bit-reproducible forward), as k_conv_fwd does.
     a.splitk = 1; a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
+    const float* real_res = a.res;
     const long P = (long)a.N * a.H * a.W;
     if (blocks < 200 && nchunks >= 2 && !a.mask) {
         int want = (int)((512 + blocks - 1) / blocks);         // two workgroups per CU
         if (want > nchunks) want = nchunks;                     // a slice is at least one chunk (= one staged halo tile) x nine taps
         if (want > 16) want = 16;
         if (want >= 2) {
-            if (a.accumulate && a.act == 0 && !a.bias) a.splitk = want;
+            if (a.accumulate && a.act == 0 && !a.bias && !a.res) a.splitk = want;
             else if (!a.accumulate && a.split_scratch) {
                 const int ldc = round_up(a.Cout, 4);
                 while (want >= 2 && (long)want * P * ldc > a.split_cap) want--;
-                if (want >= 2) { a.splitk = want; a.split_stride = P * ldc; a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; }
+                if (want >= 2) { a.splitk = want; a.split_stride = P * ldc; a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr; }
             }
         }
     }
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
+    // launches of at most one workgroup per CU (batch-1 roll-out, R's side branches): every workgroup is a serial chain of (tap, chunk) steps whose
+    // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame
+    static const int env_deep = getenv("CADDY_HX_DEEP") ? atoi(getenv("CADDY_HX_DEEP")) : 1;      // A/B aid
+    const bool deep = env_deep && !big && (a.precision == PREC_F16X3 || a.precision == PREC_BF16X3) && blocks * a.splitk <= 256;
+#define HX_LAUNCH_DEEP(T_)                                                                                                        \
+    do {                                                                                                                          \
+        if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 128, 2, 2, 3>), grid, dim3(256), 0, st, a, tx, ty);            \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 64, 2, 2, 3>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);        \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 32, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);      \
+        else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 32, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);                      \
+    } while (0)
 #define HX_LAUNCH(T_, NPL_)                                                                                                       \
     do {                                                                                                                          \
         if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3>), grid, dim3(512), 0, st, a, tx, ty);              \
@@ -567,14 +582,15 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);                   \
     } while (0)
     switch (a.precision) {
-        case PREC_F16X3: HX_LAUNCH(_Float16, 2); break;
-        case PREC_BF16X3: HX_LAUNCH(__bf16, 2); break;
+        case PREC_F16X3: if (deep) HX_LAUNCH_DEEP(_Float16); else HX_LAUNCH(_Float16, 2); break;
+        case PREC_BF16X3: if (deep) HX_LAUNCH_DEEP(__bf16); else HX_LAUNCH(__bf16, 2); break;
         case PREC_F16X1: HX_LAUNCH(_Float16, 1); break;
         default: HX_LAUNCH(__bf16, 1); break;
     }
 #undef HX_LAUNCH
+#undef HX_LAUNCH_DEEP
     g_last_conv_kernel = bn == 128 ? CK_HX_128 : (bn == 64 ? CK_HX_64 : CK_HX_32);
-    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, st);
+    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
     return 1;
 }
 

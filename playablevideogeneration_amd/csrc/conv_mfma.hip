@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     constexpr int B_BYTES = NS == 0 ? BN * PF * 4 : NS * BN * PH * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
     __shared__ long rowoff[BM];
+    __shared__ long resoff[BM];      // residual input (a.res) offsets, same rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -177,8 +178,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
     if (tid < BM) {
         long p = p0 + tid;
         long off = -1;
-        if (p < P) { long n = p / HW; off = n * a.out_sn + (p - n * HW) * a.out_ld; }
+        long roff = 0;
+        if (p < P) { long n = p / HW; off = n * a.out_sn + (p - n * HW) * a.out_ld; roff = n * a.res_sn + (p - n * HW) * a.res_ld; }
         rowoff[tid] = off;
+        resoff[tid] = roff;
     }
 
     // split-K: blockIdx.z owns a contiguous range of TAPS; partial sums are combined with atomics
@@ -309,8 +312,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
                 long off = rowoff[row];
                 if (off < 0) continue;
                 float v = acc[i][j][r] + bv;
+                if (a.res) v += a.res[resoff[row] + col];
                 if (a.act == 1) v = tanhf(v);
                 else if (a.act == 2) v = fmaxf(v, 0.f);
+                else if (a.act == 3) v = v > 0.f ? v : 0.2f * v;
                 if (a.mask) {
                     const float m = a.mask[off + col];
                     if (a.seed_ref) { const float d = m - a.seed_ref[off + col]; v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
@@ -325,7 +330,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 }
 
 // fixed-order sum of the split-K slabs of a forward conv: out[p][c] = sum_z slab_z[p][c]   (deterministic, unlike atomics)
-__global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act) {
+__global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
+                                                      const float* res, long res_sn, int res_ld) {
     const int C4 = ldc >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < P * C4; i += (long)gridDim.x * 256) {
         long p = i / C4; int c = (int)(i - p * C4) * 4;
@@ -333,8 +339,13 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long str
         float4 v = *reinterpret_cast<const float4*>(q);
         for (int z = 1; z < splits; z++) { float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
         if (bias) { v.x += bias[c < C ? c : 0]; v.y += bias[c + 1 < C ? c + 1 : 0]; v.z += bias[c + 2 < C ? c + 2 : 0]; v.w += bias[c + 3 < C ? c + 3 : 0]; }
-        if (act == 1) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
         long n = p / HW;
+        if (res) {
+            const float* rp = res + n * res_sn + (p - n * HW) * (long)res_ld + c;
+            v.x += rp[0]; if (c + 1 < C) v.y += rp[1]; if (c + 2 < C) v.z += rp[2]; if (c + 3 < C) v.w += rp[3];
+        }
+        if (act == 1) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        else if (act == 3) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
         float* o = out + n * out_sn + (p - n * HW) * (long)out_ld + c;
         if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
         else { if (c < C) o[0] = v.x; if (c + 1 < C) o[1] = v.y; if (c + 2 < C) o[2] = v.z; }
@@ -696,9 +707,10 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
     const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
     if (a.seed_ref && !a.mask) return -1;
+    const bool fold_epilogue = a.act == 3 || a.res != nullptr;      // LeakyReLU / residual epilogues (BatchNorm-folded roll-out): k_conv_fwd, k_conv_hx, k_conv_narrow
     if (!generic_only) {
-        if (conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
-        if (conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
+        if (!fold_epilogue && conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
+        if (!fold_epilogue && conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
         if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)
     }
     long P = (long)a.N * a.H * a.W;
@@ -713,15 +725,16 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
-    if (a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && blocks < 384 && niter >= 16 && a.KS == 3) {
+    if (a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && !a.res && blocks < 384 && niter >= 16 && a.KS == 3) {
         int want = (int)((512 + blocks - 1) / blocks);
         a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
     }
-    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
+    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && !a.res && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
     // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
     // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
     a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
+    const float* real_res = a.res;
     static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
     if (!a.accumulate && a.split_scratch && !no_fsplit && !generic_only && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
         int want = (int)((512 + blocks - 1) / blocks);
@@ -729,7 +742,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         int ldc = round_up(a.Cout, 4);
         if (sk > 1 && (long)sk * P * ldc <= a.split_cap) {
             a.splitk = sk; a.split_stride = P * ldc;
-            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0;
+            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr;
         }
     }
     static const int force_prec = getenv("CADDY_FP32_PLANES") ? atoi(getenv("CADDY_FP32_PLANES")) : -1;   // tuning / A-B aid: 2 | 3 = in-loop split-bf16 planes of k_conv_fwd
@@ -756,12 +769,14 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
     }
 #undef LAUNCH_CONV
-    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, st);
+    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
     return 0;
 }
-int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act, hipStream_t st) {
+int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
+                             const float* res, long res_sn, int res_ld, hipStream_t st) {
     long items = P * (ldc >> 2);
-    hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, bias, act);
+    hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, bias, act,
+                       res, res_sn, res_ld);
     return 0;
 }
 

@@ -115,6 +115,11 @@ __global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, in
                     if (c >= a.Cout) continue;
                     float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
                     if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
+                    if (a.res) {
+                        const float* rp = a.res + (long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + c;
+                        for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += rp[e];
+                    }
+                    if (a.act == 3) for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
                     if (c + 4 <= a.Cout) {
                         float4 r = make_float4(v[0], v[1], v[2], v[3]);
                         if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, in
 // returns 1 if handled, 0 if the shape does not qualify
 int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st) {
     static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;      // A/B aid
-    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || a.act != 0 || a.splitk > 1) return 0;
+    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || (a.act != 0 && a.act != 3) || a.splitk > 1) return 0;
     if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
     if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.out_ld & 3) || (a.out_sn & 3) || a.Cout_pad < 16 * ((a.Cout + 15) / 16)) return 0;
     if ((long)a.N * a.H * a.W < 4096) return 0;                    // tiny maps: the generic kernel's split-K paths do better
@@ -370,6 +375,11 @@ __global__ __launch_bounds__(256) void k_conv_c4(ConvArgs a, int tiles_x, int ti
                     if (c >= a.Cout) continue;
                     float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
                     if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
+                    if (a.res) {
+                        const float* rp = a.res + (long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + c;
+                        for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += rp[e];
+                    }
+                    if (a.act == 3) for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
                     if (c + 4 <= a.Cout) {
                         float4 r = make_float4(v[0], v[1], v[2], v[3]);
                         if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }

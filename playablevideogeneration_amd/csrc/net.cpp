@@ -199,6 +199,15 @@ void build_layers(caddy_ctx* c) {
         std::string f = q + ".final_blocks." + std::to_string(i) + ".conv";
         make_conv(c, c->d_final[i], {f + ".weight"}, f + ".bias", i == 2 ? 7 : 3, {w[i + 1]});
     }
+    {   // conv -> (avg-pool) -> BatchNorm pairs of the roll-out path (E, R's non-recurrent blocks, D): foldable in eval mode
+        auto pair = [&](ConvL& L, BNL& b) { L.fold_bn = &b; L.fold_bias = (float*)c->persist.alloc(sizeof(float) * (size_t)round_up(L.pd.Cout, 4)); };
+        auto pair_res = [&](ResL& R) { pair(R.conv1, R.bn1); pair(R.conv2, R.bn2); if (R.has_down) pair(R.down, R.bnd); };
+        pair(c->e_stem, c->e_bn1);
+        for (int i = 0; i < 6; i++) pair_res(c->e_res[i]);
+        pair(c->r_c0, c->r_bn0); pair(c->r_c1, c->r_bn1); pair(c->r_c2, c->r_bn2);
+        for (int i = 0; i < 3; i++) pair(c->d_up[i], c->d_norm[i]);
+        for (int i = 0; i < 2; i++) pair_res(c->d_res[i]);
+    }
     c->centroids = PP(c, "centroid_estimator.estimated_centroids");
     {   // gradient buckets: trainable parameters of dynamics_network (R) and rendering_network (D) are contiguous ranges of the flat buffer
         const char* pre[2] = {"dynamics_network.", "rendering_network."};
@@ -369,14 +378,16 @@ int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
     return rc;
 }
 
-T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into, bool nz_out) {
+T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into, bool nz_out, const T4* res) {
     int N = 0, H = 0, W = 0;
     for (int s = 0; s < nseg; s++) if (!segs[s].bcast) { N = segs[s].t.N; H = segs[s].t.H; W = segs[s].t.W; break; }
     T4 out = into ? *into : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout));
     ConvArgs a{};
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
-    a.bias = L.bias; a.act = actf; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
+    a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf; a.out = out.d;
+    if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
+    a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; }
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
@@ -430,9 +441,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     return out;
 }
 
-T4 caddy_ctx::pool2(const T4& x) {
+T4 caddy_ctx::pool2(const T4& x, bool actf) {
     T4 o = x.nz ? alloc_nz(x.N, x.H / 2, x.W / 2, x.C) : alloc(x.N, x.H / 2, x.W / 2, x.C);   // conv -> pool -> BatchNorm chains stay first-touch
-    RUN(pw_pool2(dv(x), dv(o), stream));
+    RUN(pw_pool2(dv(x), dv(o), stream, actf ? 1 : 0));
     if (recording) tape.push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), x.nz ? 1 : 0, stream)); });
     return o;
 }
@@ -512,6 +523,15 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
 // ResidualBlock (model/layers/residual_block.py:51-68)
 T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
     Seg sx{x, 0, true};
+    if (fold) {      // roll-out: BatchNorms folded into the convs -- conv1' (+ pool) + LeakyReLU, then act(conv2'(a) + identity) in conv2's epilogue
+        T4 a1 = conv(R.conv1, &sx, 1, R.ds == 1 ? 3 : 0, nullptr);
+        if (R.ds == 2) a1 = pool2(a1, true);
+        Seg sa{a1, 0, true};
+        if (!R.has_down) return conv(R.conv2, &sa, 1, 3, into, false, &x);
+        T4 idn = conv(R.down, &sx, 1, 0, nullptr);
+        if (R.ds == 2) idn = pool2(idn);
+        return conv(R.conv2, &sa, 1, 3, into, false, &idn);
+    }
     T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr, true);        // conv -> (pool) -> BatchNorm: single assigning gradient writer
     if (R.ds == 2) c1 = pool2(c1);
     T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr, true);      // consumed by conv2 only
@@ -529,8 +549,8 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
 T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
     Seg so{obs_in, 0, input_grad};
     T4 x = conv(e_stem, &so, 1, 0, nullptr, true);
-    x = pool2(x);
-    x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr);
+    x = pool2(x, fold);
+    if (!fold) x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr);
     for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr);
     T4 dst = into ? *into : alloc(x.N, hs, ws, 65, 68);
     return resblock(e_res[5], x, &dst);
@@ -563,6 +583,14 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
     T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     T4 hn, cn;
     if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
+    if (fold) {      // roll-out: the cell's eval-mode BatchNorm is a second output of the point-wise kernel
+        T4 hb = alloc(B, L.Hs, L.Ws, L.C);
+        const int cp = round_up(L.bn.C, 4);
+        TV hbv = dv(hb);
+        RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream, &hbv, L.bn.eval_stash + 2 * cp, L.bn.eval_stash + 3 * cp));
+        L.h = hn; L.c = cn;
+        return hb;
+    }
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
     if (recording) tape.push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
@@ -574,15 +602,16 @@ T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
     T4 x = lstm_step(0, state, aux);
     Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
     x = conv(r_c0, s0, 2, 0, nullptr, true);
-    x = pool2(x);
-    x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr);
+    x = pool2(x, fold);
+    if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr);
     x = lstm_step(1, x, aux);
     Seg s1[2] = {{x, 0, true}, {aux, 1, true}};
-    x = conv(r_c1, s1, 2, 0, nullptr, true);
-    x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr);
+    x = conv(r_c1, s1, 2, fold ? 3 : 0, nullptr, true);
+    if (!fold) x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr);
     x = up2(x);
     x = lstm_step(2, x, aux);
     Seg s2[2] = {{x, 0, true}, {aux, 1, true}};
+    if (fold) return conv(r_c2, s2, 2, 3, into);
     x = conv(r_c2, s2, 2, 0, nullptr, true);
     return bn_act(x, r_bn2, nullptr, nullptr, true, into);
 }
@@ -594,9 +623,10 @@ void caddy_ctx::render(const T4& hdn, int slot, int nslots) {
     for (int i = 0; i < 3; i++) {
         T4 u = up2(x);
         Seg su{u, 0, true};
-        T4 c = conv(d_up[i], &su, 1, 0, nullptr, true);
-        x = bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr);
+        T4 c = conv(d_up[i], &su, 1, fold ? 3 : 0, nullptr, true);
+        x = fold ? c : bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr);
         if (i < 2) x = resblock(d_res[i], x, nullptr);
+        if (rollout && i < 2) continue;      // generate_next returns the full-resolution frame only (model.py:597-601): the two low-resolution heads are dead code there
         T4 dst = tslice(frames[2 - i], B, nslots, slot);
         Seg sx{x, 0, true};
         conv(d_final[i], &sx, 1, 1, &dst);
@@ -648,11 +678,18 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tape.push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
-void caddy_ctx::pack_all() {
+void caddy_ctx::pack_all(bool with_fold) {
+    packed_fold = with_fold;
     for (ConvL* L : convs) {
-        RUN(pack_fwd(L->pd, L->wp, stream));
-        for (int s = 0; s < L->pd.nseg; s++) RUN(pack_dgrad(L->pd, s, L->wpd[s], L->cd_pad[s], L->kd, stream));
-        if (L->wq && prec_fwd != PREC_FP32) RUN(pack_hx(L->pd, L->wq, round_up(L->pd.Cout, hx_pick_bn(L->pd.Cout)), -1, PREC_F16X3, stream));
+        PackDesc fpd = L->pd;      // forward forms: optionally with the following eval-mode BatchNorm folded in (roll-out)
+        if (with_fold && L->fold_bn) {
+            const int cp = round_up(L->fold_bn->C, 4);
+            fpd.oscale = L->fold_bn->eval_stash + 2 * cp;
+            RUN(pw_fold_bias(L->bias, fpd.oscale, L->fold_bn->eval_stash + 3 * cp, L->fold_bias, L->pd.Cout, stream));
+        }
+        RUN(pack_fwd(fpd, L->wp, stream));
+        if (!with_fold) for (int s = 0; s < L->pd.nseg; s++) RUN(pack_dgrad(L->pd, s, L->wpd[s], L->cd_pad[s], L->kd, stream));
+        if (L->wq && prec_fwd != PREC_FP32) RUN(pack_hx(fpd, L->wq, round_up(L->pd.Cout, hx_pick_bn(L->pd.Cout)), -1, PREC_F16X3, stream));
         for (int s = 0; s < L->pd.nseg; s++)
             if (L->wqd[s] && prec_bwd != PREC_FP32 && recording) RUN(pack_hx(L->pd, L->wqd[s], round_up(L->pd.seg_C[s], hx_pick_bn(L->pd.seg_C[s])), s, PREC_BF16X3, stream));
     }
@@ -900,6 +937,7 @@ static void rollout_body(caddy_ctx* c) {
     const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
     c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false;
+    c->fold = c->packed_fold; c->rollout = true;
     T4 o = c->alloc(1, H, W, 3 * S);
     if (!dry) c->ck(pw_nchw_to_nhwc(c->inf_obs, 0, dv(o), c->stream), "obs layout");
     T4 x65 = c->encode(o, false, nullptr);
@@ -913,6 +951,7 @@ static void rollout_body(caddy_ctx* c) {
         c->ck(pw_copy(TV{c->inf_frame, 1, 1, 3 * H * W / 4, 4, 0, 4}, TV{c->inf_next, 1, 1, 3 * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
         if (S > 1) c->ck(pw_copy(TV{c->inf_obs, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, TV{c->inf_next + 3 * H * W, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
     }
+    c->fold = false; c->rollout = false;
 }
 void caddy_ctx::drop_graph() {
     if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -927,6 +966,7 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
     static const int graph_env = getenv("CADDY_ROLLOUT_GRAPH") ? atoi(getenv("CADDY_ROLLOUT_GRAPH")) : 1;      // A/B aid: 0 eager on the caller's stream, 2 eager on the internal stream
     static const bool graph_off = graph_env == 0;
     if (graph_env == 2) c->graph_failed_soft = true;
+    if (c->use_fold && !c->packed_fold) { c->drop_graph(); c->prepare_inference_weights(); }      // a forward pass re-packed the plain weights since start_inference
     hipStream_t user = c->stream;
     const bool try_graph = c->use_graph && !graph_off && !c->graph_failed && !dry;
     if (try_graph && !c->gstream) {
@@ -964,20 +1004,25 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
     return c->fail ? -1 : 0;
 }
 
+// eval-mode affine form of every BatchNorm + the packed weights of the roll-out (BatchNorm folded into the preceding conv unless switched off):
+// once per start_inference, and again if a forward pass re-packed the plain weights in between
+void caddy_ctx::prepare_inference_weights() {
+    for (BNL* b : bns) {
+        b->eval_valid = false;
+        if (!dry) {
+            const int cp = round_up(b->C, 4);
+            ck(pw_bn_finalize(nullptr, 1, b->gamma, b->beta, b->rmean, b->rvar, b->C, 0, b->eval_stash, b->eval_stash + cp, b->eval_stash + 2 * cp, b->eval_stash + 3 * cp, stream), "bn_finalize");
+            b->eval_valid = true;
+        }
+    }
+    pack_all(use_fold);
+}
 static int start_inference(caddy_ctx* c) {
     bool dry = c->dry;
     c->training = false; c->recording = false;
     c->drop_graph();                                   // weights / state may have changed: re-capture on the next frame
     if (c->gstream) hipStreamSynchronize(c->gstream);
-    for (BNL* b : c->bns) {                            // eval-mode affine form of every BatchNorm, once per roll-out (not inside the captured frame)
-        b->eval_valid = false;
-        if (!dry) {
-            const int cp = round_up(b->C, 4);
-            c->ck(pw_bn_finalize(nullptr, 1, b->gamma, b->beta, b->rmean, b->rvar, b->C, 0, b->eval_stash, b->eval_stash + cp, b->eval_stash + 2 * cp, b->eval_stash + 3 * cp, c->stream), "bn_finalize");
-            b->eval_valid = true;
-        }
-    }
-    c->pack_all();
+    c->prepare_inference_weights();
     for (int i = 0; i < 3; i++) {
         LstmL& L = c->lstm[i];
         T4 ih = L.ih, ic = L.ic; ih.sn = 0; ic.sn = 0; ih.N = 1; ic.N = 1;
@@ -1099,6 +1144,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { set_error("buffers must be 256-byte (workspace) / 16-byte (params, grads) aligned"); return nullptr; }
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
+    if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
         else if (!strcmp(e, "fwd")) { c->prec_bwd = PREC_FP32; c->vgg_precision_bwd = PREC_FP32; }
@@ -1155,6 +1201,7 @@ int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
     return vgg_load(c, vgg_flat);
 }
 int caddy_set_perceptual_prefetch(caddy_ctx* c, int on) { c->perc_prefetch = on != 0; return 0; }
+int caddy_set_rollout_fold(caddy_ctx* c, int on) { c->use_fold = on != 0; c->drop_graph(); c->packed_fold = false; return 0; }
 int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
 int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }

@@ -42,6 +42,7 @@ struct Arena {
     bool overflow() const { return off > top; }
 };
 
+struct BNL;
 struct ConvL {
     PackDesc pd{};
     float* wp = nullptr; float* dwp = nullptr;
@@ -54,6 +55,9 @@ struct ConvL {
     // split 16-bit operand forms for conv_hx.hip (3x3 layers with >= 32 channels on both sides): forward weights as f16 hi|lo, dgrad weights
     // (flipped / transposed) as bf16 hi|lo; re-split once per optimiser step by pack_all()
     void* wq = nullptr; void* wqd[CONV_MAX_SRC] = {nullptr, nullptr, nullptr};
+    // roll-out: the eval-mode BatchNorm that follows this conv (with nothing but an average pool in between) is folded into the packed forward
+    // weights (PackDesc.oscale) and into fold_bias = bias * scale + shift by pack_all(true)
+    struct BNL* fold_bn = nullptr; float* fold_bias = nullptr;
 };
 struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
              float* eval_stash = nullptr; bool eval_valid = false; };   // eval mode: (mean, invstd, scale, shift) from the running statistics, computed once per start_inference / eval forward
@@ -123,6 +127,10 @@ struct caddy_ctx {
     bool graph_valid = false, graph_failed = false, graph_failed_soft = false, use_graph = true;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     void drop_graph();
+    // BatchNorm folding for the roll-out (weights are constant between start_inference calls): `fold` switches encode / dynamics / render to the
+    // folded graph (conv' + LeakyReLU / residual epilogues, no BatchNorm launches), `packed_fold` says which form the packed weights hold
+    bool use_fold = true, fold = false, packed_fold = false, rollout = false;
+    void prepare_inference_weights();
     bool have_forward = false;
     bool seeds_only = false;         // caddy_debug_set_seeds_only: caddy_loss_backward stops after the loss kernels (tests of the loss gradient seeds)
     bool poison_nz = false;          // caddy_debug_set_poison: NaN-fill the first-touch gradient region before every backward (tests)
@@ -155,8 +163,8 @@ struct caddy_ctx {
     T4 alloc_nz(int N, int H, int W, int C);      // gradient not zero-filled: only for tensors with a single, assigning backward writer
     float* falloc(size_t n);
     double* dalloc(size_t n);
-    T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false);
-    T4 pool2(const T4& x);
+    T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false, const T4* res = nullptr);
+    T4 pool2(const T4& x, bool act = false);
     T4 up2(const T4& x);
     T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false);   // nz_out: the output feeds exactly one conv
     T4 resblock(ResL& R, const T4& x, const T4* into);
@@ -168,7 +176,7 @@ struct caddy_ctx {
                     const float* samples_in, const float* variations_in);
     void copy_op(const T4& src, const T4& dst);
     void alloc_gt_images(T4* gi, int Trec);
-    void pack_all();
+    void pack_all(bool fold = false);
     void unpack_all();
     void ck(int rc, const char* what);
 };

@@ -10,6 +10,7 @@ struct PackDesc {
     int KS;
     int nseg, seg_off[CONV_MAX_SRC], seg_C[CONV_MAX_SRC], seg_Cpad[CONV_MAX_SRC];
     int Cout, Cout_pad, Ktot;
+    const float* oscale;  // optional per-output-channel factor applied while packing the FORWARD forms (eval-mode BatchNorm folded into the conv for roll-outs)
 };
 int pack_fwd(const PackDesc& d, float* wp, hipStream_t st);
 int pack_dgrad(const PackDesc& d, int seg, float* wpd, int Cd_pad, int Kd, hipStream_t st);

@@ -18,7 +18,7 @@ __global__ void k_pack_fwd(PackDesc d, float* wp) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int k = (int)(i % d.Ktot); long r = i / d.Ktot; int o = (int)(r % d.Cout_pad); int tap = (int)(r / d.Cout_pad);
         float v = 0.f; int cin;
-        if (o < d.Cout && k_to_cin(d, k, &cin)) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * d.KS * d.KS + tap];
+        if (o < d.Cout && k_to_cin(d, k, &cin)) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * d.KS * d.KS + tap] * (d.oscale ? d.oscale[o] : 1.f);
         wp[i] = v;
     }
 }

@@ -4,7 +4,7 @@
 
 int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st);
 int pw_fill(const TV& d, float v, hipStream_t st);
-int pw_pool2(const TV& in, const TV& out, hipStream_t st);
+int pw_pool2(const TV& in, const TV& out, hipStream_t st, int act = 0);      // act: LeakyReLU(0.2) after pooling (BatchNorm-folded roll-out)
 int pw_pool2_bwd(const TV& dout, const TV& din, int assign, hipStream_t st);   // assign: din = ... (first and only writer) instead of din += ...
 int pw_up2(const TV& in, const TV& out, hipStream_t st);
 int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st);
@@ -25,7 +25,7 @@ int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* m
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
                     const TV& dx, float* dgamma, float* dbeta, int assign /* dx = ... instead of += : dx has no other writer */, hipStream_t st);
 int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st);
-int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st);
+int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st, const TV* hb = nullptr, const float* scale = nullptr, const float* shift = nullptr);
 int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st);
 int pw_tanh_bwd(const TV& dy, const TV& y, const TV& dz, hipStream_t st);
 int pw_attn_mul(const TV& x, const TV& out, const TV& att, hipStream_t st);
@@ -39,4 +39,5 @@ int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t s
 struct PackDesc;
 int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S /* N*Cout*9 scratch */, float* g, long g_sn,
                         float* dbias /* nullable: the conv's bias gradient falls out of the same sums */, hipStream_t st);
+int pw_fold_bias(const float* bias /* nullable */, const float* scale, const float* shift, float* out, int C, hipStream_t st);
 int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st);

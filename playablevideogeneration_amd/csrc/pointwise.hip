@@ -75,13 +75,15 @@ struct FFill {
     __device__ void operator()(long q, int c) const { st4(d.p + tv_off(d, HW, q) + c, c, d.C, make_float4(val, val, val, val)); }
 };
 struct FPool2 {  // q indexes OUTPUT pixels (F.avg_pool2d(x, 2): residual_block.py:56, same_block.py:40, representation_network.py:41)
-    TV in, out;
+    TV in, out; int act;      // act: LeakyReLU(0.2) on the pooled value (roll-out with the BatchNorm folded into the conv: conv' -> pool -> act)
     __device__ void operator()(long q, int c) const {
         int HWo = out.H * out.W;
         long n = q / HWo; int rem = (int)(q - n * HWo); int y = rem / out.W, x = rem - y * out.W;
         const float* b = in.p + n * in.sn + ((long)(2 * y) * in.W + 2 * x) * in.ld + c;
         float4 v = ld4(b, c, in.C) + ld4(b + in.ld, c, in.C) + ld4(b + (long)in.W * in.ld, c, in.C) + ld4(b + (long)(in.W + 1) * in.ld, c, in.C);
-        st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, 0.25f * v);
+        v = 0.25f * v;
+        if (act) v = lrelu4(v);
+        st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, v);
     }
 };
 struct FPool2Bwd {  // q indexes INPUT pixels; din (+)= dout/4; `assign`: first and only writer of din (no zero-fill, no read)
@@ -170,6 +172,7 @@ struct FActBwdAdd {  // dres += dout * lrelu'(out)
 };
 struct FLstmFwd {  // gates (pre-activation, channel order [i|f|o|g] x C) -> post-activation in place; c' = f*c + i*g; h' = o*tanh(c')
     TV gates, cprev, h, cn; int HW;   // convolutional_lstm_cell.py:92-101
+    TV hb; const float *scale, *shift;      // optional (roll-out): hb = h' * scale + shift, the eval-mode BatchNorm that follows the cell (conv_dynamics_network.py)
     __device__ void operator()(long q, int c) const {
         int C = h.C;
         float* gp = gates.p + tv_off(gates, HW, q) + c;
@@ -184,6 +187,7 @@ struct FLstmFwd {  // gates (pre-activation, channel order [i|f|o|g] x C) -> pos
         st4(gp, c, C, i4); st4(gp + C, c, C, f4); st4(gp + 2 * C, c, C, o4); st4(gp + 3 * C, c, C, g4);
         st4(cn.p + tv_off(cn, HW, q) + c, c, C, cc);
         st4(h.p + tv_off(h, HW, q) + c, c, C, hh);
+        if (scale) st4(hb.p + tv_off(hb, HW, q) + c, c, C, hh * ld4(scale + c, c, C) + ld4(shift + c, c, C));
     }
 };
 struct FLstmBwd {
@@ -609,7 +613,7 @@ int pw_copy(const TV& s, const TV& d, int acc, hipStream_t st) {
     return run_map((long)d.N * d.H * d.W, d.C, FCopy{s, d, d.H * d.W, acc}, st);
 }
 int pw_fill(const TV& d, float v, hipStream_t st) { return run_map((long)d.N * d.H * d.W, d.C, FFill{d, d.H * d.W, v}, st); }
-int pw_pool2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out}, st); }
+int pw_pool2(const TV& in, const TV& out, hipStream_t st, int act) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out, act}, st); }
 int pw_pool2_bwd(const TV& dout, const TV& din, int assign, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din, assign}, st); }
 int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
 int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
@@ -669,7 +673,9 @@ int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* me
     return 0;
 }
 int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st) { return run_map((long)dres.N * dres.H * dres.W, dres.C, FActBwdAdd{dout, outm, dres, dres.H * dres.W}, st); }
-int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st) { return run_map((long)h.N * h.H * h.W, h.C, FLstmFwd{gates, cprev, h, cn, h.H * h.W}, st); }
+int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st, const TV* hb, const float* scale, const float* shift) {
+    return run_map((long)h.N * h.H * h.W, h.C, FLstmFwd{gates, cprev, h, cn, h.H * h.W, hb ? *hb : TV{}, hb ? scale : nullptr, hb ? shift : nullptr}, st);
+}
 int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st) {
     return run_map((long)dh.N * dh.H * dh.W, dh.C, FLstmBwd{gates, cprev, cn, dh, dc, dgates, dcprev, dh.H * dh.W}, st);
 }
@@ -692,6 +698,15 @@ int pw_colsum(const TV& x, float* out, hipStream_t st) { RedArgs a{}; a.x = x; a
 int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st) { RedArgs a{}; a.x = x; a.outf = out; a.out_sn = out_sn; a.scale = 1.f; return run_reduce<2>(a, st); }
 int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st) { return run_map((long)d.N * d.H * d.W, 1, FNchwToNhwc{src, src_sn, d, d.H * d.W}, st); }
 int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st) { return run_map((long)s.N * s.H * s.W, 1, FNhwcToNchw{s, dst, dst_sn, s.H * s.W, acc}, st); }
+// bias of a conv with the following eval-mode BatchNorm folded in: out[o] = bias[o] * scale[o] + shift[o]
+__global__ void k_fold_bias(const float* bias, const float* scale, const float* shift, float* out, int C) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < C) out[o] = (bias ? bias[o] * scale[o] : 0.f) + shift[o];
+}
+int pw_fold_bias(const float* bias, const float* scale, const float* shift, float* out, int C, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold_bias, dim3(cdiv(C, 256)), dim3(256), 0, st, bias, scale, shift, out, C);
+    return 0;
+}
 int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_batch_sum, dim3(cdiv(n_el, 256)), dim3(256), 0, st, src, sn, n_el, N, dst);
     return 0;

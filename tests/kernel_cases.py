@@ -59,7 +59,8 @@ def make_pack(ws, segs, KS, lib):
     return d
 
 
-def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True, wgrad_precision=0, wgrad_tol=None):
+def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True, wgrad_precision=0, wgrad_tol=None,
+              res=False, oscale=False):
     """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd."""
     g = torch.Generator().manual_seed(seed)
     Cin = sum(c for c, _ in segs)
@@ -73,8 +74,16 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     ws_r = [w.clone().requires_grad_(True) for w in ws]
     full = torch.cat([x[:, :, None, None].expand(-1, -1, H, W) if bc else x for x, (c, bc) in zip(xs_r, segs)], dim=1)
     y_ref = F.conv2d(full, torch.cat(ws_r, 0), b, padding=KS // 2)
+    osc = (torch.rand(Cout, generator=g) + 0.5) if oscale else None       # PackDesc.oscale: per-output-channel factor folded into the packed weights
+    if oscale:
+        y_ref = (y_ref - (b[None, :, None, None] if bias else 0)) * osc[None, :, None, None] + (b[None, :, None, None] if bias else 0)
+    r_in = torch.randn(N, Cout, H, W, generator=g) if res else None        # ConvArgs.res: residual input added before the activation
+    if res:
+        y_ref = y_ref + r_in
     if act == 1:
         y_ref = torch.tanh(y_ref)
+    elif act == 3:
+        y_ref = F.leaky_relu(y_ref, 0.2)
     dy = torch.randn(y_ref.shape, generator=g)
     # device buffers
     st = stream(dev)
@@ -88,6 +97,8 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         d.w[i], d.gw[i] = ws_d[i].data_ptr(), gws_d[i].data_ptr()
     taps = KS * KS
     wp = torch.full((taps * d.Cout_pad * d.Ktot,), 3.0, device=dev)
+    osc_d = osc.to(dev) if oscale else None
+    d.oscale = osc_d.data_ptr() if oscale else None
     assert lib.caddy_k_pack_fwd(C.byref(d), P(wp), st) == 0
     a = ConvArgs()
     bufs = []
@@ -112,6 +123,9 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     out_ld = round_up(Cout, 4) + 4
     out = torch.full((N, H, W, out_ld), 9.0, device=dev)
     a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0
+    if res:
+        r_d = nhwc(r_in, ld=round_up(Cout, 4) + 8, dev=dev)
+        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), H * W * r_d.shape[3], r_d.shape[3]
     assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
     sync(dev)
     y = to_nchw(out, Cout)
@@ -473,7 +487,7 @@ PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
 
 
 def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
-                 split=False, seed=0, tol=None, big=-1):
+                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False):
     """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
     dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
     Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
@@ -497,6 +511,9 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     if dgrad_seg is None:
         rows_pad = round_up(Cout, lib.caddy_k_hx_pick_bn(Cout))
         wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), -1, rows_pad, planes), dtype=torch.uint8, device=dev)
+        osc = (torch.rand(Cout, generator=g) + 0.5) if oscale else None
+        osc_d = osc.to(dev) if oscale else None
+        d.oscale = osc_d.data_ptr() if oscale else None
         assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, -1, precision, st) == 0
         for i, ((c, bc), x) in enumerate(zip(segs, xs)):
             if bc:
@@ -507,7 +524,7 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
                 a.src[i] = ConvSrc(bb.data_ptr(), H * W * bb.shape[3], bb.shape[3], c, round_up(c, CONV_BK), 0)
             keep.append(bb)
         a.nsrc, out_c = len(segs), Cout
-        ref = F.conv2d(full, w.double(), b.double() if bias else None, padding=1)
+        ref = F.conv2d(full, (w * osc[:, None, None, None]).double() if oscale else w.double(), b.double() if bias else None, padding=1)
     else:
         c_s = segs[dgrad_seg][0]
         rows_pad = round_up(c_s, lib.caddy_k_hx_pick_bn(c_s))
@@ -526,10 +543,17 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     a.wq, a.precision = wq.data_ptr(), precision
     b_d = b.to(dev) if bias else None
     a.bias, a.act = (b_d.data_ptr() if bias else None), act
+    if res:
+        r_in = torch.randn(N, out_c, H, W, generator=g)
+        r_d = nhwc(r_in, ld=round_up(out_c, 4) + 8, dev=dev)
+        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), H * W * r_d.shape[3], r_d.shape[3]
+        ref = ref + r_in.double()
     if act == 1:
         ref = torch.tanh(ref)
     elif act == 2:
         ref = torch.relu(ref)
+    elif act == 3:
+        ref = F.leaky_relu(ref, 0.2)
     out_ld = round_up(out_c, 4) + 4
     init = torch.randn(N, H, W, out_ld, generator=g)
     out = init.clone().to(dev)

@@ -379,12 +379,15 @@ def pretraining_case(lib, dev, name="pre_main_s4", fwd_tol=2e-4):
     assert rel_h <= max(5 * rel_o, 3e-2), ("relative L2 gradient error vs fp64", rel_h, rel_o)
 
 
-def rollout_case(name, lib, dev, tol=2e-4):
+def rollout_case(name, lib, dev, tol=2e-4, fold=True):
+    """start_inference + generate_next vs the reference golden frames.  fold: eval-mode BatchNorms folded into the convolutions (the default
+    roll-out graph) or launched separately."""
     c, z = H.load_case(name)
     d, P, obs = H.inputs_of(c)
     cc = dict(c, B=1, T=2)
     eng = make_engine(cc, lib, dev)
     eng.load_state_dict(P)
+    eng.set_rollout_fold(fold)
     o = obs[0, 0]
     eng.start_inference()
     for i in range(c["steps"]):

@@ -108,6 +108,18 @@ def test_conv_hx_dgrad_mask_seed_epilogue_small():
     K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(160, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True)
 
 
+def test_folded_inference_epilogues_small():
+    """roll-out epilogues (eval-mode BatchNorm folded into the conv): PackDesc.oscale in both pack kernels, ConvArgs.res + LeakyReLU(0.2) (act 3) in
+    k_conv_fwd, its split-K reduce, k_conv_narrow and k_conv_hx (direct + slab split-K)"""
+    lib = load_emu()
+    K.conv_case(lib, "cpu", N=1, H=9, W=12, segs=[(48, 0)], Cout=65, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)       # generic, under-filled -> slabs + reduce
+    K.conv_case(lib, "cpu", N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)     # k_conv_narrow
+    K.conv_case(lib, "cpu", N=2, H=24, W=24, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False)                      # 1x1 down-sample conv, folded, no activation
+    K.conv_case(lib, "cpu", N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3, bias=True, oscale=True, check_bwd=False)                       # stacked-frame stem (thin-in kernel) keeps bias + scale
+    K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True, act=3, res=True, oscale=True)
+    K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(96, False)], Cout=64, bias=True, act=3, res=True, oscale=True, split=True)
+
+
 def test_wgrad_hx_split_bf16_small():
     """k_wgrad_hx on the simulator (ds_read_b64_tr_b16 transposing fragment reads): ragged tiles, three segments incl. a broadcast vector,
     output-channel tail; the forward / dgrad of the same case run on the exact kernels"""

@@ -109,6 +109,17 @@ def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)
 
 
+def test_folded_inference_epilogues(lib):
+    """roll-out epilogues (eval-mode BatchNorm folded into the conv): PackDesc.oscale, ConvArgs.res + LeakyReLU(0.2) at the batch-1 Tennis shapes"""
+    K.conv_case(lib, "cuda", N=1, H=32, W=32, segs=[(64, 0)], Cout=65, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)        # E's last block: generic kernel, slabs + reduce
+    K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=16, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)     # k_conv_narrow
+    K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False)                      # 1x1 down-sample
+    K.conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(12, 0)], Cout=16, KS=3, bias=True, oscale=True, check_bwd=False)                      # stacked-frame stem
+    K.hx_conv_case(lib, "cuda", N=1, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=3, res=True, oscale=True, split=True)         # D residual block, slab split-K
+    K.hx_conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(64, False)], Cout=32, bias=True, act=3, oscale=True)                               # D last UpBlock
+    K.hx_conv_case(lib, "cuda", N=1, H=16, W=16, segs=[(256, False), (12, True)], Cout=128, bias=True, act=3, oscale=True, split=True)       # R's middle block
+
+
 @pytest.mark.parametrize("kw", [
     dict(N=8, H=32, W=32, segs=[(64, False), (9, True), (128, False)], Cout=512, dgrad_seg=2, accumulate=True),    # dgrad to h_prev (+=), atomics split-K
     dict(N=8, H=32, W=32, segs=[(64, False), (9, True), (128, False)], Cout=512, dgrad_seg=0),

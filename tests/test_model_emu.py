@@ -31,6 +31,10 @@ def test_rollout_main_s4():
     M.rollout_case("rollout_main_s4", load_emu(), "cpu")
 
 
+def test_rollout_unfolded():
+    M.rollout_case("rollout_reduced_s1", load_emu(), "cpu", fold=False)                       # separate BatchNorm launches (the default graph folds them)
+
+
 def test_pretraining_main_s4():
     M.pretraining_case(load_emu(), "cpu")
 
