@@ -30,7 +30,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 MFMA16_DENSE_PEAK_TFLOPS = 2500.0 # same guide: bf16 / f16 dense MFMA (v_mfma_f32_32x32x16_{f16,bf16})
 SPLIT_PRODUCTS = 3                # conv_hx: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the 16-bit pipe -> 3 MFMA FLOPs per algorithmic FLOP
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "profiles/r02_pmc_traffic.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh)
+PMC_FILE = "profiles/r02_pmc_traffic_{workload}.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh <workload>)
 HX_FAMILIES = ("k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx")
 VGG_CONVS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2), (256, 256, 2), (256, 512, 3),
              (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]      # (Cin, Cout, number of 2x2 max-pools before): conv1_1 .. conv5_1
@@ -232,11 +232,12 @@ def run(a, dev, lib=None, backend="nccl"):
         peak = MFMA16_DENSE_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MATRIX_PEAK_TFLOPS
         traffic, traffic_src = None, None                    # HBM bytes per launch: only from a PMC file of THIS round; never a stale number
         try:
-            with open(os.path.join(ROOT, PMC_FILE)) as f:
+            pmc_file = PMC_FILE.format(workload=a.workload)
+            with open(os.path.join(ROOT, pmc_file)) as f:
                 pm = json.load(f)
             if pm.get("workload") == a.workload and pm.get("perceptual") == bool(perc):
                 traffic = pm["kernels"].get(name, {}).get("hbm_bytes_per_launch")
-                traffic_src = PMC_FILE
+                traffic_src = pmc_file
         except (OSError, ValueError):
             pass
         achieved = fl / ms / 1e9
