@@ -230,7 +230,7 @@ def run(a, dev, lib=None, backend="nccl"):
         tot_ms = sum(v[2] for v in fam.values())
         split = name in HX_FAMILIES                          # the dominant family runs split operands on the 16-bit matrix pipe
         peak = MFMA16_DENSE_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MATRIX_PEAK_TFLOPS
-        traffic, traffic_src = None, None                    # HBM bytes per launch: only from a PMC file of THIS round; never a stale number
+        traffic, traffic_src, step_pmc = None, None, None    # HBM bytes per launch: only from a PMC file of THIS round; never a stale number
         try:
             pmc_file = PMC_FILE.format(workload=a.workload)
             with open(os.path.join(ROOT, pmc_file)) as f:
@@ -238,6 +238,7 @@ def run(a, dev, lib=None, backend="nccl"):
             if pm.get("workload") == a.workload and pm.get("perceptual") == bool(perc):
                 traffic = pm["kernels"].get(name, {}).get("hbm_bytes_per_launch")
                 traffic_src = pmc_file
+                step_pmc = pm.get("total_hbm_bytes_per_step")
         except (OSError, ValueError):
             pass
         achieved = fl / ms / 1e9
@@ -268,6 +269,9 @@ def run(a, dev, lib=None, backend="nccl"):
                 roof["vgg19_algorithmic"] = {"gbytes": vby / 1e9, "tflop": vfl / 1e12}
                 step_bytes += vby; step_flops += vfl
             roof["step_hbm_roofline_frac"] = step_bytes / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            if step_pmc:      # rocprofv3 PMC passes of this round (all kernels of one step, FETCH_SIZE doubled + WRITE_SIZE) over THIS run's step time
+                roof["step_hbm_measured"] = {"gbytes_per_step": step_pmc / 1e9, "gb_per_s": step_pmc / 1e9 / (ms_step * 1e-3),
+                                             "frac_of_hbm_peak": step_pmc / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9), "source": traffic_src}
             roof["step_algorithmic_tflops"] = step_flops / (ms_step * 1e-3) / 1e12
             roof["step_frac_of_split_mfma_peak"] = step_flops / (ms_step * 1e-3) / (MFMA16_DENSE_PEAK_TFLOPS / SPLIT_PRODUCTS * 1e12)
     if world > 1:

@@ -8,6 +8,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o run -- python bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout > gpurun_out/pmc_$c.log 2>&1
 done
-python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/run_results.db gpurun_out/pmc_WRITE_SIZE/run_results.db $WL 1 > gpurun_out/pmc_traffic_$WL.json
+python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/run_results.db gpurun_out/pmc_WRITE_SIZE/run_results.db $WL 1 2 > gpurun_out/pmc_traffic_$WL.json
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 head -c 400 gpurun_out/pmc_traffic_$WL.json

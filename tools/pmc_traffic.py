@@ -1,5 +1,5 @@
 """HBM traffic per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only):
-    python tools/pmc_traffic.py <fetch.db> <write.db> [workload perceptual(0|1)] > profiles/<round>_pmc_traffic.json
+    python tools/pmc_traffic.py <fetch.db> <write.db> [workload perceptual(0|1) steps] > profiles/<round>_pmc_traffic_<workload>.json
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md: on gfx950 the
 counter expression tallies 128-byte read requests of wide coalesced streams at 64 bytes; WRITE_SIZE used as reported)."""
 import collections
@@ -45,4 +45,7 @@ for k in sorted(fetch):
     n, f = fetch[k]
     w = write.get(k, [n, 0.0])[1]
     out["kernels"][k] = {"launches": n, "fetch_kb_per_launch": f / n, "write_kb_per_launch": w / n, "hbm_bytes_per_launch": (2 * f + w) * 1024 / n}
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2      # training steps inside the profiled command (gpu_pmc.sh: 1 warm-up + 1 timed)
+out["steps_profiled"] = steps
+out["total_hbm_bytes_per_step"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out["kernels"].values()) / steps
 print(json.dumps(out, indent=1))
