@@ -5,7 +5,8 @@
     collate             dataset/batching.py:97-112         (stack of per-observation channel-concatenated frame stacks)
     normalisation       dataset/transforms.py:90-107       (ToTensor + Normalize(0.5, 0.5): uint8 [0, 255] -> fp32 [-1, 1])
 
-Only the tensor contract is mirrored; decoding PNG folders / pickles (dataset/video.py) stays with the caller.  `Batch.to_tuple()` moves
+The tensor contract lives here; the reader of the reference's on-disk format (PNG folders + pickles, dataset/video.py) and the sample
+grid over videos is `playablevideogeneration_amd.video_dataset`.  `Batch.to_tuple()` moves
 the tensors to the current HIP device like the reference moves them to CUDA (batching.py:67-87).
 """
 from typing import List, Sequence, Tuple

@@ -1,0 +1,121 @@
+"""Input-pipeline mirror: `playablevideogeneration_amd.video_dataset` reads the reference's on-disk video format and
+produces the same BatchElements as the reference's `dataset.video_dataset.VideoDataset` (compared directly when /root/reference is present)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from playablevideogeneration_amd import batching as BT
+from playablevideogeneration_amd import video_dataset as VD
+from playablevideogeneration_amd.evaluation_dataset_builder import EvaluationVideo
+
+REF = os.environ.get("CADDY_REFERENCE", "/root/reference")
+H, W = 20, 24
+
+
+def _write_dataset(root, seed=0):
+    rng = np.random.RandomState(seed)
+    lens = [7, 9, 5, 6]
+    frames = []
+    for vi, n in enumerate(lens):
+        fr = rng.randint(0, 256, size=(n, H, W, 3)).astype(np.uint8)
+        rewards = [None] * n if vi == 2 else [float(rng.randint(0, 3)) for _ in range(n)]      # an all-None annotation takes the default
+        EvaluationVideo(fr, [int(rng.randint(0, 4)) for _ in range(n)], rewards, [{"i": i} for i in range(n)], [bool(i == n - 1) for i in range(n)]).save(
+            os.path.join(root, f"{vi:05d}"))
+        frames.append(fr)
+    return lens, frames
+
+
+def _config(root, crop=None, size=(W, H)):
+    return {"data": {"crop": crop, "data_root": root, "dataset_style": "flat", "dataset_splits": [0.5, 0.25, 0.25]},
+            "model": {"representation_network": {"target_input_size": list(size)}},
+            "training": {"batching": {"observations_count": 3, "observation_stacking": 2, "skip_frames": 1, "batch_size": 2}},
+            "evaluation": {"batching": {"observations_count": 4, "observation_stacking": 2, "skip_frames": 0, "batch_size": 2}}}
+
+
+def test_sample_grid_and_contents(tmp_path):
+    root = str(tmp_path / "ds")
+    os.makedirs(root)
+    lens, frames = _write_dataset(root)
+    cfg = _config(root)
+    ds = VD.VideoDataset(root, cfg["training"]["batching"], VD.final_transform(cfg))
+    block = 3 + 2 * 1
+    assert len(ds) == sum(n - block + 1 for n in lens)
+    idx = 0
+    for vi, n in enumerate(lens):
+        for first in range(n - block + 1):
+            assert ds.locate(idx) == (vi, first)
+            el = ds[idx]
+            assert el.observations_count == 3 and el.observations_stacking == 2 and el.initial_frame_index == first
+            for i in range(3):
+                cur = first + 2 * i
+                prev = max(cur - 2, first % 2)
+                for got, fi in zip(el.observations[i], (cur, prev)):
+                    exp = (torch.from_numpy(frames[vi][fi]).permute(2, 0, 1).float() / 255 - 0.5) / 0.5
+                    assert got.shape == (3, H, W) and torch.equal(got, exp)
+            idx += 1
+    el = ds[len(ds) - 1]
+    assert all(r == 0.0 for r in ds.all_videos[2].rewards)                      # None annotations -> defaults
+    with pytest.raises(Exception):
+        ds[len(ds)]
+    batch = BT.single_batch_elements_collate_fn([ds[0], ds[1]])
+    obs, actions, rewards, dones = batch.to_tuple(cuda=False)
+    assert obs.shape == (2, 3, 6, H, W) and actions.shape == (2, 3) and batch.size == 3
+    assert torch.equal(obs[1, 2, :3], ds[1].observations[2][0]) and torch.equal(obs[1, 2, 3:], ds[1].observations[2][1])
+    ds.set_observations_count(2)                                                # the trainer changes the sequence length during training
+    assert len(ds) == sum(n - 3 + 1 for n in lens) and ds[0].observations_count == 2
+
+
+def test_crop_resize_transform_and_splits(tmp_path):
+    from PIL import Image
+    root = str(tmp_path / "ds")
+    os.makedirs(root)
+    lens, frames = _write_dataset(root, seed=3)
+    crop, size = [2, 1, 22, 19], (10, 9)
+    cfg = _config(root, crop, size)
+    tf = VD.final_transform(cfg)
+    img = Image.fromarray(frames[1][4])
+    exp = np.asarray(img.crop(crop).resize(size, Image.BILINEAR), dtype=np.float32).transpose(2, 0, 1) / 255.0
+    got = tf(img)
+    assert got.shape == (3, 9, 10) and np.allclose(got.numpy(), (exp - 0.5) / 0.5, atol=1e-6)
+    sp = VD.generate_splits(cfg)
+    assert sp["train"][2] == ["00000", "00001"] and sp["validation"][2] == ["00002"] and sp["test"][2] == ["00003"]
+    dss = VD.build_datasets(cfg)
+    assert len(dss["train"].all_videos) == 2 and len(dss["validation"].all_videos) == 1 and dss["validation"].observations_count == 4
+    cfg2 = dict(cfg, data=dict(cfg["data"], dataset_style="splitted"))
+    assert VD.generate_splits(cfg2)["validation"][0] == os.path.join(root, "val")
+    with pytest.raises(Exception):
+        VD.generate_splits(dict(cfg, data=dict(cfg["data"], dataset_style="other")))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+def test_against_the_reference_dataset_classes(tmp_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ref_harness
+    ref_harness.install()
+    from dataset.video_dataset import VideoDataset as RefDataset
+    from dataset.dataset_splitter import DatasetSplitter
+    from dataset.batching import single_batch_elements_collate_fn as ref_collate
+    root = str(tmp_path / "ds")
+    os.makedirs(root)
+    _write_dataset(root, seed=5)
+    cfg = _config(root, [1, 2, 21, 18], (12, 10))
+    tf = VD.final_transform(cfg)
+    for key in ("training", "evaluation"):
+        bc = cfg[key]["batching"]
+        mine, ref = VD.VideoDataset(root, bc, tf), RefDataset(root, bc, tf)
+        assert len(mine) == len(ref)
+        for i in range(len(ref)):
+            a, b = mine[i], ref[i]
+            assert a.actions == b.actions and a.rewards == b.rewards and a.dones == b.dones and a.initial_frame_index == b.initial_frame_index
+            for sa, sb in zip(a.observations, b.observations):
+                for fa, fb in zip(sa, sb):
+                    assert torch.equal(fa, fb)
+        ba, bb = BT.single_batch_elements_collate_fn([mine[0], mine[2]]), ref_collate([ref[0], ref[2]])
+        for x, y in zip(ba.to_tuple(cuda=False), bb.to_tuple(cuda=False)):
+            assert torch.equal(x, y)
+    rs = DatasetSplitter.generate_splits(cfg)
+    ms = VD.generate_splits(cfg)
+    assert {k: (v[0], v[2]) for k, v in rs.items()} == {k: (v[0], v[2]) for k, v in ms.items()}
