@@ -17,7 +17,7 @@ def build_emu(force=False):
     if not force and not B._stale(EMU_LIB, deps):
         return EMU_LIB
     cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi", "-Wno-unused-value", "-x", "c++",
+    flags = ["-O3", "-march=native", "-fno-math-errno", "-std=c++17", "-fPIC", "-Wno-psabi", "-Wno-unused-value", "-x", "c++",
              "-I", EMU_DIR, "-I", B.HERE, "-I", os.path.join(B.ROOT, "include")]
     objs = B._compile_objects([cxx] + flags, os.path.dirname(EMU_LIB), srcs, headers)
     subprocess.check_call([cxx, "-shared", "-fPIC", "-o", EMU_LIB] + objs + ["-lpthread"])

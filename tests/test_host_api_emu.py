@@ -201,6 +201,13 @@ def headless_evaluator_case(make_model, dev):
     assert abs(log["val/action_directions_kl_loss"] - O.kl_gaussian_loss(ref[10]).item()) < 1e-3 * max(1.0, abs(O.kl_gaussian_loss(ref[10]).item()))
     mi = O.mutual_information_loss(torch.softmax(ref[6], -1), torch.softmax(ref[15], -1))[0].item()
     assert abs(log["val/action_mutual_information_loss"] - mi) < 1e-4
+    # frame-quality numbers of the paper's protocol on the same roll-out (metrics.py: mse.py:13-24, psnr.py:11-31 on [0, 1] frames)
+    from playablevideogeneration_amd import metrics as MT
+    torch.manual_seed(9)
+    q = MT.rollout_quality(m, (obs, acts, None, None), ground_truth_observations_init=1)
+    a, b = (obs[:, 1:, :3] + 1) / 2, (ref[0] + 1) / 2
+    assert abs(q["mse"] - ((a - b) ** 2).mean(dim=[2, 3, 4]).mean().item()) < 1e-4 and len(q["psnr_per_position"]) == 3
+    assert abs(q["psnr"] - (-10 * torch.log10(((a - b) ** 2).mean(dim=[2, 3, 4]) + 1e-8)).mean().item()) < 5e-2
     # Hungarian accuracy: best one-to-one relabelling of the model's actions
     pred, gt = ref[5].reshape(-1), acts[:, :-1].reshape(-1)
     import itertools

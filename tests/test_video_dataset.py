@@ -119,3 +119,18 @@ def test_against_the_reference_dataset_classes(tmp_path):
     rs = DatasetSplitter.generate_splits(cfg)
     ms = VD.generate_splits(cfg)
     assert {k: (v[0], v[2]) for k, v in rs.items()} == {k: (v[0], v[2]) for k, v in ms.items()}
+
+
+def test_mse_psnr_metrics():
+    from playablevideogeneration_amd import metrics as MT
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(2, 3, 3, 8, 9, generator=g), torch.rand(2, 3, 3, 8, 9, generator=g)
+    m = MT.mse(a, b)
+    assert m.shape == (2, 3) and torch.allclose(m[1, 2], ((a[1, 2] - b[1, 2]) ** 2).mean())
+    p = MT.psnr(a * 255, b * 255, 255.0)
+    assert torch.allclose(p, -10 * torch.log10(m + 1e-8), atol=1e-4)
+    assert abs(MT.psnr(a, a)[0, 0].item() - 80.0) < 1e-3                         # the stabilising constant caps identical frames at 80 dB
+    if os.path.isdir(REF):
+        sys.path.insert(0, REF)
+        from evaluation.metrics.psnr import PSNR
+        assert torch.allclose(PSNR()(a, b), MT.psnr(a, b), atol=1e-6)
