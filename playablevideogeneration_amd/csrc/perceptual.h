@@ -6,7 +6,7 @@
 #define VGG_NCONV 13      // conv1_1 .. conv5_1: what model/layers/vgg.py:25-34 evaluates of torchvision's vgg19().features
 
 struct VggLayer { PackDesc pd; float* wp; float* wpd; float* bias; int kd, cd_pad;
-                  void* wq[2]; void* wqd[2]; };      // split 16-bit forms (conv_hx.hip): [0] two planes (3 products), [1] one plane; forward f16, dgrad bf16
+                  void* wq[3]; void* wqd[2]; };      // split 16-bit forms (conv_hx.hip): [0] two planes (3 products), [1] one plane; forward f16, dgrad bf16; wq[2]: forward as split bf16
 struct VggState { bool enabled = false, loaded = false; VggLayer conv[VGG_NCONV]; };
 struct VggLevels { double numel[3][5]; };      // elements of the level-l feature map at resolution r (N * C * H * W)
 

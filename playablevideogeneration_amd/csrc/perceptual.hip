@@ -176,6 +176,7 @@ void vgg_build(caddy_ctx* c) {
             L.wq[pl] = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2 - pl));
             L.wqd[pl] = VGG[i].cin >= 32 ? c->persist.alloc(hx_weight_bytes(d, 0, round_up(VGG[i].cin, hx_pick_bn(VGG[i].cin)), 2 - pl)) : nullptr;
         }
+        L.wq[2] = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2));
     }
 }
 
@@ -195,6 +196,7 @@ int vgg_load(caddy_ctx* c, const float* flat) {
             RUN_CK(c, pack_hx(L.pd, L.wq[pl], round_up(L.pd.Cout, hx_pick_bn(L.pd.Cout)), -1, pl == 0 ? PREC_F16X3 : PREC_F16X1, c->stream));
             if (L.wqd[pl]) RUN_CK(c, pack_hx(L.pd, L.wqd[pl], round_up(VGG[i].cin, hx_pick_bn(VGG[i].cin)), 0, pl == 0 ? PREC_BF16X3 : PREC_BF16X1, c->stream));
         }
+        RUN_CK(c, pack_hx(L.pd, L.wq[2], round_up(L.pd.Cout, hx_pick_bn(L.pd.Cout)), -1, PREC_BF16X3, c->stream));
         if (!dry) hipLaunchKernelGGL(k_copy_f, dim3(1), dim3(256), 0, c->stream, flat + off + nw, L.bias, (long)VGG[i].cout);
         L.pd.w[0] = nullptr;      // the caller's buffer is not referenced after this call
         off += nw + round_up(VGG[i].cout, 4);
@@ -231,8 +233,8 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
         a.src[0] = ConvSrc{x.d, x.sn, x.ld, x.C, round_up(x.C, CONV_BK), 0};
         a.nsrc = 1; a.N = x.N; a.H = x.H; a.W = x.W; a.KS = 3; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
         a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld;
-        a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : PREC_F16X3);
-        if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : 0];
+        a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : (c->vgg_precision == PREC_BF16X3 ? PREC_BF16X3 : PREC_F16X3));
+        if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : (a.precision == PREC_BF16X3 ? 2 : 0)];
         if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
         B.a[i] = out; x = out;
     }

@@ -10,7 +10,7 @@ from tests import model_cases as M  # noqa: E402
 
 lib = _lib.load()
 for name in ("perc_main_s1",):
-    for label, prec in (("exact fp32", (0, 0)), ("split f16 / split bf16", (16, 17)), ("f16 x1 fwd / split bf16 dgrad", (18, 17)), ("f16 x1 / bf16 x1", (18, 19))):
+    for label, prec in (("exact fp32", (0, 0)), ("split f16 / split bf16", (16, 17)), ("split bf16 fwd / split bf16 dgrad", (17, 17)), ("f16 x1 fwd / split bf16 dgrad", (18, 17)), ("f16 x1 / bf16 x1", (18, 19))):
         try:
             eng, info = M.perceptual_case(name, lib, "cuda", prep=lambda e: e.set_vgg_precision(*prec))
             print(f"{name:22s} {label:32s} PASS  per-image median {['%.1e' % v for v in info['per_image_median']]} worst {['%.1e' % v for v in info['per_image_worst']]} "
