@@ -73,6 +73,7 @@ struct ConvArgs {
     const float* res;
     long res_sn;
     int res_ld;
+    int xcd_map;            // set by the launcher (conv_hx): workgroup -> (tile, channel block) order that keeps a pixel tile's channel blocks on one XCD
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and

@@ -71,11 +71,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int tile = blockIdx.x;
+    // workgroup -> (pixel tile, output-channel block).  Workgroups go to the 8 XCDs round-robin in launch order (x fastest); with several
+    // output-channel blocks (a.xcd_map) the ones of a pixel tile are put on the SAME XCD in consecutive slots, so that the tile's halo images are
+    // fetched into that XCD's L2 once instead of once per channel block
+    int tile = blockIdx.x, nblk = blockIdx.y;
+    if (a.xcd_map && gridDim.y > 1) {
+        const int nby = gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int grp = lin / (8 * nby), r = lin - grp * (8 * nby);
+        const int m = (int)gridDim.x - grp * 8 < 8 ? (int)gridDim.x - grp * 8 : 8;      // tiles in this group (the last one may be short)
+        tile = grp * 8 + r % m; nblk = r / m;
+    }
     const int n = tile / (tiles_x * tiles_y);
     tile -= n * tiles_x * tiles_y;
     const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nblk * BN;
     const int nchunks = a.Kq / KC;
 
     // ---- A staging roles: float4 column q of halo pixels (tid >> 3) + 32 i ----
@@ -559,6 +568,8 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
             }
         }
     }
+    static const int env_xcd = getenv("CADDY_HX_XCD") ? atoi(getenv("CADDY_HX_XCD")) : 1;      // A/B aid
+    a.xcd_map = env_xcd;
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
     // launches of at most one workgroup per CU (batch-1 roll-out, R's side branches): every workgroup is a serial chain of (tap, chunk) steps whose
     // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame

@@ -104,6 +104,8 @@ def test_adam(lib):
     dict(N=8, H=32, W=32, segs=[(64, False)], Cout=64),                                                # E / A on one time step: 8x16 x 64-channel tiles
     dict(N=8, H=64, W=64, segs=[(32, False)], Cout=32, bias=True),                                     # 8x16 x 32-channel tiles
     dict(N=8, H=32, W=32, segs=[(64, False)], Cout=65),
+    dict(N=16, H=256, W=256, segs=[(64, False)], Cout=64, bias=True, act=2),                             # VGG19 conv1_2
+    dict(N=8, H=250, W=256, segs=[(64, False)], Cout=32, bias=True),                                    # D's last UpBlock: 32 channels, ragged rows
 ])
 def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)
