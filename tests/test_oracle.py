@@ -180,3 +180,20 @@ def test_oracle_bitwise_vs_imported_reference():
     torch.manual_seed(3)
     oout = orc.forward_full(obs, 2, tau=0.6)
     _cmp(oout, list(rout), 0.0, "bitwise")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree only exists in the build container")
+def test_reference_motion_weighted_losses_cannot_run():
+    """Why `use_motion_weights` raises in the trainer mirror instead of being implemented: the reference's own weighted paths are dead code.
+    The mask calculator works (losses.py:591-649), but ObservationsLoss' weighted branch calls TensorFolder.fold without its second argument
+    (losses.py:105) and raises TypeError for any input -- there is no reference behaviour to be on par with (default False, configuration.py:66)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ref_harness as rh
+    rh.install()
+    from training.losses import MotionLossWeightMaskCalculator, ObservationsLoss
+    g = torch.Generator().manual_seed(0)
+    obs, rec = torch.rand(2, 4, 3, 16, 24, generator=g) * 2 - 1, torch.rand(2, 3, 3, 16, 24, generator=g) * 2 - 1
+    mask = MotionLossWeightMaskCalculator(0.1).compute_weight_mask(obs, rec)
+    assert mask.shape == (2, 4, 1, 16, 24) and torch.all(mask[:, 0] == 1.0)
+    with pytest.raises(TypeError):
+        ObservationsLoss()(obs, rec, mask)
