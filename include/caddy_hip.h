@@ -170,9 +170,9 @@ int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, co
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.
  *     out = CADDY_PROFILE_FAMILIES kernel families (csrc/common.h CK_*: the four k_conv_fwd tilings, k_conv_thin_out, k_conv_thin_in, three
- *             k_conv_wgrad tilings, k_conv_wgrad_small, k_wgrad_thin, k_conv_wgrad_tile, k_conv_narrow, k_conv_hx<128|64|32>, k_wgrad_hx)
+ *             k_conv_wgrad tilings, k_conv_wgrad_small, k_wgrad_thin, k_conv_wgrad_tile, k_conv_narrow, k_conv_hx<128|64|32> on 4 waves, k_wgrad_hx, k_conv_hx<128> on 8 waves)
  *             x {launches, algorithmic FLOPs, total milliseconds, algorithmic bytes} (SURVEY 8d definitions) --- */
-#define CADDY_PROFILE_FAMILIES 17
+#define CADDY_PROFILE_FAMILIES 18
 /* test aid: NaN-fill the not-zero-filled (first-touch) part of the gradient arena before every backward pass */
 int caddy_debug_set_poison(caddy_ctx* ctx, int on);
 /* test aid: caddy_loss_backward stops after the loss kernels, so caddy_get_output_grad returns the gradient of the DIRECT loss terms only

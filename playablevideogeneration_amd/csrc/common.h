@@ -110,7 +110,7 @@ struct WgradArgs {
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
 enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW,
-       CK_HX_128, CK_HX_64, CK_HX_32, CK_WGRAD_HX, CK_COUNT };
+       CK_HX_128, CK_HX_64, CK_HX_32, CK_WGRAD_HX, CK_HX_128_8W, CK_COUNT };      // CK_HX_128_8W: the 16x16x128 tile on 8 waves (VGG19, wide well-filled layers); CK_HX_128: 8x16x128 on 4 waves
 extern thread_local int g_last_conv_kernel;
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);

@@ -600,7 +600,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     }
 #undef HX_LAUNCH
 #undef HX_LAUNCH_DEEP
-    g_last_conv_kernel = bn == 128 ? CK_HX_128 : (bn == 64 ? CK_HX_64 : CK_HX_32);
+    g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
     if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
     return 1;
 }

@@ -412,7 +412,7 @@ class Engine:
     CONV_FAMILIES = ["k_conv_fwd<2, 2, 2, 2, 0, 1>", "k_conv_fwd<2, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 2, 2, 0, 1>", "k_conv_fwd<1, 1, 4, 1, 0, 1>",
                      "k_conv_thin_out", "k_conv_thin_in", "k_conv_wgrad<2, 2, 2, 2>", "k_conv_wgrad<1, 2, 2, 2>", "k_conv_wgrad<1, 1, 1, 4>",
                      "k_conv_wgrad_small", "k_wgrad_thin", "k_conv_wgrad_tile", "k_conv_narrow",
-                     "k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx"]      # csrc/common.h: CK_* (kernel families of the profiling API)
+                     "k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx", "k_conv_hx<128, 8 waves>"]      # csrc/common.h: CK_* (kernel families of the profiling API)
 
     def profile_begin(self):
         self._check(self.lib.caddy_profile_begin(C.c_void_p(self.ctx)))

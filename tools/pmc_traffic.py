@@ -11,11 +11,15 @@ import sys
 
 def short(name):
     if "k_conv_hx" in name:      # hipcc leaves these template kernels mangled in the trace (and rocprofv3 half-demangles some of them)
-        nums = [int(x) for x in re.findall(r"Li(\d+)E", name)]
-        if "k_conv_hxI" in name and len(nums) >= 4:
-            return f"k_conv_hx<{nums[3]}>"                      # <T, NPL, TH, TW, BN, WM, WN, D>
-        m = re.search(r"ELi16ELi(\d+)ELi", name)
-        return f"k_conv_hx<{m.group(1)}>" if m else "k_conv_hx<?>"
+        nums = [int(x) for x in re.findall(r"Li(\d+)E", name)]      # mangled: <T, NPL, TH, TW, BN, WM, WN, D> -> NPL, TH, TW, BN, WM, WN, D
+        if "k_conv_hxI" in name and len(nums) >= 6:
+            bn, waves = nums[3], nums[4] * nums[5]
+        else:
+            m = re.search(r"ELi16ELi(\d+)ELi(\d+)E\D*(\d+)", name)      # half-demangled: "...ELi16ELi128ELi4E, 2, 3>" = TW, BN, WM, then WN
+            if not m:
+                return "k_conv_hx<?>"
+            bn, waves = int(m.group(1)), int(m.group(2)) * int(m.group(3))
+        return f"k_conv_hx<{bn}, 8 waves>" if (bn == 128 and waves == 8) else f"k_conv_hx<{bn}>"
     if "k_wgrad_hx" in name:
         return "k_wgrad_hx"
     n = re.sub(r"\(anonymous namespace\)::", "", name)
