@@ -266,12 +266,13 @@ T4 caddy_ctx::alloc(int N, int H, int W, int C, int ld) {
     dbg.push_back(t);
     return t;
 }
-T4 caddy_ctx::alloc_nz(int N, int H, int W, int C) {
+T4 caddy_ctx::alloc_nz(int N, int H, int W, int C, bool second_writer_is_conv) {
     static const bool off = getenv("CADDY_FIRST_TOUCH") && atoi(getenv("CADDY_FIRST_TOUCH")) == 0;      // A/B aid: everything zero-filled + accumulated
     if (off) return alloc(N, H, W, C);
     int ld = round_up(C, 4);
     float* d = (float*)act.alloc_top((size_t)N * H * W * ld * 4);
     T4 t{d, (float*)((char*)d + grad_delta), N, H, W, C, (long)H * W * ld, ld, true};
+    t.nz2 = second_writer_is_conv;
     dbg.push_back(t);
     return t;
 }
@@ -426,8 +427,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
                 if (!sg[s].bcast) {
                     // first-touch inputs (this conv is their only consumer): dgrad assigns -- plain stores, or the deterministic slab split-K when under-filled
-                    d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = sg[s].t.nz ? 0 : 1;
-                    if (sg[s].t.nz) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
+                    const bool assign = sg[s].t.nz && !sg[s].t.nz2;      // nz2: a point-wise writer (residual add / up-sampling backward) assigned before this dgrad runs
+                    d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = assign ? 0 : 1;
+                    if (assign) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
                     RUN(timed_conv_fwd(d, dfl));
                 }
                 else {
@@ -448,9 +450,9 @@ T4 caddy_ctx::pool2(const T4& x, bool actf) {
     return o;
 }
 T4 caddy_ctx::up2(const T4& x) {
-    T4 o = alloc(x.N, x.H * 2, x.W * 2, x.C);
+    T4 o = alloc_nz(x.N, x.H * 2, x.W * 2, x.C);      // every up-sampled map feeds exactly one conv (UpBlock / ConvLSTM gates): its dgrad assigns, no zero-fill, no read-modify-write
     RUN(pw_up2(dv(x), dv(o), stream));
-    if (recording) tape.push_back([=]() { RUN(pw_up2_bwd(gv(o), gv(x), stream)); });
+    if (recording) tape.push_back([=]() { RUN(pw_up2_bwd(gv(o), gv(x), stream, x.nz2 ? 1 : 0)); });      // x.nz2: this is the first writer of d(x)
     return o;
 }
 
@@ -480,8 +482,8 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     }
     return s;
 }
-T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into, bool nz_out) {
-    T4 out = into ? *into : (nz_out ? alloc_nz(x.N, x.H, x.W, x.C) : alloc(x.N, x.H, x.W, x.C));
+T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into, bool nz_out, bool nz2_out) {
+    T4 out = into ? *into : ((nz_out || nz2_out) ? alloc_nz(x.N, x.H, x.W, x.C, nz2_out) : alloc(x.N, x.H, x.W, x.C));
     static const bool no_small = getenv("CADDY_BN_SMALL") && atoi(getenv("CADDY_BN_SMALL")) == 0;      // A/B aid
     const bool small = training && !bn2 && !no_small && pw_bn_small_pays(dv(x));      // one-launch path for R's small maps
     TV x2v{}; if (x2) x2v = dv(*x2);
@@ -503,7 +505,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             const TV* omp = actf ? &om : nullptr;
             if (small) {
                 TV dres{}; if (has2) dres = gv(x2c);
-                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, x.nz ? 1 : 0, stream));
+                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
                 return;
             }
             RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream));   // sums assigned; param grads fused
@@ -512,8 +514,8 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
                 RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, b2->dgamma, b2->dbeta, stream));
                 RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
             } else if (has2) {
-                if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream));
-                else RUN(pw_copy(gv(out), gv(x2c), 1, stream));
+                if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream, x2c.nz2 ? 1 : 0));      // identity path: first writer of d(x) when x is nz2
+                else RUN(pw_copy(gv(out), gv(x2c), x2c.nz2 ? 0 : 1, stream));
             }
         });
     }
@@ -521,7 +523,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
 }
 
 // ResidualBlock (model/layers/residual_block.py:51-68)
-T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
+T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into, bool nz2_out) {
     Seg sx{x, 0, true};
     if (fold) {      // roll-out: BatchNorms folded into the convs -- conv1' (+ pool) + LeakyReLU, then act(conv2'(a) + identity) in conv2's epilogue
         T4 a1 = conv(R.conv1, &sx, 1, R.ds == 1 ? 3 : 0, nullptr);
@@ -540,9 +542,9 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into) {
     if (R.has_down) {
         T4 idn = conv(R.down, &sx, 1, 0, nullptr, true);
         if (R.ds == 2) idn = pool2(idn);
-        return bn_act(c2, R.bn2, &idn, &R.bnd, true, into);
+        return bn_act(c2, R.bn2, &idn, &R.bnd, true, into, false, nz2_out);
     }
-    return bn_act(c2, R.bn2, &x, nullptr, true, into);
+    return bn_act(c2, R.bn2, &x, nullptr, true, into, false, nz2_out);
 }
 
 // RepresentationNetwork.forward (model/main_model/representation_network.py:32-58); output keeps the 65th (attention) channel
@@ -550,8 +552,9 @@ T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
     Seg so{obs_in, 0, input_grad};
     T4 x = conv(e_stem, &so, 1, 0, nullptr, true);
     x = pool2(x, fold);
-    if (!fold) x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr);
-    for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr);
+    // (outputs consumed by a residual block WITHOUT down-sampling path -- identity add + one conv -- get first-touch gradients: T4::nz2)
+    if (!fold) x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr, false, !e_res[0].has_down);
+    for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr, !e_res[i + 1].has_down);
     T4 dst = into ? *into : alloc(x.N, hs, ws, 65, 68);
     return resblock(e_res[5], x, &dst);
 }
@@ -594,7 +597,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
     if (recording) tape.push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
-    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr);
+    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true);      // feeds exactly one conv (as its first segment)
 }
 
 // ConvDynamicsNetwork.forward (model/main_model/conv_dynamics_network.py:111-133)
@@ -603,11 +606,11 @@ T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
     Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
     x = conv(r_c0, s0, 2, 0, nullptr, true);
     x = pool2(x, fold);
-    if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr);
+    if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr, true);      // -> ConvLSTM 1 gates conv only
     x = lstm_step(1, x, aux);
     Seg s1[2] = {{x, 0, true}, {aux, 1, true}};
     x = conv(r_c1, s1, 2, fold ? 3 : 0, nullptr, true);
-    if (!fold) x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr);
+    if (!fold) x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr, false, true);      // -> bilinear x2 only: its backward assigns
     x = up2(x);
     x = lstm_step(2, x, aux);
     Seg s2[2] = {{x, 0, true}, {aux, 1, true}};
@@ -624,8 +627,8 @@ void caddy_ctx::render(const T4& hdn, int slot, int nslots) {
         T4 u = up2(x);
         Seg su{u, 0, true};
         T4 c = conv(d_up[i], &su, 1, fold ? 3 : 0, nullptr, true);
-        x = fold ? c : bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr);
-        if (i < 2) x = resblock(d_res[i], x, nullptr);
+        x = fold ? c : bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr, i == 2, i < 2);      // last stage -> 7x7 FinalBlock only; others -> residual block (identity add + conv)
+        if (i < 2) x = resblock(d_res[i], x, nullptr, true);      // -> next stage's up-sampling (assigns) + this stage's FinalBlock conv (accumulates)
         if (rollout && i < 2) continue;      // generate_next returns the full-resolution frame only (model.py:597-601): the two low-resolution heads are dead code there
         T4 dst = tslice(frames[2 - i], B, nslots, slot);
         Seg sx{x, 0, true};
@@ -642,7 +645,7 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     H.att = alloc(NT, hs, ws, 1);
     RUN(pw_attn_mul(dv(x65), dv(st), dv(H.att), stream));
     if (recording) { T4 att = H.att; tape.push_back([=]() { TV none{}; (void)att; RUN(pw_attn_mul_bwd(dv(x65), gv(st), none, gv(x65), stream)); }); }
-    T4 r = resblock(a_res[0], st, nullptr);
+    T4 r = resblock(a_res[0], st, nullptr, !a_res[1].has_down);
     r = resblock(a_res[1], r, nullptr);
     HeadBufs& b = H.b;
     float* feat = falloc((size_t)NT * hp.F);

@@ -15,6 +15,8 @@ struct T4 {            // activation + gradient views with identical geometry
     float* d; float* g;
     int N, H, W, C; long sn; int ld;
     bool nz = false;   // gradient lives in the NOT-zero-filled part of the arena: its single backward writer assigns (see Arena::alloc_top)
+    bool nz2 = false;  // ... with TWO backward writers: a point-wise one that runs first in the reverse replay (residual add, bilinear up-sampling) and
+                       // assigns, and a convolution dgrad that runs later and accumulates
 };
 static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
 static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
@@ -160,14 +162,14 @@ struct caddy_ctx {
 
     // ---- helpers ----
     T4 alloc(int N, int H, int W, int C, int ld = 0);
-    T4 alloc_nz(int N, int H, int W, int C);      // gradient not zero-filled: only for tensors with a single, assigning backward writer
+    T4 alloc_nz(int N, int H, int W, int C, bool second_writer_is_conv = false);      // gradient not zero-filled: single assigning backward writer (or T4::nz2)
     float* falloc(size_t n);
     double* dalloc(size_t n);
     T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false, const T4* res = nullptr);
     T4 pool2(const T4& x, bool act = false);
     T4 up2(const T4& x);
-    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false);   // nz_out: the output feeds exactly one conv
-    T4 resblock(ResL& R, const T4& x, const T4* into);
+    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false, bool nz2_out = false);   // nz_out: the output feeds exactly one conv; nz2_out: T4::nz2
+    T4 resblock(ResL& R, const T4& x, const T4* into, bool nz2_out = false);
     T4 encode(const T4& obs_in, bool input_grad, const T4* into);
     T4 lstm_step(int i, const T4& x, const T4& aux);
     T4 dynamics(const T4& state, const T4& aux, const T4* into);

@@ -7,7 +7,7 @@ int pw_fill(const TV& d, float v, hipStream_t st);
 int pw_pool2(const TV& in, const TV& out, hipStream_t st, int act = 0);      // act: LeakyReLU(0.2) after pooling (BatchNorm-folded roll-out)
 int pw_pool2_bwd(const TV& dout, const TV& din, int assign, hipStream_t st);   // assign: din = ... (first and only writer) instead of din += ...
 int pw_up2(const TV& in, const TV& out, hipStream_t st);
-int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st);
+int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st, int assign = 0);      // assign: din = ... (first writer of a T4::nz2 gradient)
 #define RED_MAX_BLOCKS 512   // per-block partial sums: scratch = RED_MAX_BLOCKS * 2 * C doubles (C <= 1024)
 int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st);
 int pw_bn_finalize(const double* sums, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, int training,
@@ -19,12 +19,12 @@ bool pw_bn_small_pays(const TV& x);
 int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* rmean, float* rvar, float* mean, float* invstd, float* scale, float* shift,
                     const TV* x2, int act, const TV& out, hipStream_t st);
 int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
-                    float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st);
+                    float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st, int res_assign = 0)      /* res_assign: dres = ... (first writer of a T4::nz2 gradient) */;
 int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st);
 int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st);
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
                     const TV& dx, float* dgamma, float* dbeta, int assign /* dx = ... instead of += : dx has no other writer */, hipStream_t st);
-int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st);
+int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st, int assign = 0);
 int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st, const TV* hb = nullptr, const float* scale = nullptr, const float* shift = nullptr);
 int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st);
 int pw_tanh_bwd(const TV& dy, const TV& y, const TV& dz, hipStream_t st);

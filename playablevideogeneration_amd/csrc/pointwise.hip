@@ -115,8 +115,8 @@ struct FUp2 {  // bilinear x2, align_corners=False (up_block.py:35,43); q indexe
         st4(out.p + n * out.sn + (long)rem * out.ld + c, c, out.C, r);
     }
 };
-struct FUp2Bwd {  // q indexes INPUT pixels: din += sum_{a,b} w_a w_b dout[clamp(2i-1+a), clamp(2j-1+b)], w = {.25,.75,.75,.25}
-    TV dout, din;
+struct FUp2Bwd {  // q indexes INPUT pixels: din (+)= sum_{a,b} w_a w_b dout[clamp(2i-1+a), clamp(2j-1+b)], w = {.25,.75,.75,.25}
+    TV dout, din; int assign;
     __device__ void operator()(long q, int c) const {
         int HWi = din.H * din.W;
         long n = q / HWi; int rem = (int)(q - n * HWi); int i = rem / din.W, j = rem - i * din.W;
@@ -131,7 +131,7 @@ struct FUp2Bwd {  // q indexes INPUT pixels: din += sum_{a,b} w_a w_b dout[clamp
             }
         }
         float* o = din.p + n * din.sn + (long)rem * din.ld + c;
-        st4(o, c, din.C, ld4(o, c, din.C) + acc);
+        st4(o, c, din.C, assign ? acc : ld4(o, c, din.C) + acc);
     }
 };
 struct FBnApply {  // out = act(x*scale+shift + second), second = x2*scale2+shift2 | x2 | 0   (residual_block.py:57-68)
@@ -162,12 +162,12 @@ struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*l
         st4(o, c, dx.C, assign ? g : ld4(o, c, dx.C) + g);      // assign: dx has no other writer (conv output consumed by this BatchNorm only)
     }
 };
-struct FActBwdAdd {  // dres += dout * lrelu'(out)
-    TV dout, outm, dres; int HW;
+struct FActBwdAdd {  // dres (+)= dout * lrelu'(out)
+    TV dout, outm, dres; int HW; int assign;
     __device__ void operator()(long q, int c) const {
         float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C) * lmask4(ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
         float* o = dres.p + tv_off(dres, HW, q) + c;
-        st4(o, c, dres.C, ld4(o, c, dres.C) + dz);
+        st4(o, c, dres.C, assign ? dz : ld4(o, c, dres.C) + dz);
     }
 };
 struct FLstmFwd {  // gates (pre-activation, channel order [i|f|o|g] x C) -> post-activation in place; c' = f*c + i*g; h' = o*tanh(c')
@@ -416,7 +416,7 @@ int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
 // registers, the block reduces in fp64 (shuffles + LDS), finalises, and applies from registers -- one launch, one read of x.
 constexpr int BNS_PPT = 32;                  // pixels per thread -> up to 256 * 32 = 8192 pixels
 struct BnSmallFwd { TV x, x2, out; int has2, act; BnFin fin; };
-struct BnSmallBwd { TV dout, outm, x, dx, dres; int act, has_res; const float *mean, *invstd, *gamma; float *dgamma, *dbeta; int assign; };
+struct BnSmallBwd { TV dout, outm, x, dx, dres; int act, has_res; const float *mean, *invstd, *gamma; float *dgamma, *dbeta; int assign; int res_assign; };
 
 __device__ __forceinline__ void block_reduce8(double* s, double* sh, int tid) {   // result valid for all threads in sh[0..7]
 #pragma unroll
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(BnSmallBwd a) {
             float4 g = ga * is * (dz[i] - s1 - xh * s2);
             float* o = a.dx.p + tv_off(a.dx, HW, q) + c;
             st4(o, c, C, a.assign ? g : ld4(o, c, C) + g);
-            if (a.has_res) { float* r = a.dres.p + tv_off(a.dres, HW, q) + c; st4(r, c, C, ld4(r, c, C) + dz[i]); }
+            if (a.has_res) { float* r = a.dres.p + tv_off(a.dres, HW, q) + c; st4(r, c, C, a.res_assign ? dz[i] : ld4(r, c, C) + dz[i]); }
         }
     }
 }
@@ -616,7 +616,7 @@ int pw_fill(const TV& d, float v, hipStream_t st) { return run_map((long)d.N * d
 int pw_pool2(const TV& in, const TV& out, hipStream_t st, int act) { return run_map((long)out.N * out.H * out.W, out.C, FPool2{in, out, act}, st); }
 int pw_pool2_bwd(const TV& dout, const TV& din, int assign, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FPool2Bwd{dout, din, assign}, st); }
 int pw_up2(const TV& in, const TV& out, hipStream_t st) { return run_map((long)out.N * out.H * out.W, out.C, FUp2{in, out}, st); }
-int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din}, st); }
+int pw_up2_bwd(const TV& dout, const TV& din, hipStream_t st, int assign) { return run_map((long)din.N * din.H * din.W, din.C, FUp2Bwd{dout, din, assign}, st); }
 int pw_stats(const TV& x, double* sums, double* scratch, hipStream_t st) { RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch; return run_reduce<0>(a, st); }
 static BnFin make_fin(long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C, float* mean, float* invstd, float* scale, float* shift) {
     BnFin f; f.count = (double)count; f.gamma = gamma; f.beta = beta; f.rmean = rmean; f.rvar = rvar; f.C = C; f.momentum = 0.1f; f.eps = 1e-5f;
@@ -650,9 +650,9 @@ int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* r
 }
 // BatchNorm backward in one launch: dx += ..., dgamma/dbeta +=, and (optional) dres += dout * act'(out) for the residual input
 int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
-                    float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st) {
+                    float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st, int res_assign) {
     if (!pw_bn_small_ok(x)) return -1;
-    BnSmallBwd a{dout, outm ? *outm : dout, x, dx, dres ? *dres : dx, outm ? 1 : 0, dres ? 1 : 0, mean, invstd, gamma, dgamma, dbeta, assign};
+    BnSmallBwd a{dout, outm ? *outm : dout, x, dx, dres ? *dres : dx, outm ? 1 : 0, dres ? 1 : 0, mean, invstd, gamma, dgamma, dbeta, assign, res_assign};
     hipLaunchKernelGGL(k_bn_small_bwd, dim3(cdiv(x.C, 4)), dim3(256), 0, st, a);
     return 0;
 }
@@ -672,7 +672,7 @@ int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* me
     if (dgamma) hipLaunchKernelGGL(k_bn_param_grad, dim3(cdiv(x.C, 64)), dim3(64), 0, st, sums, x.C, dgamma, dbeta);
     return 0;
 }
-int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st) { return run_map((long)dres.N * dres.H * dres.W, dres.C, FActBwdAdd{dout, outm, dres, dres.H * dres.W}, st); }
+int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st, int assign) { return run_map((long)dres.N * dres.H * dres.W, dres.C, FActBwdAdd{dout, outm, dres, dres.H * dres.W, assign}, st); }
 int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st, const TV* hb, const float* scale, const float* shift) {
     return run_map((long)h.N * h.H * h.W, h.C, FLstmFwd{gates, cprev, h, cn, h.H * h.W, hb ? *hb : TV{}, hb ? scale : nullptr, hb ? shift : nullptr}, st);
 }
