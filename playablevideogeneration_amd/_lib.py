@@ -25,7 +25,8 @@ class ConvArgs(C.Structure):
                 ("wp", C.c_void_p), ("Ktot", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("bias", C.c_void_p), ("act", C.c_int),
                 ("out", C.c_void_p), ("out_sn", C.c_long), ("out_ld", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("splitk", C.c_int), ("aux", C.c_void_p), ("split_scratch", C.c_void_p), ("split_cap", C.c_long), ("split_stride", C.c_long),
                 ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float),
-                ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int), ("xcd_map", C.c_int)]
+                ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int), ("xcd_map", C.c_int),
+                ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int)]
 
 
 class WgradArgs(C.Structure):

@@ -74,6 +74,13 @@ struct ConvArgs {
     long res_sn;
     int res_ld;
     int xcd_map;            // set by the launcher (conv_hx): workgroup -> (tile, channel block) order that keeps a pixel tile's channel blocks on one XCD
+    // MaxPool2d(2, 2) of the activated output written by the conv epilogue (k_conv_hx only; the four pixels of a window sit in one lane's
+    // accumulators): (N, H/2, W/2, Cout) with floor semantics on odd sizes.  skip_out: do not write the full-resolution output at all (a branch
+    // that is never back-propagated: the ground-truth features of the VGG19 loss)
+    float* pool_out;
+    long pool_sn;
+    int pool_ld;
+    int skip_out;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and

@@ -271,7 +271,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     v = mk > 0.f ? v : 0.f;
                 }
                 if (a.accumulate) v += a.out[off];
-                a.out[off] = v;
+                if (!a.skip_out) a.out[off] = v;
+                acc[i][j][r] = v;                              // (kept for the fused max-pool below)
+            }
+            if (a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const int m = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int py = (y0 + m / TW) >> 1, px = (x0 + m % TW) >> 1;
+                    if (py >= (a.H >> 1) || px >= (a.W >> 1)) continue;      // floor semantics: the last row / column of an odd map belongs to no window
+                    const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
+                    a.pool_out[(long)n * a.pool_sn + ((long)py * (a.W >> 1) + px) * a.pool_ld + col] = mx;
+                }
             }
         }
     }
@@ -537,6 +548,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     const int bn = hx_pick_bn(a.Cout);
     a.Cout_pad = round_up(a.Cout, bn);
     if (a.mask && a.accumulate) return -1;
+    if (a.pool_out && (a.accumulate || a.mask)) return -1;
     const int nchunks = kq / HX_KC;
     // tiles: 128-channel layers -> 16x16 pixels x 128 channels on 8 waves with the 3-deep weight-tile ring when that fills the chip, else
     // 8x16 pixels on 4 waves (R's small feature maps); 16x16 x 64 / 32 channels for the narrower layers
@@ -555,7 +567,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     const float* real_res = a.res;
     const long P = (long)a.N * a.H * a.W;
-    if (blocks < 200 && nchunks >= 2 && !a.mask) {
+    if (blocks < 200 && nchunks >= 2 && !a.mask && !a.pool_out) {
         int want = (int)((512 + blocks - 1) / blocks);         // two workgroups per CU
         if (want > nchunks) want = nchunks;                     // a slice is at least one chunk (= one staged halo tile) x nine taps
         if (want > 16) want = 16;

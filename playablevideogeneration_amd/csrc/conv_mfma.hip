@@ -705,6 +705,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
     { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
+    if (a.pool_out || a.skip_out) return -1;      // fused max-pool / write-less epilogues exist in k_conv_hx only: the caller must not ask the other kernels for them
     const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
     if (a.seed_ref && !a.mask) return -1;
     const bool fold_epilogue = a.act == 3 || a.res != nullptr;      // LeakyReLU / residual epilogues (BatchNorm-folded roll-out): k_conv_fwd, k_conv_hx, k_conv_narrow

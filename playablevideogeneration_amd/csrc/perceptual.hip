@@ -216,17 +216,22 @@ int conv_call(caddy_ctx* c, const ConvArgs& a, double flops, int kind) {
     return rc;
 }
 // 13 x (conv3x3 + bias + ReLU) with the 2x2 max-pools; taps[] (if given) receive the five tapped feature maps in place
-void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
+void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool keep_all) {
     bool dry = c->dry;
     VggState& V = c->vgg;
     T4 x = img;
+    T4 pooled{};                                              // output of a max-pool fused into the previous conv's epilogue
+    bool have_pooled = false;
     for (int i = 0; i < VGG_NCONV; i++) {
         VggLayer& L = V.conv[i];
         if (VGG[i].pool_before) {
-            T4 p = valloc(c, x.N, x.H / 2, x.W / 2, x.C);
-            const long n4 = (long)p.N * p.H * p.W * (p.C / 4);
-            if (!dry) hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(n4)), dim3(256), 0, c->stream, (const float*)x.d, p.d, n4, x.H, x.W, p.C / 4);
-            B.p[i] = p; x = p;
+            if (have_pooled) { B.p[i] = pooled; x = pooled; have_pooled = false; }
+            else {
+                T4 p = valloc(c, x.N, x.H / 2, x.W / 2, x.C);
+                const long n4 = (long)p.N * p.H * p.W * (p.C / 4);
+                if (!dry) hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(n4)), dim3(256), 0, c->stream, (const float*)x.d, p.d, n4, x.H, x.W, p.C / 4);
+                B.p[i] = p; x = p;
+            }
         }
         T4 out = (taps && VGG[i].tap >= 0) ? taps[VGG[i].tap] : valloc(c, x.N, x.H, x.W, VGG[i].cout);
         ConvArgs a{};
@@ -235,6 +240,16 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps) {
         a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld;
         a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : (c->vgg_precision == PREC_BF16X3 ? PREC_BF16X3 : PREC_F16X3));
         if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : (a.precision == PREC_BF16X3 ? 2 : 0)];
+        // MaxPool2d(2, 2) in front of the next conv: written by THIS conv's epilogue on the split-operand kernel (the window's four pixels sit in
+        // one lane) -- no separate pass over the full-resolution map; a branch that is never back-propagated (keep_all = false: the ground truth)
+        // does not even store the full-resolution map of such a layer (it is no tap: the taps are the first convs AFTER a pool)
+        static const bool no_fuse = getenv("CADDY_VGG_FUSE_POOL") && atoi(getenv("CADDY_VGG_FUSE_POOL")) == 0;      // A/B aid
+        if (!no_fuse && i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && VGG[i].cin >= 32) {
+            pooled = valloc(c, x.N, x.H / 2, x.W / 2, VGG[i].cout);
+            a.pool_out = pooled.d; a.pool_sn = pooled.sn; a.pool_ld = pooled.ld;
+            a.skip_out = (!keep_all && VGG[i].tap < 0) ? 1 : 0;
+            have_pooled = true;
+        }
         if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
         B.a[i] = out; x = out;
     }
@@ -260,7 +275,7 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
         const size_t m0 = c->act.off;
         Branch G{};
         const bool was_dry = c->dry; c->dry = true;
-        vgg_forward(c, c->gt_img[0], G, c->gt_taps[0]);
+        vgg_forward(c, c->gt_img[0], G, c->gt_taps[0], false);
         c->dry = was_dry;
         scratch_bytes = c->act.off - m0;
         // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every resolution
@@ -279,7 +294,7 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
         const size_t keep = c->act.off;
         c->act.off = c->gt_scratch_off;                        // (host-side bump pointer only: the region is private to the side stream)
         Branch G{};
-        vgg_forward(c, gi, G, c->gt_taps[r]);
+        vgg_forward(c, gi, G, c->gt_taps[r], false);
         c->act.off = keep;
     }
     c->stream = main_st;
@@ -307,10 +322,10 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
             int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
             for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; }      // MaxPool2d floors odd sizes
             const size_t mark2 = c->act.off;
-            vgg_forward(c, gt_img[r], G, taps);
+            vgg_forward(c, gt_img[r], G, taps, false);
             c->act.off = mark2;                  // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
         }
-        vgg_forward(c, rec, R, nullptr);
+        vgg_forward(c, rec, R, nullptr, true);
         // per-level sums and weights.  w_l = lambda * (l == 0 ? 1 : 2) / 3 / numel_l   (aliasing of level 0 with the total, see the header)
         float wl[5];
         int li[5];

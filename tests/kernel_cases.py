@@ -487,7 +487,7 @@ PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
 
 
 def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
-                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False):
+                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False, pool=False, skip_out=False):
     """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
     dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
     Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
@@ -575,6 +575,10 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
         scr = torch.zeros(8 * N * H * W * round_up(out_c, 4), device=dev)
         a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
+    if pool:                               # MaxPool2d(2, 2) of the activated output written by the conv epilogue (floor on odd sizes)
+        pld = round_up(out_c, 4) + 4
+        pout = torch.full((N, H // 2, W // 2, pld), 5.5, device=dev)
+        a.pool_out, a.pool_sn, a.pool_ld, a.skip_out = pout.data_ptr(), (H // 2) * (W // 2) * pld, pld, 1 if skip_out else 0
     lib.caddy_k_hx_force_big(big)          # 1: the 8-wave 16x16x128 variant with the 3-deep weight-tile ring even on a small grid
     try:
         assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
@@ -583,9 +587,17 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     sync(dev)
     y = to_nchw(out, out_c).double()
     scale = ref.abs().max().item()
-    err = (y - ref).abs().max().item() / scale
     if tol is None:
         tol = {PREC_F16X3: 2e-6, PREC_BF16X3: 1e-4, PREC_F16X1: 4e-3, PREC_BF16X1: 3e-2}[precision]
+    if pool:
+        pref = F.max_pool2d(ref, 2, 2)
+        perr = (to_nchw(pout, out_c).double() - pref).abs().max().item() / scale
+        assert perr < tol, ("fused max-pool", perr, tol)
+        assert torch.all(pout[..., out_c:].cpu() == 5.5)
+    if skip_out:
+        assert torch.equal(out.cpu(), init)                                 # the full-resolution output was not written at all
+        return 0.0
+    err = (y - ref).abs().max().item() / scale
     assert err < tol, ("hx conv", err, tol)
     assert torch.equal(out[..., out_c:].cpu(), init[..., out_c:])           # pad channels untouched
     return err

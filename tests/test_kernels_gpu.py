@@ -111,6 +111,14 @@ def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)
 
 
+def test_conv_hx_fused_maxpool_epilogue(lib):
+    """MaxPool2d(2, 2) written by the conv epilogue at VGG19 shapes (conv1_2 / conv3_4 / conv4_4), incl. the write-less ground-truth form and an odd map"""
+    K.hx_conv_case(lib, "cuda", N=4, H=256, W=256, segs=[(64, False)], Cout=64, bias=True, act=2, pool=True)
+    K.hx_conv_case(lib, "cuda", N=8, H=64, W=64, segs=[(256, False)], Cout=256, bias=True, act=2, pool=True, skip_out=True)
+    K.hx_conv_case(lib, "cuda", N=16, H=32, W=32, segs=[(512, False)], Cout=512, bias=True, act=2, pool=True)
+    K.hx_conv_case(lib, "cuda", N=3, H=41, W=53, segs=[(128, False)], Cout=128, bias=True, act=2, pool=True)
+
+
 def test_folded_inference_epilogues(lib):
     """roll-out epilogues (eval-mode BatchNorm folded into the conv): PackDesc.oscale, ConvArgs.res + LeakyReLU(0.2) at the batch-1 Tennis shapes"""
     K.conv_case(lib, "cuda", N=1, H=32, W=32, segs=[(64, 0)], Cout=65, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)        # E's last block: generic kernel, slabs + reduce

@@ -60,6 +60,16 @@ def test_perceptual_loss_small():
     M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=80, gt=1, tau=0.8), lam=0.7)
 
 
+def test_perceptual_loss_small_split_operands_and_fused_pools():
+    """the same on the MI355X default arithmetic: split-f16 / split-bf16 VGG19 convolutions, max-pools written by the conv epilogues, the
+    ground-truth branch without its full-resolution maps"""
+    M.SIM_SPLIT = True
+    try:
+        M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=64, gt=1, tau=0.8), lam=0.7)
+    finally:
+        M.SIM_SPLIT = False
+
+
 def test_full_reduced_s1_split_operand_kernels():
     """the default arithmetic of the MI355X runs (split-f16 forward, split-bf16 backward on conv_hx.hip) through the whole driver"""
     M.SIM_SPLIT = True
