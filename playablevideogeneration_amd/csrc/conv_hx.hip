@@ -50,7 +50,9 @@ template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 // layer (9.4 MB split) do not stay in the 4 MB L2 of an XCD, and one step of MFMA work (0.3 - 0.6 us) cannot hide that round trip).
 // Measured on the MI355X (tools/gpu_hx_experiments.sh, VGG 512 -> 512 @32x32 x 60): of 864 us at D = 1 / 4 waves, 46 % was the weight-tile
 // path and 32 % the activation staging (its global loads were also waited for by the in-order vmcnt of the next weight tile).
-template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D>
+// EPX: epilogue extras compiled in -- the fused 2x2 max-pool (ConvArgs.pool_out) and the write-less mode (skip_out) of the VGG19 layers in front of a
+// pool.  A template parameter, not a run-time test: with the code present in every instance the batch-1 roll-out ran 7 % slower (1232 -> 1150 frames/s).
+template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, bool EPX = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -271,10 +273,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     v = mk > 0.f ? v : 0.f;
                 }
                 if (a.accumulate) v += a.out[off];
-                if (!a.skip_out) a.out[off] = v;
-                acc[i][j][r] = v;                              // (kept for the fused max-pool below)
+                if (!EPX || !a.skip_out) a.out[off] = v;
+                if (EPX) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
             }
-            if (a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
+            if (EPX && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
                     const int m = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -557,7 +559,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     bool big = bn == 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) >= 384;
     if (force_big >= 0) big = bn == 128 && force_big == 1;
     // narrower layers: 16x16-pixel tiles, or 8x16 when those would leave CUs idle (E / A on one time step's frames, R's side branches)
-    const bool small_tiles = bn < 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) < 384;
+    const bool small_tiles = bn < 128 && force_big != 1 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) < 384;      // (tests force the well-filled variants with 1)
     const int th = ((bn == 128 && !big) || small_tiles) ? 8 : 16;
     const int tx = cdiv(a.W, 16), ty = cdiv(a.H, th);
     const long blocks = (long)a.N * tx * ty * (a.Cout_pad / bn);
@@ -604,6 +606,13 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);  \
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);                   \
     } while (0)
+    if (a.pool_out || a.skip_out) {      // VGG19 layers in front of a max-pool: the two tile variants those layers run on (perceptual.hip asks only when this holds)
+        if (a.precision != PREC_F16X3 || !(big || (bn == 64 && !small_tiles))) return -1;
+        if (big) hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 128, 4, 2, 3, true>), grid, dim3(512), 0, st, a, tx, ty);
+        else hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 64, 4, 1, 1, true>), grid, dim3(256), 0, st, a, tx, ty);
+        g_last_conv_kernel = big ? CK_HX_128_8W : CK_HX_64;
+        return 1;
+    }
     switch (a.precision) {
         case PREC_F16X3: if (deep) HX_LAUNCH_DEEP(_Float16); else HX_LAUNCH(_Float16, 2); break;
         case PREC_BF16X3: if (deep) HX_LAUNCH_DEEP(__bf16); else HX_LAUNCH(__bf16, 2); break;

@@ -425,6 +425,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux;
                 if (Lp->wqd[s] && prec_bwd != PREC_FP32) { d.wq = Lp->wqd[s]; d.precision = PREC_BF16X3; }
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
+                const int kind_save = prof_kind_override;
+                if (prof_kind_override < 0) prof_kind_override = 1;      // profiling: a dgrad launch, whether it assigns or accumulates
+                struct KindRestore { int& k; int v; ~KindRestore() { k = v; } } kind_restore{prof_kind_override, kind_save};
                 if (!sg[s].bcast) {
                     // first-touch inputs (this conv is their only consumer): dgrad assigns -- plain stores, or the deterministic slab split-K when under-filled
                     const bool assign = sg[s].t.nz && !sg[s].t.nz2;      // nz2: a point-wise writer (residual add / up-sampling backward) assigned before this dgrad runs

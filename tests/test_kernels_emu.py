@@ -103,13 +103,13 @@ def test_conv_hx_8wave_pipelined_variant_small():
 
 
 def test_conv_hx_fused_maxpool_epilogue_small():
-    """MaxPool2d(2, 2) of the ReLU output written by the conv epilogue (VGG19 layers in front of a pool): odd map sizes (floor), every tile variant,
-    and the write-less form of the ground-truth branch"""
+    """MaxPool2d(2, 2) of the ReLU output written by the conv epilogue (VGG19 layers in front of a pool; the two tile variants that carry that
+    epilogue, forced here): odd map sizes (floor), two channel blocks, and the write-less form of the ground-truth branch"""
     lib = load_emu()
-    K.hx_conv_case(lib, "cpu", N=2, H=19, W=21, segs=[(40, False)], Cout=48, bias=True, act=2, pool=True)                     # 8x16x64 tiles, odd H and W
-    K.hx_conv_case(lib, "cpu", N=1, H=20, W=36, segs=[(64, False)], Cout=130, bias=True, act=2, pool=True, big=1)             # 8-wave 16x16x128, two channel blocks
-    K.hx_conv_case(lib, "cpu", N=1, H=16, W=18, segs=[(64, False)], Cout=128, bias=True, act=2, pool=True, skip_out=True, big=0)
-    K.hx_conv_case(lib, "cpu", N=1, H=34, W=16, segs=[(32, False)], Cout=32, act=2, pool=True)
+    K.hx_conv_case(lib, "cpu", N=2, H=19, W=21, segs=[(40, False)], Cout=48, bias=True, act=2, pool=True, big=1)                # 16x16x64 tiles, odd H and W
+    K.hx_conv_case(lib, "cpu", N=1, H=20, W=36, segs=[(64, False)], Cout=130, bias=True, act=2, pool=True, big=1)               # 8-wave 16x16x128, two channel blocks
+    K.hx_conv_case(lib, "cpu", N=1, H=16, W=18, segs=[(64, False)], Cout=128, bias=True, act=2, pool=True, skip_out=True, big=1)
+    K.hx_conv_case(lib, "cpu", N=1, H=34, W=16, segs=[(32, False)], Cout=64, act=2, pool=True, skip_out=True, big=1)
 
 
 def test_conv_hx_dgrad_mask_seed_epilogue_small():

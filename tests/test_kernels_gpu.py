@@ -114,9 +114,9 @@ def test_conv_hx_forward(lib, kw):
 def test_conv_hx_fused_maxpool_epilogue(lib):
     """MaxPool2d(2, 2) written by the conv epilogue at VGG19 shapes (conv1_2 / conv3_4 / conv4_4), incl. the write-less ground-truth form and an odd map"""
     K.hx_conv_case(lib, "cuda", N=4, H=256, W=256, segs=[(64, False)], Cout=64, bias=True, act=2, pool=True)
-    K.hx_conv_case(lib, "cuda", N=8, H=64, W=64, segs=[(256, False)], Cout=256, bias=True, act=2, pool=True, skip_out=True)
-    K.hx_conv_case(lib, "cuda", N=16, H=32, W=32, segs=[(512, False)], Cout=512, bias=True, act=2, pool=True)
-    K.hx_conv_case(lib, "cuda", N=3, H=41, W=53, segs=[(128, False)], Cout=128, bias=True, act=2, pool=True)
+    K.hx_conv_case(lib, "cuda", N=12, H=64, W=64, segs=[(256, False)], Cout=256, bias=True, act=2, pool=True, skip_out=True)
+    K.hx_conv_case(lib, "cuda", N=24, H=32, W=32, segs=[(512, False)], Cout=512, bias=True, act=2, pool=True)
+    K.hx_conv_case(lib, "cuda", N=40, H=41, W=53, segs=[(128, False)], Cout=128, bias=True, act=2, pool=True)
 
 
 def test_folded_inference_epilogues(lib):

@@ -60,9 +60,9 @@ def test_perceptual_loss_small():
     M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=80, gt=1, tau=0.8), lam=0.7)
 
 
-def test_perceptual_loss_small_split_operands_and_fused_pools():
-    """the same on the MI355X default arithmetic: split-f16 / split-bf16 VGG19 convolutions, max-pools written by the conv epilogues, the
-    ground-truth branch without its full-resolution maps"""
+def test_perceptual_loss_small_split_operands():
+    """the same on the MI355X default arithmetic: split-f16 / split-bf16 VGG19 convolutions (the fused max-pool epilogue needs >= 384 workgroups:
+    kernel-level cases in test_kernels_emu.py, end to end in the GPU suite)"""
     M.SIM_SPLIT = True
     try:
         M.perceptual_oracle_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=64, gt=1, tau=0.8), lam=0.7)
