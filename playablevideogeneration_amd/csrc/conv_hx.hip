@@ -50,13 +50,17 @@ template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 // layer (9.4 MB split) do not stay in the 4 MB L2 of an XCD, and one step of MFMA work (0.3 - 0.6 us) cannot hide that round trip).
 // Measured on the MI355X (tools/gpu_hx_experiments.sh, VGG 512 -> 512 @32x32 x 60): of 864 us at D = 1 / 4 waves, 46 % was the weight-tile
 // path and 32 % the activation staging (its global loads were also waited for by the in-order vmcnt of the next weight tile).
-// EPX: epilogue extras compiled in -- the fused 2x2 max-pool (ConvArgs.pool_out) and the write-less mode (skip_out) of the VGG19 layers in front of a
-// pool.  A template parameter, not a run-time test: with the code present in every instance the batch-1 roll-out ran 7 % slower (1232 -> 1150 frames/s).
-template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, bool EPX = false>
+// EP: epilogue extras compiled in (template parameter, not run-time tests: a workgroup of an under-filled launch is a cold-start chain of prologue ->
+// 9..18 steps -> epilogue, and the fully unrolled epilogue is half of the ~40 KB of code it has to fetch; with the VGG19-only paths in every
+// instance the batch-1 roll-out ran 7 % slower).  0: bias / residual / ReLU / LeakyReLU / accumulate / split-K -- everything the model's layers need;
+// 1: + fused 2x2 max-pool (ConvArgs.pool_out) and write-less mode (skip_out) of the VGG19 layers in front of a pool; 2: + ReLU mask / L1 seed of the
+// VGG19 dgrad chain (ConvArgs.mask, seed_ref); 3: both (single-product study variants).  tanh (FinalBlocks) is not an hx epilogue at all.
+template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, int EP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int NT = 64 * WM * WN;                         // threads
+    constexpr bool E_POOL = EP == 1 || EP == 3, E_MASK = EP == 2 || EP == 3;
     constexpr int BM = TH * TW;
     constexpr int HW_ = TW + 2, HH_ = TH + 2, HPX = HW_ * HH_;
     constexpr int PITCH = NPL * KC + 8;                      // LDS row pitch in 16-bit elements: 72 (144 B) or 40 (80 B)
@@ -264,19 +268,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     continue;
                 }
                 if (a.res) v += a.res[(long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + col];
-                if (a.act == 1) v = tanhf(v);
-                else if (a.act == 2) v = fmaxf(v, 0.f);
+                if (a.act == 2) v = fmaxf(v, 0.f);
                 else if (a.act == 3) v = v > 0.f ? v : 0.2f * v;
-                if (a.mask) {
+                if (E_MASK && a.mask) {
                     const float mk = a.mask[off];
                     if (a.seed_ref) { const float d = mk - a.seed_ref[off]; v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
                     v = mk > 0.f ? v : 0.f;
                 }
                 if (a.accumulate) v += a.out[off];
-                if (!EPX || !a.skip_out) a.out[off] = v;
-                if (EPX) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
+                if (!E_POOL || !a.skip_out) a.out[off] = v;
+                if (E_POOL) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
             }
-            if (EPX && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
+            if (E_POOL && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
                     const int m = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -542,7 +545,7 @@ int g_hx_big_override = -1;      // tests: force (1) / forbid (0) the 8-wave 16x
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
-    if (a.KS != 3 || !a.wq || a.precision < PREC_F16X3 || a.precision > PREC_BF16X1) return 0;
+    if (a.KS != 3 || !a.wq || a.precision < PREC_F16X3 || a.precision > PREC_BF16X1 || a.act == 1) return 0;      // (tanh: FinalBlocks, 3 output channels -- never an hx layer)
     int kq = 0;
     for (int s = 0; s < a.nsrc; s++) { if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return -1; kq += round_up(a.src[s].C, HX_KC); }
     a.Kq = kq;
@@ -589,35 +592,42 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame
     static const int env_deep = getenv("CADDY_HX_DEEP") ? atoi(getenv("CADDY_HX_DEEP")) : 1;      // A/B aid
     const bool deep = env_deep && !big && (a.precision == PREC_F16X3 || a.precision == PREC_BF16X3) && blocks * a.splitk <= 256;
-#define HX_LAUNCH_DEEP(T_)                                                                                                        \
+#define HX_LAUNCH_DEEP(T_, EP_)                                                                                                   \
     do {                                                                                                                          \
-        if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 128, 2, 2, 3>), grid, dim3(256), 0, st, a, tx, ty);            \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 64, 2, 2, 3>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);        \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 32, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);      \
-        else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 32, 4, 1, 3>), grid, dim3(256), 0, st, a, tx, ty);                      \
+        if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 128, 2, 2, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);       \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 64, 2, 2, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 32, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty); \
+        else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 32, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);                 \
     } while (0)
-#define HX_LAUNCH(T_, NPL_)                                                                                                       \
+#define HX_LAUNCH(T_, NPL_, EP_)                                                                                                  \
     do {                                                                                                                          \
-        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3>), grid, dim3(512), 0, st, a, tx, ty);              \
-        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, 1>), grid, dim3(256), 0, st, a, tx, ty);    \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, 1>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);     \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);  \
-        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);                   \
+        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_>), grid, dim3(512), 0, st, a, tx, ty);         \
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);    \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);     \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);  \
+        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);                   \
     } while (0)
+    const bool vgg_bwd = a.mask != nullptr;      // ReLU mask / L1 seed epilogue (VGG19 dgrad chain): split-bf16 instances with EP = 2
     if (a.pool_out || a.skip_out) {      // VGG19 layers in front of a max-pool: the two tile variants those layers run on (perceptual.hip asks only when this holds)
         if (a.precision != PREC_F16X3 || !(big || (bn == 64 && !small_tiles))) return -1;
-        if (big) hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 128, 4, 2, 3, true>), grid, dim3(512), 0, st, a, tx, ty);
-        else hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 64, 4, 1, 1, true>), grid, dim3(256), 0, st, a, tx, ty);
+        if (big) hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 128, 4, 2, 3, 1>), grid, dim3(512), 0, st, a, tx, ty);
+        else hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 64, 4, 1, 1, 1>), grid, dim3(256), 0, st, a, tx, ty);
         g_last_conv_kernel = big ? CK_HX_128_8W : CK_HX_64;
         return 1;
     }
     switch (a.precision) {
-        case PREC_F16X3: if (deep) HX_LAUNCH_DEEP(_Float16); else HX_LAUNCH(_Float16, 2); break;
-        case PREC_BF16X3: if (deep) HX_LAUNCH_DEEP(__bf16); else HX_LAUNCH(__bf16, 2); break;
-        case PREC_F16X1: HX_LAUNCH(_Float16, 1); break;
-        default: HX_LAUNCH(__bf16, 1); break;
+        case PREC_F16X3:
+            if (vgg_bwd) return -1;      // (masks exist on the gradient side only)
+            if (deep) HX_LAUNCH_DEEP(_Float16, 0); else HX_LAUNCH(_Float16, 2, 0);
+            break;
+        case PREC_BF16X3:
+            if (vgg_bwd) { if (deep) HX_LAUNCH_DEEP(__bf16, 2); else HX_LAUNCH(__bf16, 2, 2); }
+            else { if (deep) HX_LAUNCH_DEEP(__bf16, 0); else HX_LAUNCH(__bf16, 2, 0); }
+            break;
+        case PREC_F16X1: HX_LAUNCH(_Float16, 1, 3); break;
+        default: HX_LAUNCH(__bf16, 1, 3); break;
     }
 #undef HX_LAUNCH
 #undef HX_LAUNCH_DEEP
