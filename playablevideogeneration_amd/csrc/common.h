@@ -124,7 +124,8 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 struct PackDesc;
 int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
-int conv_hx_try(const ConvArgs& a, hipStream_t st);           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
+int conv_hx_try(const ConvArgs& a, hipStream_t st);
+bool conv_hx_pool_ok(int N, int H, int W, int Cout);      // will conv_hx_try run this geometry on a tile variant with the fused max-pool epilogue?           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
 int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward form, else dgrad form of that input segment */, int precision, hipStream_t st);
 size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);

@@ -542,6 +542,18 @@ int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg, int precision, h
 int hx_pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 int g_hx_big_override = -1;      // tests: force (1) / forbid (0) the 8-wave 16x16x128 tile variant regardless of the grid size
 
+// does conv_hx_try run a launch of this geometry on one of the two tile variants that carry the fused max-pool epilogue (EP = 1)?
+// (the same decisions as below, incl. the test / environment overrides)
+bool conv_hx_pool_ok(int N, int H, int W, int Cout) {
+    const int bn = hx_pick_bn(Cout);
+    const long wgs = (long)N * cdiv(W, 16) * cdiv(H, 16) * (round_up(Cout, bn) / bn);
+    static const int env_big = getenv("CADDY_HX_BIG") ? atoi(getenv("CADDY_HX_BIG")) : -1;
+    const int force_big = g_hx_big_override >= 0 ? g_hx_big_override : env_big;
+    if (bn == 128) return force_big >= 0 ? force_big == 1 : wgs >= 384;
+    if (bn == 64) return force_big == 1 || wgs >= 384;
+    return false;
+}
+
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
@@ -648,7 +660,7 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     const int tx = cdiv(a.W, WG_TW), ty = cdiv(a.H, WG_TH);
     const long ntiles = (long)a.N * tx * ty;
     const int kt = cdiv(a.Ktot, WG_KC), ot = cdiv(a.Cout, WG_OC);
-    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 512;      // persistent workgroups (2 per CU)
+    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;      // persistent workgroups: one per CU (measured in the step: 128 / 192 / 256 / 384 / 512 -> 169.1 / 166.7 / 167.7 / 169.0 / 170.8 ms -- the side stream should not crowd the dgrad chain)
     long g = blocks / ((long)kt * ot);
     if (g < 1) g = 1;
     if (g > ntiles) g = ntiles;

@@ -244,9 +244,7 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
         // one lane) -- no separate pass over the full-resolution map; a branch that is never back-propagated (keep_all = false: the ground truth)
         // does not even store the full-resolution map of such a layer (it is no tap: the taps are the first convs AFTER a pool)
         static const bool no_fuse = getenv("CADDY_VGG_FUSE_POOL") && atoi(getenv("CADDY_VGG_FUSE_POOL")) == 0;      // A/B aid
-        // (only where the launcher runs one of the two tile variants that carry the pooling epilogue: >= 384 workgroups of 16x16 pixels, split f16)
-        const long wgs = (long)x.N * ((x.W + 15) / 16) * ((x.H + 15) / 16) * (round_up(VGG[i].cout, hx_pick_bn(VGG[i].cout)) / hx_pick_bn(VGG[i].cout));
-        if (!no_fuse && i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && wgs >= 384) {
+        if (!no_fuse && i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && conv_hx_pool_ok(x.N, x.H, x.W, VGG[i].cout)) {
             pooled = valloc(c, x.N, x.H / 2, x.W / 2, VGG[i].cout);
             a.pool_out = pooled.d; a.pool_sn = pooled.sn; a.pool_ld = pooled.ld;
             a.skip_out = (!keep_all && VGG[i].tap < 0) ? 1 : 0;
