@@ -251,6 +251,7 @@ void build_layers(caddy_ctx* c) {
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
+    c->conv_aux2 = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
     c->conv_split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
 }

@@ -114,6 +114,7 @@ struct caddy_ctx {
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
+    float* conv_aux2 = nullptr;      // ... of the VGG19 levels that run on the side stream (perceptual.hip)
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     VggState vgg;                    // VGG19 perceptual loss (perceptual.hip); enabled by caddy_config.perceptual
     int vgg_precision = PREC_F16X3, vgg_precision_bwd = PREC_BF16X3;   // ConvArgs.precision of the VGG convolutions (forward / dgrad); PREC_FP32 = exact

@@ -311,7 +311,22 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
     hipStream_t st = c->stream;
     const bool pre = c->gt_prefetched && !dry;      // the ground-truth branch already ran beside the forward pass (vgg_gt_prefetch)
     if (pre) hipStreamWaitEvent(st, c->gt_done, 0);
-    for (int r = 0; r < 3; r++) {
+    // The half- and quarter-resolution levels (24 % of the work, most of it in under-filled launches on 8x8 ... 64x64 maps) run on the driver's side
+    // stream BESIDE the full-resolution level: separate memory (they are allocated first and stay live until the join), their own thin-kernel
+    // scratch, the three levels only meet in the loss accumulators (atomics) and write disjoint gradient tensors (d rec_r).
+    static const bool no_par = getenv("CADDY_VGG_LEVELS_PARALLEL") && atoi(getenv("CADDY_VGG_LEVELS_PARALLEL")) == 0;      // A/B aid
+    const bool par = !no_par && !dry && c->use_side && c->side != nullptr && !c->prof;
+    hipStream_t side = par ? c->wgrad_stream() : st;      // (ordered after the L1 kernels that wrote the seeds / resized ground truth)
+    const size_t mark_all = c->act.off;
+    size_t side_end = mark_all;                             // memory layout is the parallel one whether or not the levels really overlap (dry-run sizing)
+    const int order[3] = {1, 2, 0};
+    for (int oi = 0; oi < 3; oi++) {
+        const int r = order[oi];
+        const bool on_side = par && r != 0;
+        c->stream = on_side ? side : st;
+        hipStream_t st = c->stream;                         // (shadows the outer one for the point-wise launches below)
+        float* const aux = on_side ? c->conv_aux2 : c->conv_aux;
+        if (r == 0 && !no_par) c->act.off = side_end;      // above everything levels 1 / 2 may still be using
         const T4& rec = c->frames[r];
         const size_t mark = c->act.off;
         // ground-truth branch: keeps only the five tapped maps
@@ -348,7 +363,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 ConvArgs d{};
                 d.src[0] = ConvSrc{gz.g, gz.sn, gz.ld, L.pd.Cout, L.kd, 0};
                 d.nsrc = 1; d.N = in.N; d.H = in.H; d.W = in.W; d.KS = 3; d.wp = L.wpd; d.Ktot = L.kd;
-                d.Cout = VGG[i].cin; d.Cout_pad = L.cd_pad; d.bias = nullptr; d.act = 0; d.aux = c->conv_aux;
+                d.Cout = VGG[i].cin; d.Cout_pad = L.cd_pad; d.bias = nullptr; d.act = 0; d.aux = aux;
                 d.precision = c->vgg_precision_bwd == PREC_BF16X1 ? PREC_BF16X1 : (c->vgg_precision_bwd == PREC_FP32 ? PREC_FP32 : PREC_BF16X3);
                 if (d.precision != PREC_FP32 && L.wqd[0]) d.wq = L.wqd[d.precision == PREC_BF16X1 ? 1 : 0];
                 d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
@@ -365,6 +380,14 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 }
             }
         }
-        c->act.off = mark;
+        if (r != 0 && c->act.off > side_end) side_end = c->act.off;
+        c->act.off = mark;                                  // levels 1 and 2 share memory (same stream, in order)
     }
+    c->stream = st;
+    if (par) {                                               // join: the tape replay reads d(rec_1), d(rec_2)
+        hipEvent_t e = c->sev();
+        hipEventRecord(e, side);
+        hipStreamWaitEvent(st, e, 0);
+    }
+    c->act.off = mark_all;
 }
