@@ -6,7 +6,7 @@
 // accumulation (3 MFMAs per fp32 product -> ~830 TFLOP/s effective peak).  f16 halves carry 11 + 11 mantissa bits (error ~2^-22, "fp32
 // re-ordering class" -- measured indistinguishable from a fp32 summation-order change over 15 closed-loop steps);
 // bf16 halves carry 8 + 8 bits with the full fp32 exponent range (error ~2^-16, used for the gradient operands whose magnitude is
-// unbounded below).  NPROD = 1 keeps only hi*hi (plain 16-bit operands; selectable for the frozen VGG19 loss network).
+// unbounded below).  NPL = 1 keeps only hi*hi (plain 16-bit operands; a study variant for the frozen VGG19 loss network -- it fails the parity bounds).
 //
 // Structure (what the exact-fp32 k_conv_fwd could not do): operands arrive PRE-SPLIT where they are reused -- weights are split once per
 // optimiser step by pack_hx (frozen VGG19 weights: once) -- and activations are split ONCE PER TILE, not once per tap: a workgroup owns a
@@ -18,7 +18,7 @@
 //
 // Replaces nn.Conv2d(k=3, padding=1) of every wide layer on the path (model/layers/*.py), its dgrad
 // (same kernel on the flipped / transposed split weights) and the VGG19 convolutions of the perceptual loss (conv + bias + ReLU forward,
-// dgrad with the fused ReLU mask / L1 seed epilogue).
+// 2x2 max-pool written by the epilogue of the layer in front of it; dgrad with the fused ReLU mask / L1 seed epilogue).
 #include "common.h"
 #include "pack.h"
 #include <cstdlib>
