@@ -738,7 +738,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);      // a forward without a backward in between: the side stream may still read the old observations
-    c->act.reset(); c->tape.clear(); c->dbg.clear();
+    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0;
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -800,7 +800,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);
-    c->act.reset(); c->tape.clear(); c->dbg.clear();
+    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0;
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -875,7 +875,13 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     if (perc && !c->vgg.loaded) { set_error("perceptual loss requested but no VGG19 weights were loaded (caddy_load_vgg)"); return -2; }
     c->act.off = c->fwd_off;                  // release what a previous loss_backward allocated past the forward graph
     if (!dry) {
-        hipMemsetAsync((char*)c->act.base + c->grad_delta, 0, c->act.off, st);   // (zero-filling on the side stream during the forward pass was measured: no gain, the step is throughput-bound)
+        // gradient mirror of the forward's bottom-up activations (accumulating writers), minus the ground-truth VGG19 taps / scratch in its middle (several GB
+        // at BAIR 256x256 that never receive a gradient).  (Zero-filling on the side stream during the forward pass was measured: no gain.)
+        char* gm = (char*)c->act.base + c->grad_delta;
+        if (c->gt_hi > c->gt_lo && c->gt_hi <= c->act.off) {
+            hipMemsetAsync(gm, 0, c->gt_lo, st);
+            if (c->act.off > c->gt_hi) hipMemsetAsync(gm + c->gt_hi, 0, c->act.off - c->gt_hi, st);
+        } else hipMemsetAsync(gm, 0, c->act.off, st);
         static const bool poison_env = getenv("CADDY_POISON_NZ") != nullptr;   // test aid: NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
         if ((poison_env || c->poison_nz) && c->act.top < c->act.cap) hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
             hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
@@ -973,7 +979,7 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
     static const int graph_env = getenv("CADDY_ROLLOUT_GRAPH") ? atoi(getenv("CADDY_ROLLOUT_GRAPH")) : 1;      // A/B aid: 0 eager on the caller's stream, 2 eager on the internal stream
     static const bool graph_off = graph_env == 0;
     if (graph_env == 2) c->graph_failed_soft = true;
-    if (c->use_fold && !c->packed_fold) { c->drop_graph(); c->prepare_inference_weights(); }      // a forward pass re-packed the plain weights since start_inference
+    if (c->use_fold && !c->packed_fold) { if (c->gstream) hipStreamSynchronize(c->gstream); c->drop_graph(); c->prepare_inference_weights(); }      // a forward pass re-packed the plain weights since start_inference
     hipStream_t user = c->stream;
     const bool try_graph = c->use_graph && !graph_off && !c->graph_failed && !dry;
     if (try_graph && !c->gstream) {
@@ -1027,8 +1033,8 @@ void caddy_ctx::prepare_inference_weights() {
 static int start_inference(caddy_ctx* c) {
     bool dry = c->dry;
     c->training = false; c->recording = false;
+    if (c->gstream) hipStreamSynchronize(c->gstream);  // a graph launch of the previous roll-out may still be executing: never destroy its exec object under it
     c->drop_graph();                                   // weights / state may have changed: re-capture on the next frame
-    if (c->gstream) hipStreamSynchronize(c->gstream);
     c->prepare_inference_weights();
     for (int i = 0; i < 3; i++) {
         LstmL& L = c->lstm[i];

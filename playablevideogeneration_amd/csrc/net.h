@@ -121,6 +121,7 @@ struct caddy_ctx {
     int prec_fwd = PREC_F16X3, prec_bwd = PREC_BF16X3;                 // ... of the model's wide 3x3 convolutions (caddy_set_precision; CADDY_PRECISION=exact)
     // ground-truth VGG19 branch overlapped with the forward pass on the side stream (perceptual.hip: vgg_gt_prefetch)
     T4 gt_img[3]{}, gt_taps[3][5]{}; size_t gt_scratch_off = 0, gt_scratch_end = 0; bool gt_prefetched = false, perc_prefetch = true; hipEvent_t gt_done = nullptr;
+    size_t gt_lo = 0, gt_hi = 0;     // [gt_lo, gt_hi) of the activation arena: ground-truth VGG19 taps + scratch of vgg_gt_prefetch -- never back-propagated, so their gradient mirror is not zero-filled
     size_t fwd_off = 0;              // act.off at the end of the last forward: loss_backward allocates its VGG buffers past it and releases them
     int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1
     // roll-out (generate_next) as ONE graph launch per frame: static input / output / action buffers, the per-frame kernel sequence captured on

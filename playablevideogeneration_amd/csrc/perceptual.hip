@@ -266,6 +266,7 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     const int N = g.batch * Trec;
     const int tc[5] = {64, 128, 256, 512, 512};
     size_t scratch_bytes = 0;
+    c->gt_lo = (c->act.off + 255) & ~(size_t)255;
     for (int r = 0; r < 3; r++) {
         int h = g.height >> r, w = g.width >> r;
         c->gt_img[r] = valloc(c, N, h, w, 3);                  // (ld 4)
@@ -281,6 +282,7 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
         // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every resolution
         c->gt_scratch_off = m0; c->gt_scratch_end = c->act.off;
     }
+    c->gt_hi = c->act.off;
     c->gt_prefetched = false;
     if (dry || !c->vgg.loaded || !c->perc_prefetch || !c->training) return;
     c->ensure_side();

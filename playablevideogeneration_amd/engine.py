@@ -63,6 +63,7 @@ def _bind(lib):
     lib.caddy_vgg_param_info_get.argtypes = [C.c_int, C.c_void_p]
     lib.caddy_load_vgg.argtypes = [C.c_void_p, C.c_void_p]
     lib.caddy_set_vgg_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.caddy_set_perceptual_prefetch.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_set_rollout_fold.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_set_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
@@ -232,6 +233,11 @@ class Engine:
     def set_vgg_precision(self, forward: int, dgrad: int):
         """arithmetic of the VGG19 convolutions: forward 0 (exact fp32) | 16 (split f16, default) | 18 (plain f16); dgrad 0 | 17 (split bf16, default) | 19"""
         self._check(self.lib.caddy_set_vgg_precision(self.ctx, int(forward), int(dgrad)))
+
+    def set_perceptual_prefetch(self, on: bool):
+        """VGG19 features of the ground-truth frames on the side stream beside the forward pass (default) or inside loss_backward; switch it off for
+        steps that will not use the perceptual term (weight 0, no logging): the branch would run for nothing"""
+        self._check(self.lib.caddy_set_perceptual_prefetch(self.ctx, 1 if on else 0))
 
     def set_rollout_fold(self, on: bool):
         """roll-out with the eval-mode BatchNorms folded into the preceding convolutions (default) or as separate launches; takes effect at the next

@@ -6,8 +6,9 @@ Adam run fused inside libcaddy_hip.so and only one small buffer of loss scalars 
 
 VGG19 weights: the reference downloads torchvision's pretrained VGG19 at construction (model/layers/vgg.py:16).  Here they come from
 `config["training"]["vgg19_weights"]` (path of a torchvision `vgg19().state_dict()` / `.features.state_dict()` file, or the dict itself) or,
-if that key is absent, from an importable torchvision; with a non-zero `perceptual_loss_lambda[_pretraining]` and no weights the
-constructor RAISES instead of silently training a different objective.
+with the explicit opt-in `training.vgg19_from_torchvision: true`, from an importable torchvision; they are only resolved when a perceptual lambda is
+non-zero (or `training.log_perceptual: true` asks for the logged value of a zero-weight term).  With a non-zero `perceptual_loss_lambda[_pretraining]`
+and no weights the constructor RAISES instead of silently training a different objective.
 """
 import math
 import os
@@ -39,7 +40,8 @@ class Trainer:
         lw = tr["loss_weights"]
         self.perceptual_lambda = float(lw.get("perceptual_loss_lambda", 0.0))
         self.perceptual_lambda_pretraining = float(lw.get("perceptual_loss_lambda_pretraining", 0.0))
-        self.vgg_state = self._find_vgg_weights(tr)
+        need_vgg = self.perceptual_lambda != 0.0 or self.perceptual_lambda_pretraining != 0.0 or bool(tr.get("log_perceptual", False))
+        self.vgg_state = self._find_vgg_weights(tr) if need_vgg else None      # (a zero-weight term would still cost a full VGG19 forward per step)
         if (self.perceptual_lambda != 0.0 or self.perceptual_lambda_pretraining != 0.0) and self.vgg_state is None:
             raise Exception("loss_weights.perceptual_loss_lambda is non-zero but no VGG19 weights are available: set training.vgg19_weights to a "
                             "torchvision vgg19 state_dict file (the reference downloads it, model/layers/vgg.py:16) or set the lambdas to 0")
@@ -58,8 +60,10 @@ class Trainer:
         if isinstance(src, str):
             sd = torch.load(src, map_location="cpu", weights_only=True)
             return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
-        try:                                                   # what the reference does (needs torchvision + its cached / downloadable weights)
-            from torchvision import models
+        if not tr.get("vgg19_from_torchvision", False):
+            return None
+        try:                                                   # explicit opt-in only: what the reference does (torchvision + its cached / downloadable weights); never implicit --
+            from torchvision import models                     # on an air-gapped box the constructor would block on the download
             return models.vgg19(pretrained=True).features.state_dict()
         except Exception:
             return None
@@ -146,9 +150,9 @@ class Trainer:
         batch_tuple = batch.to_tuple() if hasattr(batch, "to_tuple") else batch
         model(batch_tuple, gt, gumbel_temperature=tau, fetch_outputs=False)
         eng = model.module.last_engine
+        self._to_engine_device(eng)              # BEFORE the engine takes the raw pointer of the MI estimator (a checkpoint loaded before model.cuda() left it on the CPU)
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
-        self._to_engine_device(eng)
         li = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None)
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema
@@ -171,10 +175,10 @@ class Trainer:
         batch_tuple = batch.to_tuple() if hasattr(batch, "to_tuple") else batch
         model(batch_tuple, pretraining=True, gumbel_temperature=tau, fetch_outputs=False)
         eng = model.module.last_engine
+        self._to_engine_device(eng)
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
         w = self.loss_weights(pretraining=True)
-        self._to_engine_device(eng)
         li = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None)
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema

@@ -160,6 +160,7 @@ def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
     res = json.load(open(tmp_path / "bench.json"))
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 and res["config"]["parallelism"] == "dp2"
     assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["roofline"] is not None
+    assert res["rccl_ranks_seen"] == 2 and res["erad_only"]["ms_per_step"] > 0 and "erad_hbm_frac" not in res["roofline"]      # (no SURVEY 8d figures for the tiny workload)
     for k in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
         assert k in res
 

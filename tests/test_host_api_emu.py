@@ -224,23 +224,28 @@ def trainer_golden_case(name, make_model, with_vgg):
     """One training step of the REAL reference (SmoothMITrainer.compute_losses[_pretraining] + Adam step, tools/gen_trainer_golden.py) vs the
     trainer mirror: schedule values, every shared loss_info entry incl. the logging diagnostics (and, with VGG19 weights, the perceptual
     entries), the MI estimator state, and the parameters after the optimiser step.  Shared by the simulator and the MI355X suites."""
-    from playablevideogeneration_amd import smooth_mi_trainer
+    from playablevideogeneration_amd import smooth_mi_trainer, trainer as plain_trainer
     z = np.load(H.GOLDEN + "/" + name + ".npz", allow_pickle=False)
     pretraining = "_pre_" in name
+    plain = "_plain_" in name              # training.trainer: MutualInformationLoss without the estimator (losses.py:238-302, configs/03_tennis.yaml)
     lam = float(z["perceptual_lambda"]) if "perceptual_lambda" in z.files else 0.0
     assert with_vgg or lam == 0.0
     cfg = _config(res=(8, 8))
+    if plain:
+        cfg["training"]["trainer"] = "playablevideogeneration_amd.trainer"
     cfg["training"]["loss_weights"].update(PRE_W)
     cfg["training"]["loss_weights"]["perceptual_loss_lambda"] = lam
     cfg["training"]["loss_weights"]["perceptual_loss_lambda_pretraining"] = lam
     if with_vgg:
         cfg["training"]["vgg19_weights"] = O.make_vgg_params()
+        cfg["training"]["log_perceptual"] = True              # the reference logs the VGG19 term even at weight 0; the mirror only on request
     cfg["logging"] = {"save_root_directory": "/tmp"}
     m = make_model(cfg)
     d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
     m.load_state_dict(O.make_params(d, seed=7))
     m.train()
-    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    tr = (plain_trainer if plain else smooth_mi_trainer).trainer(cfg, m, dataset=None, logger=None)
+    assert tr.SMOOTH_MI == (not plain)
     tr.global_step = int(z["global_step"])
     obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
     torch.manual_seed(int(z["step_seed"]))
@@ -259,7 +264,10 @@ def trainer_golden_case(name, make_model, with_vgg):
         perc_checked += "perceptual" in k
     assert checked - perc_checked >= (22 if pretraining else 25), checked                      # schedules, loss components, raw losses, diagnostics
     assert not with_vgg or perc_checked == 20, perc_checked                                    # avg + component + 3 x (total + 5 levels)
-    assert np.allclose(tr.mi_ema.cpu().numpy(), z["mi_ema"], atol=1e-6)
+    if plain:
+        assert tr.mi_ema is None and "mi_ema" not in z.files
+    else:
+        assert np.allclose(tr.mi_ema.cpu().numpy(), z["mi_ema"], atol=1e-6)
     tr.optimizer_step(m)
     assert abs(tr._get_current_lr() - float(z["lr"])) < 1e-12
     # Adam's first step moves every weight by ~lr * sign(g): compare per-parameter summaries; an element whose gradient is ~0 may move
@@ -278,6 +286,49 @@ def trainer_golden_case(name, make_model, with_vgg):
 def test_trainer_mirror_matches_reference_trainer_golden():
     """(the pretraining golden and the two goldens with the perceptual term run on the MI355X: tests/test_host_api_gpu.py)"""
     trainer_golden_case("trainer_reduced_s1", _make_model, with_vgg=False)
+
+
+def test_plain_trainer_mirror_matches_reference_trainer_golden():
+    """`training.trainer` of the reference (plain MutualInformationLoss, configs/03_tennis.yaml): loss_info, post-Adam parameters, no estimator state"""
+    trainer_golden_case("trainer_plain_reduced_s1", _make_model, with_vgg=False)
+
+
+def test_checkpoint_loaded_before_device_move_then_step(tmp_path):
+    """load_checkpoint() runs before the model reaches its device in train.py (:61-68).  The optimiser / MI-estimator tensors restored
+    from the checkpoint must follow the engine's device BEFORE their raw pointers are handed to the kernels -- and the step after the resume must
+    equal the step of the trainer that never went through a checkpoint."""
+    from playablevideogeneration_amd import smooth_mi_trainer
+    cfg = _config()
+    cfg["logging"] = {"save_root_directory": str(tmp_path)}
+    obs = torch.rand(2, 4, 3, 32, 32, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+
+    def fresh():
+        m = _make_model(cfg)
+        m.load_state_dict(O.make_params(d, seed=7))
+        m.train()
+        tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+        tr.global_step = 20000
+        return m, tr
+
+    def step(m, tr, seed):
+        torch.manual_seed(seed)
+        loss, _, _ = tr.compute_losses(m, (obs, None, None, None), 4)
+        tr.optimizer_step(m)
+        return loss
+    m, tr = fresh()
+    step(m, tr, 100)
+    tr.save_checkpoint(m)
+    want = step(m, tr, 101)
+    m2, tr2 = fresh()
+    tr2.load_checkpoint(m2)
+    ema_before = tr2.mi_ema.clone()
+    got = step(m2, tr2, 101)
+    assert abs(got - want) < 1e-6 * max(1.0, abs(want)), (got, want)
+    # the estimator the kernel updated through its raw pointer is the trainer's own tensor, on the engine's device (the GPU suite runs the
+    # same scenario with the real device move: test_checkpoint_loaded_before_cuda_then_step)
+    assert tr2.mi_ema.device == m2.last_engine.grads.device and m2.last_engine.mi_ema is tr2.mi_ema and not torch.equal(tr2.mi_ema, ema_before)
+    assert torch.allclose(m2._flat, m._flat, atol=1e-6)
 
 
 def test_trainer_refuses_objectives_it_does_not_implement(monkeypatch):

@@ -52,10 +52,41 @@ def test_plugin_factories_forward_and_training_progress(tmp_path):
     assert torch.equal(m2._flat.cpu(), m._flat.cpu())
 
 
-@pytest.mark.parametrize("name", ["trainer_reduced_s1", "trainer_pre_reduced_s1", "trainer_perc_reduced_s1", "trainer_perc_pre_reduced_s1"])
+@pytest.mark.parametrize("name", ["trainer_reduced_s1", "trainer_pre_reduced_s1", "trainer_perc_reduced_s1", "trainer_perc_pre_reduced_s1", "trainer_plain_reduced_s1"])
 def test_trainer_mirror_matches_reference_trainer_golden_on_gpu(name):
     """the REAL reference's training step (loss_info, MI estimator, post-Adam parameters), perceptual weight 0 and 1, on the real library"""
     trainer_golden_case(name, _build, with_vgg=True)
+
+
+def test_checkpoint_loaded_before_cuda_then_step(tmp_path):
+    """train.py loads the checkpoint BEFORE model.cuda() (train.py:61-68): Adam moments and the MI estimator restored on the CPU must be on the
+    GPU before the kernels get their raw pointers -- the resumed step equals the uninterrupted one."""
+    cfg = _config()
+    cfg["logging"] = {"save_root_directory": str(tmp_path)}
+    obs = torch.rand(2, 4, 3, 32, 32, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    P = O.make_params(d, seed=7)
+    mk = lambda m: getattr(importlib.import_module(cfg["training"]["trainer"]), "trainer")(cfg, m, dataset=None, logger=None)
+
+    def step(m, tr, seed):
+        torch.manual_seed(seed)
+        loss, _, _ = tr.compute_losses(m, (obs, None, None, None), 4)
+        tr.optimizer_step(m)
+        return loss
+    m = _build(cfg); m.load_state_dict(P); m.train()
+    tr = mk(m); tr.global_step = 20000
+    step(m, tr, 100)
+    tr.save_checkpoint(m)
+    want = step(m, tr, 101)
+    m2 = getattr(importlib.import_module(cfg["model"]["architecture"]), "model")(cfg)      # still on the CPU, as in train.py:38-39
+    tr2 = mk(m2); tr2.global_step = 20000
+    tr2.load_checkpoint(m2)                                                                  # train.py:61-65
+    assert not tr2.mi_ema.is_cuda and not tr2.adam_m.is_cuda
+    m2 = m2.cuda(); m2.train()                                                               # train.py:67-68
+    got = step(m2, tr2, 101)
+    assert tr2.mi_ema.is_cuda and tr2.adam_m.is_cuda
+    assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (got, want)
+    assert torch.allclose(m2._flat, m._flat, atol=1e-6)
 
 
 def test_evaluator_mirror_on_gpu():

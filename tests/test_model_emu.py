@@ -15,6 +15,12 @@ def test_full_reduced_s1():
     M.full_case("full_reduced_s1", load_emu(), "cpu")
 
 
+@pytest.mark.parametrize("name", ["full_reduced_s1_plainmi", "full_main_s1_nogumbel", "full_reduced_s1_novar"])
+def test_full_model_config_branches(name):
+    """plain MutualInformationLoss (training.trainer, caddy_loss_cfg.mi_ema = NULL), use_gumbel: False, use_variations: False -- goldens of the reference"""
+    M.full_case(name, load_emu(), "cpu")
+
+
 def test_rollout_reduced():
     M.rollout_case("rollout_reduced_s1", load_emu(), "cpu")
 

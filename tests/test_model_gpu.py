@@ -20,6 +20,13 @@ def test_full_model_parity(lib, name):
     M.full_case(name, lib, "cuda")
 
 
+@pytest.mark.parametrize("name", ["full_reduced_s1_plainmi", "full_main_s1_nogumbel", "full_reduced_s1_novar"])
+def test_full_model_parity_config_branches(lib, name):
+    """reference configuration branches outside the BAIR / Breakout YAMLs: the plain MutualInformationLoss of `training.trainer` (03_tennis.yaml,
+    caddy_loss_cfg.mi_ema = NULL), use_gumbel: False, use_variations: False -- forward, losses, gradients against goldens of the reference itself"""
+    M.full_case(name, lib, "cuda")
+
+
 def test_single_step_gradients_tight(lib):
     M.single_step_grad_case(lib, "cuda")
 
@@ -108,6 +115,38 @@ def test_baseline_geometry_properties(lib):
     """BASELINE.json configs[1] at full size (BAIR 256x256, T=16, B=8, gt=6): reproducibility, batch-permutation equivariance,
     loss composition, linearity of the backward (the oracle cannot run this size in test time)."""
     M.property_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=8, T=16, H=256, W=256, gt=6, tau=1.0))
+    torch.cuda.empty_cache()
+
+
+def test_baseline_geometry_properties_with_perceptual_term(lib):
+    """BASELINE.json configs[1] exactly as bench.py times it: BAIR 256x256, T=16, B=8, gt=6 WITH the VGG19 perceptual term inside the step (ground-truth
+    branch on the side stream beside the forward, half / quarter-resolution levels beside the full-resolution one, 8-wave tiles at N = 120):
+    reproducible forward, loss composition incl. the perceptual term, linearity of the backward in the weights, repeatable + finite gradients."""
+    M.property_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=8, T=16, H=256, W=256, gt=6, tau=1.0), perceptual=True)
+    torch.cuda.empty_cache()
+
+
+def test_perceptual_loss_256_vs_oracle(lib):
+    """the perceptual term at the BASELINE frame size (256x256: every VGG19 level on its well-filled tile variant, fused max-pool epilogues) vs the oracle"""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    M.perceptual_oracle_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=1, T=3, H=256, W=256, gt=1, tau=0.6), lam=1.0)
+    torch.cuda.empty_cache()
+
+
+def test_split_operand_arithmetic_vs_exact_fp32_on_device(lib):
+    """BAIR 256x256, T=16, gt=6, B=2: the default split 16-bit arithmetic vs the exact-fp32 kernels on the same device, same inputs.
+    Measured values go to profiles/ (tools/gpu_*.sh copies gpurun_out/split_vs_exact.json)."""
+    import json, os
+    res = M.split_vs_exact_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=16, H=256, W=256, gt=6, tau=0.4))
+    print(json.dumps(res, indent=1))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/split_vs_exact.json", "w") as f:
+        json.dump(res, f, indent=1)
+    for k, v in res.items():
+        if k.startswith("bwd_only:"):      # identical forward: only the 8+8-bit gradient operands differ from fp32
+            assert v["rel_l2"] <= 1e-3 and v["cosine"] >= 0.9999, (k, v)
+        elif k.startswith("fwd_and_bwd:"):
+            assert v["rel_l2"] <= 0.15 and v["cosine"] >= 0.99, (k, v)
     torch.cuda.empty_cache()
 
 

@@ -29,6 +29,12 @@ CASES = {
     # whose quarter-resolution output still reaches relu5_1 (four 2x2 max-pools)
     "perc_main_s1": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=4, H=64, W=64, gt=2, tau=0.6, hard=False, pre=False, perc=1.0),
     "perc_pre_reduced_s1": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=80, gt=0, tau=1.0, hard=False, pre=True, perc=0.5),
+    # configuration branches of the reference that the cases above do not take: the PLAIN MutualInformationLoss of training.trainer (03_tennis.yaml;
+    # losses.py:238-302, no estimator state), use_gumbel: False (plain softmax as the action assignment, model.py:177-179) and
+    # use_variations: False (zeroed action variations, model.py:188-189)
+    "full_reduced_s1_plainmi": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False, mi="plain"),
+    "full_main_s1_nogumbel": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.4, hard=False, pre=False, use_gumbel=False),
+    "full_reduced_s1_novar": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False, use_variations=False),
 }
 INTERP = [(1, 2, 0.3), (0, 2, 0.8)]           # (first_action, second_action, interpolation_factor) appended to the roll-out cases
 SAMPLER_CASES = {
@@ -41,7 +47,8 @@ PARAM_SEED, OBS_SEED, NOISE_SEED = 7, 1, 5
 
 def case_inputs(c):
     cfg = rh.make_config(variant=c["variant"], actions=c["K"], action_dim=c["Da"], hidden=c["Ch"], stacking=c["S"],
-                         state_res=(c["H"] // 8, c["W"] // 8), hard_gumbel=c["hard"])
+                         state_res=(c["H"] // 8, c["W"] // 8), hard_gumbel=c["hard"], use_gumbel=c.get("use_gumbel", True),
+                         use_variations=c.get("use_variations", True))
     d = O.Dims.from_config(cfg)
     P = O.make_params(d, seed=PARAM_SEED)
     obs = torch.rand(c["B"], c["T"], 3 * c["S"], c["H"], c["W"], generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
@@ -78,7 +85,7 @@ def main():
         data = flat_outputs(out)
         data["case"] = np.array(repr(c))
         if not c["pre"] or c.get("perc"):
-            smi = RL.SmoothMutualInformationLoss(cfg)
+            smi = RL.MutualInformationLoss() if c.get("mi") == "plain" else RL.SmoothMutualInformationLoss(cfg)
             rec = [RL.ObservationsLoss()(obs, m) for m in out[1]]
             li, lo = (7, 15) if c["pre"] else (6, 15)       # logits / reconstructed logits in the two tuple layouts
             comp = {
@@ -118,7 +125,8 @@ def main():
             data["loss_total"] = np.array(total.item())
             for k, v in comp.items():
                 data["loss_" + k] = np.array(v.item())
-            data["mi_ema"] = smi.matrix_estimator.estimated_matrix.detach().numpy()
+            if c.get("mi") != "plain":
+                data["mi_ema"] = smi.matrix_estimator.estimated_matrix.detach().numpy()
             names, gsum, gabs, gfirst = [], [], [], []
             for n, p in ref.named_parameters():
                 if p.grad is None:

@@ -27,18 +27,22 @@ PRE_W = {"reconstruction_loss_lambda_pretraining": 1.0, "perceptual_loss_lambda_
 
 
 def main():
+    only = set(sys.argv[1:])
     for perc in (0.0, 1.0):
         for pre in (False, True):
-            one(pre, perc)
+            if not only or "smooth" in only:
+                one(pre, perc)
+    if not only or "plain" in only:
+        one(False, 0.0, plain=True)          # training.trainer (03_tennis.yaml): plain MutualInformationLoss, no estimator state in the checkpoint
 
 
-def one(pretraining, perc=0.0):
+def one(pretraining, perc=0.0, plain=False):
     rh.install()
     cfg = _config(res=(8, 8))          # 64 x 64 frames: the (stub) VGG19 of the reference's perceptual loss needs >= 16 pixels at the quarter resolution
     cfg["model"]["architecture"] = "model.reduced_model.model"
     cfg["model"]["action_network"]["use_variations"] = True
     tr = cfg["training"]
-    tr["trainer"] = "training.smooth_mi_trainer"
+    tr["trainer"] = "training.trainer" if plain else "training.smooth_mi_trainer"
     tr["batching"].update(batch_size=2, num_workers=0)
     tr.update(motion_weights_bias=0.1, use_motion_weights=False, action_mutual_information_entropy_lambda=1.0, action_direction_plotting_freq=10 ** 9,
               max_steps=10 ** 6)
@@ -49,9 +53,9 @@ def one(pretraining, perc=0.0):
     d = O.Dims.from_config(cfg)
     P = O.make_params(d, seed=PARAM_SEED)
     ref = nn.DataParallel(rh.build_reference_model(cfg, P))            # CPU: pass-through, but provides `.module` as the trainer expects
-    import training.smooth_mi_trainer as SM
+    import importlib
     logger = types.SimpleNamespace(print=lambda *a, **k: None, get_wandb=lambda: types.SimpleNamespace(log=lambda *a, **k: None))
-    trainer = SM.SmoothMITrainer(cfg, ref, [0] * 8, logger)
+    trainer = importlib.import_module(tr["trainer"]).trainer(cfg, ref, [0] * 8, logger)          # train.py:54
     trainer.global_step = GLOBAL_STEP
     obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
     acts = torch.zeros(2, 4, dtype=torch.int32)
@@ -73,10 +77,12 @@ def one(pretraining, perc=0.0):
         names.append(n); psum.append(p.detach().double().sum().item()); pabs.append(p.detach().double().abs().sum().item())
         first.append(p.detach().flatten()[:4].tolist() + [0.0] * max(0, 4 - p.numel()))
     data["param_names"], data["param_sum"], data["param_abs"], data["param_first4"] = np.array(names), np.array(psum), np.array(pabs), np.array(first, dtype=np.float32)
-    data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
+    if not plain:
+        data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
+    data["trainer"] = np.array(tr["trainer"])
     data["lr"] = np.array(trainer._get_current_lr())
     data["perceptual_lambda"] = np.array(perc)
-    out = os.path.join(ROOT, "tests", "golden", ("trainer_perc_" if perc else "trainer_") + ("pre_reduced_s1.npz" if pretraining else "reduced_s1.npz"))
+    out = os.path.join(ROOT, "tests", "golden", ("trainer_plain_" if plain else ("trainer_perc_" if perc else "trainer_")) + ("pre_reduced_s1.npz" if pretraining else "reduced_s1.npz"))
     np.savez_compressed(out, **data)
     print("written", out, {k: float(v) for k, v in data.items() if k.startswith("info:")})
 
