@@ -187,6 +187,11 @@ int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);
 /* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last
  *     forward, converted to (N,C,H,W) --- */
 int caddy_debug_count(caddy_ctx* ctx);
+/* BatchNorm fusion bookkeeping since creation: out3 = {train-mode BatchNorm calls, ... whose statistics came from the producing conv's epilogue,
+ * ... whose normalised output was never materialised (applied by the consuming convolution)} */
+int caddy_debug_fusion_counts(caddy_ctx* ctx, long* out3);
+/* tests / A-B: which BatchNorm paths the driver may pick (all default to 1): the one-launch kernel for tiny maps, the lazily applied form, statistics from the conv epilogue */
+int caddy_debug_set_bn_paths(caddy_ctx* ctx, int small, int lazy, int epilogue_stats);
 int caddy_debug_dims(caddy_ctx* ctx, int i, int* nhwc4);
 int caddy_debug_get(caddy_ctx* ctx, int i, int grad, float* dst_nchw);
 
@@ -198,6 +203,14 @@ long caddy_bn_calls(caddy_ctx* ctx, int i, char* name_out128);
 struct ConvArgs; struct WgradArgs; struct PackDesc; struct TV;
 int caddy_k_conv_fwd(const struct ConvArgs* a, void* stream);
 int caddy_k_conv_wgrad(const struct WgradArgs* a, void* stream);
+/* BatchNorm fused with the convolutions around it (reference: the conv -> BatchNorm2d -> LeakyReLU chains of model/layers/residual_block.py:51-68,
+ * same_block.py:34-47, up_block.py:31-45): per-tile partial sums from the producing conv's epilogue (ConvArgs.stats) -> finalisation without a pass over
+ * the tensor; backward of a BatchNorm whose output was never materialised (ConvSrc.bn_scale / bn_shift applied by the consumer while staging) */
+int caddy_k_conv_stats_tiles(void);
+int caddy_k_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream);
+int caddy_k_bn_bwd_lazy(const struct TV* dout, const struct TV* x, const float* mean, const float* invstd, const float* gamma, const float* scale, const float* shift, int act,
+                        double* sums, double* scratch, const struct TV* dx, float* dgamma, float* dbeta, void* stream);
 int caddy_k_conv_pick_bn(int cout);
 /* split 16-bit operand form of a layer's weights for the 16-bit-MFMA convolution (conv_hx.hip): seg < 0 forward, else dgrad of that segment */
 int caddy_k_hx_pick_bn(int cout);

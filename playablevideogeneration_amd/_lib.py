@@ -17,7 +17,8 @@ class TV(C.Structure):
 
 
 class ConvSrc(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("sn", C.c_long), ("ld", C.c_int), ("C", C.c_int), ("Cpad", C.c_int), ("bcast", C.c_int)]
+    _fields_ = [("p", C.c_void_p), ("sn", C.c_long), ("ld", C.c_int), ("C", C.c_int), ("Cpad", C.c_int), ("bcast", C.c_int),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_act", C.c_int), ("bn_gn", C.c_int), ("bn_gs", C.c_long)]      # lazily applied BatchNorm of the producer (common.h)
 
 
 class ConvArgs(C.Structure):
@@ -26,13 +27,15 @@ class ConvArgs(C.Structure):
                 ("out", C.c_void_p), ("out_sn", C.c_long), ("out_ld", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("splitk", C.c_int), ("aux", C.c_void_p), ("split_scratch", C.c_void_p), ("split_cap", C.c_long), ("split_stride", C.c_long),
                 ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float),
                 ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int), ("xcd_map", C.c_int),
-                ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int)]
+                ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int),
+                ("stats", C.c_void_p), ("stats_ld", C.c_int)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
-                ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long), ("precision", C.c_int)]
+                ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long), ("precision", C.c_int),
+                ("src_bn_gs", C.c_long * CONV_MAX_SRC)]
 
 
 class PackDesc(C.Structure):

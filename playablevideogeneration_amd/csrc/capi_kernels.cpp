@@ -7,6 +7,16 @@
 #define ST(s) ((hipStream_t)(s))
 extern "C" {
 int caddy_k_conv_fwd(const ConvArgs* a, void* s) { return conv_fwd_launch(*a, ST(s)); }
+int caddy_k_conv_stats_tiles(void) { return g_last_conv_stats_tiles; }      // pixel tiles whose BatchNorm partial sums the last caddy_k_conv_fwd of this thread wrote (ConvArgs.stats)
+int caddy_k_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
+                              float* mean, float* invstd, float* scale, float* shift, void* s) {
+    return pw_bn_finalize_tiles(part, ntiles, ldp, count, gamma, beta, rmean, rvar, C, mean, invstd, scale, shift, ST(s));
+}
+int caddy_k_bn_bwd_lazy(const TV* dout, const TV* x, const float* mean, const float* invstd, const float* gamma, const float* scale, const float* shift, int act,
+                        double* sums, double* scratch, const TV* dx, float* dgamma, float* dbeta, void* s) {      // backward of a lazily applied BatchNorm (no materialised output)
+    int rc = pw_bn_bwd_reduce(*dout, nullptr, *x, mean, invstd, sums, scratch, dgamma, dbeta, ST(s), act ? scale : nullptr, shift);
+    return rc ? rc : pw_bn_bwd_apply(*dout, nullptr, *x, mean, invstd, gamma, sums, *dx, nullptr, nullptr, 1, ST(s), act ? scale : nullptr, shift);
+}
 int caddy_k_conv_wgrad(const WgradArgs* a, void* s) { return conv_wgrad_launch(*a, ST(s)); }
 int caddy_k_conv_pick_bn(int cout) { return conv_pick_bn(cout); }
 int caddy_k_hx_pick_bn(int cout) { return hx_pick_bn(cout); }

@@ -36,6 +36,16 @@ struct ConvSrc {
     int C;      // logical channels
     int Cpad;   // round_up(C, CONV_BK)
     int bcast;
+    // Lazily applied train-mode BatchNorm (+ LeakyReLU 0.2) of the PRODUCER of this segment: the consumer reads the raw conv output x and sees
+    // act(x * bn_scale[c] + bn_shift[c]) -- the normalised tensor is never written to HBM (reference: conv -> BatchNorm2d -> LeakyReLU chains of
+    // residual_block.py:51-68, same_block.py:34-47, up_block.py:31-45, conv_dynamics_network.py:41-45).  nullptr: plain input.  Zero padding is
+    // applied AFTER the affine map (the reference pads the normalised tensor).  bn_gn > 0: per-sample-group parameters (time-batched calls whose
+    // statistics stay per time step): sample n uses bn_scale + (n / bn_gn) * bn_gs.  Understood by k_conv_hx and k_wgrad_hx only.
+    const float* bn_scale;
+    const float* bn_shift;
+    int bn_act;
+    int bn_gn;
+    long bn_gs;
 };
 
 struct ConvArgs {
@@ -81,6 +91,11 @@ struct ConvArgs {
     long pool_sn;
     int pool_ld;
     int skip_out;
+    // Per-channel partial sums of the values this launch stores (k_conv_hx, EP = 0, splitk == 1 only): workgroup (pixel tile t, channel block) writes
+    // stats[(t * stats_ld + c) * 2 + {0, 1}] = {sum v, sum v^2} over the valid pixels of its tile -- the BatchNorm statistics of the consumer without a
+    // second pass over the conv output.  The launcher reports the number of tiles in g_last_conv_stats_tiles (0: this launch did not produce them).
+    float* stats;
+    int stats_ld;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
@@ -113,12 +128,16 @@ struct WgradArgs {
     long src_gs[CONV_MAX_SRC];
     long dy_gs;
     int precision;      // PREC_BF16X3: 3x3 layers with >= 32 channels on both sides run on the 16-bit matrix pipe (k_wgrad_hx); 0: exact fp32
+    long src_bn_gs[CONV_MAX_SRC];   // time-batched launches: float distance between the (scale, shift) tables of consecutive groups of a lazily normalised source
 };
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
 enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW,
        CK_HX_128, CK_HX_64, CK_HX_32, CK_WGRAD_HX, CK_HX_128_8W, CK_COUNT };      // CK_HX_128_8W: the 16x16x128 tile on 8 waves (VGG19, wide well-filled layers); CK_HX_128: 8x16x128 on 4 waves
 extern thread_local int g_last_conv_kernel;
+extern thread_local int g_last_conv_stats_tiles;      // pixel tiles of the last conv_fwd_launch that wrote ConvArgs.stats (0 = none written)
+bool conv_src_lazy_ok(const ConvArgs& a);             // will conv_fwd_launch run this launch on a kernel that applies ConvSrc.bn_* ?
+bool wgrad_src_lazy_ok(const WgradArgs& a);           // ... conv_wgrad_launch ?
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);

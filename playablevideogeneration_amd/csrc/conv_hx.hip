@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return 
 #define HX_EXPERIMENT 0      // timing experiments only (tools/gpu_hx_experiments.sh): 1 = no weight-tile traffic in the K loop, 2 = no activation staging, 4 = no per-tap barrier
 #endif
 constexpr int KC = HX_KC;      // channels per chunk
-struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; };
+struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; const float* bn_scale; const float* bn_shift; int bn_act; int bn_gn; long bn_gs; };
 template <typename T> struct is_bf16 { static constexpr bool value = false; };
 template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         const int m = (int)gridDim.x - grp * 8 < 8 ? (int)gridDim.x - grp * 8 : 8;      // tiles in this group (the last one may be short)
         tile = grp * 8 + r % m; nblk = r / m;
     }
+    const int tile_lin = tile;                                // (sample, tile row, tile column) in launch-independent order: index of this tile's BatchNorm partial sums
     const int n = tile / (tiles_x * tiles_y);
     tile -= n * tiles_x * tiles_y;
     const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
     float4 ra[NA];
+    float4 rsc, rsh;                                          // lazily applied BatchNorm of the producer (ConvSrc.bn_*): scale / shift of this thread's four channels, chunk in flight
 #define HX_SEG_OF(chunk_)                                                                                                          \
         int s_ = 0, c0_ = (chunk_) * KC;                                                                                          \
         while (s_ + 1 < a.nsrc && c0_ >= (a.src[s_].C + KC - 1) / KC * KC) { c0_ -= (a.src[s_].C + KC - 1) / KC * KC; s_++; }     \
@@ -121,17 +123,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         const int pl_ = sg_.bcast ? 0 : sg_.ld;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < NA; i++)                                                                            \
             ra[i] = *reinterpret_cast<const float4*>(base_ + (long)((cok_ && pixoff[i] >= 0) ? pixoff[i] : 0) * pl_);             \
+        /* (unconditional, clamped to a valid address when the segment carries no BatchNorm: no branch around loads) */           \
+        const long bo_ = (sg_.bn_gn > 0 ? (long)(n / sg_.bn_gn) * sg_.bn_gs : 0L) + (cok_ ? c_ : 0);                              \
+        rsc = *reinterpret_cast<const float4*>(sg_.bn_scale ? sg_.bn_scale + bo_ : sg_.p);                                        \
+        rsh = *reinterpret_cast<const float4*>(sg_.bn_scale ? sg_.bn_shift + bo_ : sg_.p);                                        \
     } while (0)
 #define HX_STORE_A(chunk_)                                                                                                         \
     do {                                                                                                                           \
         HX_SEG_OF(chunk_)                                                                                                          \
         const bool m1_ = c_ + 1 < sg_.C, m2_ = c_ + 2 < sg_.C, m3_ = c_ + 3 < sg_.C;                                              \
+        const bool bn_ = sg_.bn_scale != nullptr;               /* wave-uniform */                                                \
+        const float sl_ = sg_.bn_act ? 0.2f : 1.f;                                                                                \
         _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                                          \
             const int p_ = (tid >> 3) + APP * i;                                                                                  \
             if (HPX % APP == 0 || p_ < HPX) {                                                                                      \
                 const bool ok_ = cok_ && pixoff[i] >= 0;                                                                           \
-                const float x0_ = ok_ ? ra[i].x : 0.f, x1_ = (ok_ && m1_) ? ra[i].y : 0.f;                                         \
-                const float x2_ = (ok_ && m2_) ? ra[i].z : 0.f, x3_ = (ok_ && m3_) ? ra[i].w : 0.f;                                \
+                float4 v_ = ra[i];                                                                                                 \
+                if (bn_) {      /* act(x * scale + shift); the zero padding below applies to the NORMALISED tensor */             \
+                    v_.x = fmaf(v_.x, rsc.x, rsh.x); v_.y = fmaf(v_.y, rsc.y, rsh.y); v_.z = fmaf(v_.z, rsc.z, rsh.z); v_.w = fmaf(v_.w, rsc.w, rsh.w); \
+                    v_.x = v_.x > 0.f ? v_.x : sl_ * v_.x; v_.y = v_.y > 0.f ? v_.y : sl_ * v_.y;                                  \
+                    v_.z = v_.z > 0.f ? v_.z : sl_ * v_.z; v_.w = v_.w > 0.f ? v_.w : sl_ * v_.w;                                  \
+                }                                                                                                                  \
+                const float x0_ = ok_ ? v_.x : 0.f, x1_ = (ok_ && m1_) ? v_.y : 0.f;                                               \
+                const float x2_ = (ok_ && m2_) ? v_.z : 0.f, x3_ = (ok_ && m3_) ? v_.w : 0.f;                                      \
                 v4 hi_, lo_;                                                                                                       \
                 hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
                 lo_[0] = (T)(x0_ - (float)hi_[0]); lo_[1] = (T)(x1_ - (float)hi_[1]);                                             \
@@ -248,6 +262,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     }
 
     // ---- epilogue: D fragment map col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile) ----
+    float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
+#pragma unroll
+    for (int j = 0; j < TNt; j++) { st1[j] = 0.f; st2[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TNt; j++) {
         const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     v = mk > 0.f ? v : 0.f;
                 }
                 if (a.accumulate) v += a.out[off];
+                if (EP == 0) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
                 if (!E_POOL || !a.skip_out) a.out[off] = v;
                 if (E_POOL) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
             }
@@ -288,6 +306,37 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
                     a.pool_out[(long)n * a.pool_sn + ((long)py * (a.W >> 1) + px) * a.pool_ld + col] = mx;
                 }
+            }
+        }
+    }
+    // ---- BatchNorm partial sums of this tile: the two 32-lane halves of a wave hold different pixel rows of one channel, the WM waves of a column
+    // block different rows too -> shuffle, then LDS (the staging tiles are dead), one plain store per (tile, channel): no atomics, fixed order ----
+    if (EP == 0 && a.stats != nullptr) {                      // (grid-uniform; the launcher only passes it with splitk == 1)
+#pragma unroll
+        for (int j = 0; j < TNt; j++) { st1[j] += __shfl_xor(st1[j], 32); st2[j] += __shfl_xor(st2[j], 32); }
+        float* red = reinterpret_cast<float*>(As);            // WM x BN x 2 floats <= 4 KB
+        if (WM > 1) {
+            __syncthreads();                                   // every wave is done with As / Bs
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < TNt; j++) {
+                    const int cl = wn * (BN / WN) + j * 32 + lane;
+                    red[(wm * BN + cl) * 2] = st1[j]; red[(wm * BN + cl) * 2 + 1] = st2[j];
+                }
+            }
+            __syncthreads();
+        }
+        if (wm == 0 && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < TNt; j++) {
+                const int cl = wn * (BN / WN) + j * 32 + lane, col = n0 + cl;
+                float s1 = st1[j], s2 = st2[j];
+                if (WM > 1) {
+                    s1 = red[cl * 2]; s2 = red[cl * 2 + 1];
+#pragma unroll
+                    for (int w = 1; w < WM; w++) { s1 += red[(w * BN + cl) * 2]; s2 += red[(w * BN + cl) * 2 + 1]; }
+                }
+                if (col < a.Cout) { float* o = a.stats + ((long)tile_lin * a.stats_ld + col) * 2; o[0] = s1; o[1] = s2; }
             }
         }
     }
@@ -325,6 +374,7 @@ __device__ __forceinline__ SegRefH find_seg16(const ConvSrc* src, int nsrc, int 
     int s = 0;
     while (s + 1 < nsrc && k >= src[s].Cpad) { k -= src[s].Cpad; s++; }
     SegRefH r; r.p = src[s].p; r.sn = src[s].sn; r.ld = src[s].ld; r.C = src[s].C; r.bcast = src[s].bcast; r.c0 = k; r.idx = s;
+    r.bn_scale = src[s].bn_scale; r.bn_shift = src[s].bn_shift; r.bn_act = src[s].bn_act; r.bn_gn = src[s].bn_gn; r.bn_gs = src[s].bn_gs;
     return r;
 }
 
@@ -337,8 +387,10 @@ __device__ __forceinline__ typename Vec<T>::v8 tr_frag(const T* base, int off0, 
     return u.v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int tiles_y) {
+// OCC: workgroups per CU the register allocation is bounded for (2: 256 registers per lane -- 144 accumulators + everything else, ~2 spilled -- so that the
+// LDS-store / barrier phase of one workgroup runs under the MFMA phase of the other; 1: the unconstrained allocation, one workgroup per CU)
+template <typename T, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     __shared__ __attribute__((aligned(16))) T Xh[WG_HH * WG_HW * WG_PITCH];
@@ -356,6 +408,9 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
     const int cx = sg.c0 + (q & 3) * 4;                       // channel inside the segment
     const int yc = o0 + q * 4;
     float4 rx[WG_XLOADS], ry[WG_YLOADS];
+    float4 rxs, rxh;                                          // lazily applied BatchNorm of the X source (ConvSrc.bn_*): scale / shift of this thread's four channels, tile in flight
+    const bool xbn = sg.bn_scale != nullptr;
+    const float xsl = sg.bn_act ? 0.2f : 1.f;
 
 #define WG_GEOM(tile_)                                                                                                              \
         int n_ = (int)((tile_) / (tiles_x * tiles_y));                                                                             \
@@ -371,7 +426,11 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
         WG_GEOM(tile_)                                                                                                              \
         const float* xp_ = sg.p;                                                                                                   \
         const float* dyb_ = a.dy;                                                                                                  \
-        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * a.src_gs[sg.idx]; dyb_ += grp_ * a.dy_gs; } \
+        long bo_ = cok_ ? cx : 0;                                                                                                  \
+        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * a.src_gs[sg.idx]; dyb_ += grp_ * a.dy_gs; bo_ += grp_ * a.src_bn_gs[sg.idx]; } \
+        if (sg.bn_gn > 0) bo_ += (long)(n_ / sg.bn_gn) * sg.bn_gs;                                                                 \
+        rxs = *reinterpret_cast<const float4*>(xbn ? sg.bn_scale + bo_ : sg.p);      /* (clamped to a valid address without BatchNorm) */ \
+        rxh = *reinterpret_cast<const float4*>(xbn ? sg.bn_shift + bo_ : sg.p);                                                    \
         const float* xb_ = xp_ + (long)n_ * sg.sn + (cok_ ? cx : 0);                                                               \
         const int pl_ = sg.bcast ? 0 : sg.ld;                                                                                      \
         _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
@@ -408,6 +467,11 @@ __global__ __launch_bounds__(256) void k_wgrad_hx(WgradArgs a, int tiles_x, int 
             const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
             const bool ok_ = cok_ && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                                   \
             float4 v_ = rx[i];                                                                                                     \
+            if (xbn) {      /* act(x * scale + shift): what the forward conv consumed; zero padding applies to the normalised tensor */ \
+                v_.x = fmaf(v_.x, rxs.x, rxh.x); v_.y = fmaf(v_.y, rxs.y, rxh.y); v_.z = fmaf(v_.z, rxs.z, rxh.z); v_.w = fmaf(v_.w, rxs.w, rxh.w); \
+                v_.x = v_.x > 0.f ? v_.x : xsl * v_.x; v_.y = v_.y > 0.f ? v_.y : xsl * v_.y;                                      \
+                v_.z = v_.z > 0.f ? v_.z : xsl * v_.z; v_.w = v_.w > 0.f ? v_.w : xsl * v_.w;                                      \
+            }                                                                                                                      \
             v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && cx + 1 < sg.C) ? v_.y : 0.f;                                                   \
             v_.z = (ok_ && cx + 2 < sg.C) ? v_.z : 0.f; v_.w = (ok_ && cx + 3 < sg.C) ? v_.w : 0.f;                                \
             if (pix_ < WG_HH * WG_HW) WG_SPLIT_STORE(&Xh[pix_ * WG_PITCH + 4 * q], v_);                                           \
@@ -554,6 +618,14 @@ bool conv_hx_pool_ok(int N, int H, int W, int Cout) {
     return false;
 }
 
+// will conv_fwd_launch hand this launch to k_conv_hx (the only forward kernel that applies ConvSrc.bn_* while staging its input)?
+bool conv_src_lazy_ok(const ConvArgs& a) {
+    if (a.KS != 3 || !a.wq || a.precision < PREC_F16X3 || a.precision > PREC_BF16X1 || a.act == 1) return false;
+    for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return false;
+    return true;
+}
+thread_local int g_last_conv_stats_tiles = 0;
+
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
@@ -599,6 +671,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     }
     static const int env_xcd = getenv("CADDY_HX_XCD") ? atoi(getenv("CADDY_HX_XCD")) : 1;      // A/B aid
     a.xcd_map = env_xcd;
+    // BatchNorm partial sums from the epilogue: EP = 0 instances with the whole K range in one workgroup only (split launches: the caller falls back to its own reduction)
+    if (a.stats && (a.splitk != 1 || a.mask || a.pool_out || a.skip_out || a.precision == PREC_F16X1 || a.precision == PREC_BF16X1)) a.stats = nullptr;
+    g_last_conv_stats_tiles = a.stats ? (int)((long)a.N * tx * ty) : 0;
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
     // launches of at most one workgroup per CU (batch-1 roll-out, R's side branches): every workgroup is a serial chain of (tap, chunk) steps whose
     // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame
@@ -650,20 +725,30 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
 
 // 1 = handled: 3x3 weight gradient with >= 32 channels on both sides on the 16-bit matrix pipe (split bf16 operands).  Same packed fp32
 // gradient layout (dwp[tap][Cout_pad][Ktot], segments padded to 16) and (group, sample) time-batched addressing as k_conv_wgrad_tile.
-int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
+static bool wgrad_hx_applies(const WgradArgs& a) {
     static const bool off = getenv("CADDY_WGRAD_HX") && atoi(getenv("CADDY_WGRAD_HX")) == 0;      // A/B aid
-    if (off || a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return 0;
-    for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0;
-    if ((a.dy_ld & 3) || (a.dy_sn & 3)) return 0;
+    if (off || a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return false;
+    for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return false;
+    if ((a.dy_ld & 3) || (a.dy_sn & 3)) return false;
+    return true;
+}
+bool wgrad_src_lazy_ok(const WgradArgs& a) { return wgrad_hx_applies(a); }      // k_wgrad_hx is the only weight-gradient kernel that applies ConvSrc.bn_*
+int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
+    if (!wgrad_hx_applies(a)) return 0;
     g_last_conv_kernel = CK_WGRAD_HX;
     if (dry) return 1;
     const int tx = cdiv(a.W, WG_TW), ty = cdiv(a.H, WG_TH);
     const long ntiles = (long)a.N * tx * ty;
     const int kt = cdiv(a.Ktot, WG_KC), ot = cdiv(a.Cout, WG_OC);
-    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;      // persistent workgroups: one per CU (measured in the step: 128 / 192 / 256 / 384 / 512 -> 169.1 / 166.7 / 167.7 / 169.0 / 170.8 ms -- the side stream should not crowd the dgrad chain)
+    // Register bound 2 (256 per lane) with still ONE persistent workgroup per CU: the side stream's workgroup then leaves half of every SIMD's register file
+    // to the BPTT chain on the main stream, which shares the CU with it (measured, E/R/A/D step: unbounded 89.0 ms; bound 2 with 256 / 384 / 512 workgroups
+    // 85.6 / 87.2 / 89.6 ms; serialised streams 94.5 -> 91.6 ms)
+    static const int occ = getenv("CADDY_WGRAD_OCC") ? atoi(getenv("CADDY_WGRAD_OCC")) : 2;      // A/B aid
+    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;
     long g = blocks / ((long)kt * ot);
     if (g < 1) g = 1;
     if (g > ntiles) g = ntiles;
-    hipLaunchKernelGGL((k_wgrad_hx<__bf16>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
+    if (occ == 2) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 1>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
     return 1;
 }

@@ -704,7 +704,9 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int bn = conv_pick_bn(a.Cout);
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     a.splitk = 1;
+    g_last_conv_stats_tiles = 0;
     { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
+    for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs are understood by k_conv_hx only: the caller must have materialised them
     if (a.pool_out || a.skip_out) return -1;      // fused max-pool / write-less epilogues exist in k_conv_hx only: the caller must not ask the other kernels for them
     const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
     if (a.seed_ref && !a.mask) return -1;
@@ -803,6 +805,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     if (a.group_n > 0 && a.N <= a.group_n) a.group_n = 0;
     if (conv_hx_wgrad_try(a, st, dry) == 1) return 0;       // wide 3x3 layers: split bf16 on the 16-bit matrix pipe (conv_hx.hip)
+    for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs: k_wgrad_hx only
     if (conv_c4_wgrad_try(a, st, dry) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
     if (conv_thin_wgrad_try(a, st, dry) == 1) return 0;
     if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)

@@ -286,7 +286,7 @@ static inline T4 chan(const T4& t, int c0, int C) { T4 r = t; r.d += c0; r.g += 
 static void fill_srcs(ConvSrc* dst, const Seg* segs, int nseg) {
     for (int s = 0; s < nseg; s++) {
         const T4& t = segs[s].t;
-        dst[s] = ConvSrc{t.d, t.sn, t.ld, t.C, round_up(t.C, CONV_BK), segs[s].bcast};
+        dst[s] = ConvSrc{t.d, t.sn, t.ld, t.C, round_up(t.C, CONV_BK), segs[s].bcast, t.bn_scale, t.bn_shift, t.bn_act, 0, 0};
     }
 }
 
@@ -328,7 +328,7 @@ void caddy_ctx::flush_wgrad(PendingW& p) {
     WgradArgs w = p.first;
     if (p.count > 1) {
         w.group_n = p.first.N; w.N = p.first.N * p.count;
-        for (int s = 0; s < w.nsrc; s++) w.src_gs[s] = p.src_gs[s];
+        for (int s = 0; s < w.nsrc; s++) { w.src_gs[s] = p.src_gs[s]; w.src_bn_gs[s] = p.bn_gs[s]; }
         w.dy_gs = p.dy_gs;
     }
     double fl = p.flops;
@@ -347,22 +347,28 @@ void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
     if (p->count > 0) {
         const WgradArgs& f = p->first;
         bool ok = f.N == w.N && f.H == w.H && f.W == w.W && f.nsrc == w.nsrc && f.dy_sn == w.dy_sn && f.dy_ld == w.dy_ld && f.dwp == w.dwp;
-        long ds[CONV_MAX_SRC] = {0, 0, 0};
+        long ds[CONV_MAX_SRC] = {0, 0, 0}, db[CONV_MAX_SRC] = {0, 0, 0};
         for (int s = 0; ok && s < w.nsrc; s++) {
             ok = f.src[s].sn == w.src[s].sn && f.src[s].ld == w.src[s].ld && f.src[s].C == w.src[s].C && f.src[s].bcast == w.src[s].bcast;
             ds[s] = w.src[s].p - p->last_src[s];
+            // lazily normalised source: every time step has its own (scale, shift) table -- same form, constant distance
+            ok = ok && (f.src[s].bn_scale != nullptr) == (w.src[s].bn_scale != nullptr) && f.src[s].bn_act == w.src[s].bn_act;
+            if (ok && w.src[s].bn_scale) {
+                db[s] = w.src[s].bn_scale - p->last_bn[s];
+                ok = (w.src[s].bn_shift - w.src[s].bn_scale) == (f.src[s].bn_shift - f.src[s].bn_scale) && (db[s] & 3) == 0;
+            }
         }
         long dd = w.dy - p->last_dy;
         if (ok && p->count > 1) {                 // the stride between consecutive time steps must stay the same
-            for (int s = 0; s < w.nsrc; s++) ok = ok && ds[s] == p->src_gs[s];
+            for (int s = 0; s < w.nsrc; s++) ok = ok && ds[s] == p->src_gs[s] && db[s] == p->bn_gs[s];
             ok = ok && dd == p->dy_gs;
         }
         if (!ok) flush_wgrad(*p);
-        else if (p->count == 1) { for (int s = 0; s < w.nsrc; s++) p->src_gs[s] = ds[s]; p->dy_gs = dd; }
+        else if (p->count == 1) { for (int s = 0; s < w.nsrc; s++) { p->src_gs[s] = ds[s]; p->bn_gs[s] = db[s]; } p->dy_gs = dd; }
     }
     if (p->count == 0) p->first = w;
     p->count++; p->flops += flops;
-    for (int s = 0; s < w.nsrc; s++) p->last_src[s] = w.src[s].p;
+    for (int s = 0; s < w.nsrc; s++) { p->last_src[s] = w.src[s].p; p->last_bn[s] = w.src[s].bn_scale; }
     p->last_dy = w.dy;
     if (p->count >= chunk) flush_wgrad(*p);
 }
@@ -391,8 +397,22 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; }
+    for (int s = 0; s < nseg; s++)
+        if (segs[s].t.bn_scale && !conv_src_lazy_ok(a)) { fail = true; set_error("internal: lazily normalised input handed to a convolution that cannot apply it"); }
+    TileStats* ts_slot = nullptr;
+    if (want_stats) {      // per-tile BatchNorm partial sums from the epilogue; sized for the smallest tile (8 x 16 pixels) whatever the launcher picks (dry-run safe)
+        want_stats = false;
+        if (epi_stats && training && !into && a.wq) {
+            const int ldp = round_up(L.pd.Cout, 4);
+            float* part = falloc((size_t)N * cdiv(H, 8) * cdiv(W, 16) * ldp * 2);
+            a.stats = part; a.stats_ld = ldp;
+            ts_slot = &stats_ring[stats_next]; stats_next ^= 1;
+            *ts_slot = TileStats{out.d, part, 0, ldp};
+        }
+    }
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
+    if (ts_slot && !dry) ts_slot->tiles = g_last_conv_stats_tiles;
     if (recording) {
         T4 dz{}; if (actf == 1) dz = alloc(N, H, W, L.pd.Cout);
         Seg sg[CONV_MAX_SRC]; T4 tmp[CONV_MAX_SRC];
@@ -472,7 +492,12 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     BNStash s = bn_stash(c, bn);
     bool dry = c->dry;
     if (c->training) {
-        if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, bn.rmean, bn.rvar, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
+        const caddy_ctx::TileStats* ts = dry ? nullptr : c->find_stats(x.d);
+        if (!dry) c->n_bn_calls++;
+        if (ts) c->n_bn_tile_stats++;
+        if (ts)      // the producing convolution left per-tile partial sums behind: no pass over x
+            c->ck(pw_bn_finalize_tiles(ts->part, ts->tiles, ts->ldp, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize_tiles");
+        else if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, bn.rmean, bn.rvar, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
         if (!dry) bn.calls++;
         bn.eval_valid = false;
         return s;
@@ -486,10 +511,38 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     }
     return s;
 }
-T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into, bool nz_out, bool nz2_out) {
+// can `consumer` (a 3x3 convolution reading x's normalised form as one of its segments, same H x W) apply the BatchNorm while staging -- forward AND weight gradient?
+bool caddy_ctx::lazy_ok(const ConvL& consumer, const T4& x) const {
+    if (!lazy_bn || !consumer.wq || prec_fwd == PREC_FP32 || consumer.pd.KS != 3) return false;
+    if (recording) {      // its weight gradient must run on k_wgrad_hx (conv_hx_wgrad_try's conditions)
+        static const bool wg_off = getenv("CADDY_WGRAD_HX") && atoi(getenv("CADDY_WGRAD_HX")) == 0;
+        if (wg_off || prec_bwd == PREC_FP32 || consumer.pd.Cout < 32 || consumer.pd.Ktot < 32 || x.W < 8 || x.H < 2) return false;
+    }
+    return (x.ld & 3) == 0 && (x.sn & 3) == 0;
+}
+
+T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, const T4* into, bool nz_out, bool nz2_out, const ConvL* lazy_for) {
+    const bool small = training && !bn2 && bn_small && pw_bn_small_pays(dv(x));      // one-launch path for R's small maps
+    // lazily applied form: statistics + finalisation only; the single consumer (a k_conv_hx / k_wgrad_hx convolution) forms act(x * scale + shift) while
+    // staging its input and the backward takes the LeakyReLU slope from the same expression -- the normalised tensor never exists in HBM
+    if (lazy_for && !x2 && !into && !small && !fold && x.ld == round_up(x.C, 4) && x.sn == (long)x.H * x.W * x.ld && lazy_ok(*lazy_for, x)) {
+        BNStash s1 = bn_forward(this, x, bn);
+        if (!dry) n_bn_lazy++;
+        T4 ag = alloc_nz(x.N, x.H, x.W, x.C);      // only its gradient half is used: d(loss) / d(normalised value), assigned by the consumer's dgrad
+        T4 out = x;
+        out.g = ag.g; out.nz = true; out.nz2 = false;
+        out.bn_scale = s1.scale; out.bn_shift = s1.shift; out.bn_act = actf ? 1 : 0;
+        if (recording) {
+            BNL* b1 = &bn;
+            tape.push_back([=]() {
+                const float* ls = actf ? s1.scale : nullptr;
+                RUN(pw_bn_bwd_reduce(gv(out), nullptr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream, ls, s1.shift));
+                RUN(pw_bn_bwd_apply(gv(out), nullptr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream, ls, s1.shift));
+            });
+        }
+        return out;
+    }
     T4 out = into ? *into : ((nz_out || nz2_out) ? alloc_nz(x.N, x.H, x.W, x.C, nz2_out) : alloc(x.N, x.H, x.W, x.C));
-    static const bool no_small = getenv("CADDY_BN_SMALL") && atoi(getenv("CADDY_BN_SMALL")) == 0;      // A/B aid
-    const bool small = training && !bn2 && !no_small && pw_bn_small_pays(dv(x));      // one-launch path for R's small maps
     TV x2v{}; if (x2) x2v = dv(*x2);
     BNStash s1{}, s2{};
     if (small) {
@@ -538,12 +591,15 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into, bool nz2_out) {
         if (R.ds == 2) idn = pool2(idn);
         return conv(R.conv2, &sa, 1, 3, into, false, &idn);
     }
+    want_stats = R.ds == 1;                                   // (a pooled map's statistics are not the conv output's)
     T4 c1 = conv(R.conv1, &sx, 1, 0, nullptr, true);        // conv -> (pool) -> BatchNorm: single assigning gradient writer
     if (R.ds == 2) c1 = pool2(c1);
-    T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr, true);      // consumed by conv2 only
+    T4 a1 = bn_act(c1, R.bn1, nullptr, nullptr, true, nullptr, true, false, &R.conv2);      // consumed by conv2 only: never materialised when conv2 runs on k_conv_hx
     Seg sa{a1, 0, true};
+    want_stats = true;
     T4 c2 = conv(R.conv2, &sa, 1, 0, nullptr, true);
     if (R.has_down) {
+        want_stats = R.ds == 1;
         T4 idn = conv(R.down, &sx, 1, 0, nullptr, true);
         if (R.ds == 2) idn = pool2(idn);
         return bn_act(c2, R.bn2, &idn, &R.bnd, true, into, false, nz2_out);
@@ -569,7 +625,7 @@ void caddy_ctx::copy_op(const T4& src, const T4& dst) {
 }
 
 // ConvLSTM step (convolutional_lstm.py:50-74, convolutional_lstm_cell.py:88-101) followed by its BatchNorm
-T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
+T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     LstmL& L = lstm[i];
     const int B = x.N;
     bool persistent = !training && !recording && L.h.d == L.ph.d && L.h.d != nullptr;
@@ -601,24 +657,26 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux) {
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
     if (recording) tape.push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
-    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true);      // feeds exactly one conv (as its first segment)
+    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
 }
 
 // ConvDynamicsNetwork.forward (model/main_model/conv_dynamics_network.py:111-133)
 T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
-    T4 x = lstm_step(0, state, aux);
+    T4 x = lstm_step(0, state, aux, &r_c0);
     Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
     x = conv(r_c0, s0, 2, 0, nullptr, true);
     x = pool2(x, fold);
-    if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr, true);      // -> ConvLSTM 1 gates conv only
-    x = lstm_step(1, x, aux);
+    if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr, true, false, &lstm[1].gates);      // -> ConvLSTM 1 gates conv only
+    x = lstm_step(1, x, aux, &r_c1);
     Seg s1[2] = {{x, 0, true}, {aux, 1, true}};
+    want_stats = !fold;
     x = conv(r_c1, s1, 2, fold ? 3 : 0, nullptr, true);
     if (!fold) x = bn_act(x, r_bn1, nullptr, nullptr, true, nullptr, false, true);      // -> bilinear x2 only: its backward assigns
     x = up2(x);
-    x = lstm_step(2, x, aux);
+    x = lstm_step(2, x, aux, &r_c2);
     Seg s2[2] = {{x, 0, true}, {aux, 1, true}};
     if (fold) return conv(r_c2, s2, 2, 3, into);
+    want_stats = true;
     x = conv(r_c2, s2, 2, 0, nullptr, true);
     return bn_act(x, r_bn2, nullptr, nullptr, true, into);
 }
@@ -630,6 +688,7 @@ void caddy_ctx::render(const T4& hdn, int slot, int nslots) {
     for (int i = 0; i < 3; i++) {
         T4 u = up2(x);
         Seg su{u, 0, true};
+        want_stats = !fold;
         T4 c = conv(d_up[i], &su, 1, fold ? 3 : 0, nullptr, true);
         x = fold ? c : bn_act(c, d_norm[i], nullptr, nullptr, true, nullptr, i == 2, i < 2);      // last stage -> 7x7 FinalBlock only; others -> residual block (identity add + conv)
         if (i < 2) x = resblock(d_res[i], x, nullptr, true);      // -> next stage's up-sampling (assigns) + this stage's FinalBlock conv (accumulates)
@@ -738,7 +797,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);      // a forward without a backward in between: the side stream may still read the old observations
-    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0;
+    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -800,7 +859,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);
-    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0;
+    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -949,7 +1008,7 @@ static void rollout_body(caddy_ctx* c) {
     const caddy_config& g = c->cfg;
     const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
-    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false;
+    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->fold = c->packed_fold; c->rollout = true;
     T4 o = c->alloc(1, H, W, 3 * S);
     if (!dry) c->ck(pw_nchw_to_nhwc(c->inf_obs, 0, dv(o), c->stream), "obs layout");
@@ -1158,6 +1217,9 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
+    if (const char* e = getenv("CADDY_BN_SMALL")) c->bn_small = atoi(e) != 0;           // A/B aid: 0 = no one-launch BatchNorm for tiny maps
+    if (const char* e = getenv("CADDY_BN_LAZY")) c->lazy_bn = atoi(e) != 0;             // A/B aid: 0 = every BatchNorm output is materialised
+    if (const char* e = getenv("CADDY_BN_EPI_STATS")) c->epi_stats = atoi(e) != 0;      // A/B aid: 0 = BatchNorm statistics by a separate pass over the conv output
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
         else if (!strcmp(e, "fwd")) { c->prec_bwd = PREC_FP32; c->vgg_precision_bwd = PREC_FP32; }
@@ -1171,6 +1233,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
+int caddy_debug_set_bn_paths(caddy_ctx* c, int small, int lazy, int epilogue_stats) { c->bn_small = small != 0; c->lazy_bn = lazy != 0; c->epi_stats = epilogue_stats != 0; return 0; }
 int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }
 int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
@@ -1255,6 +1318,7 @@ int caddy_profile_end(caddy_ctx* c, double* out18) {   // CK_COUNT kernel famili
     c->prof = false; c->prof_recs.clear();
     return 0;
 }
+int caddy_debug_fusion_counts(caddy_ctx* c, long* out3) { out3[0] = c->n_bn_calls; out3[1] = c->n_bn_tile_stats; out3[2] = c->n_bn_lazy; return 0; }
 int caddy_debug_count(caddy_ctx* c) { return (int)c->dbg.size(); }
 int caddy_debug_dims(caddy_ctx* c, int i, int* nhwc4) {
     if (i < 0 || i >= (int)c->dbg.size()) return -1;

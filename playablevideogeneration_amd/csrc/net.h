@@ -17,6 +17,9 @@ struct T4 {            // activation + gradient views with identical geometry
     bool nz = false;   // gradient lives in the NOT-zero-filled part of the arena: its single backward writer assigns (see Arena::alloc_top)
     bool nz2 = false;  // ... with TWO backward writers: a point-wise one that runs first in the reverse replay (residual add, bilinear up-sampling) and
                        // assigns, and a convolution dgrad that runs later and accumulates
+    // lazily normalised tensor: `d` holds the RAW conv output x, the logical value is act(x * bn_scale[c] + bn_shift[c]) and is only ever formed inside the
+    // consuming convolution's staging (ConvSrc.bn_*); `g` is the gradient w.r.t. the logical (normalised) value
+    const float* bn_scale = nullptr; const float* bn_shift = nullptr; int bn_act = 0;
 };
 static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
 static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
@@ -156,7 +159,8 @@ struct caddy_ctx {
     void ensure_side();
     // weight gradients of a layer are queued over consecutive BPTT time steps and launched as ONE time-batched kernel (WgradArgs.group_n)
     struct PendingW { WgradArgs first{}; int count = 0; long src_gs[CONV_MAX_SRC] = {0, 0, 0}; long dy_gs = 0; double flops = 0;
-                      const float* last_src[CONV_MAX_SRC] = {nullptr, nullptr, nullptr}; const float* last_dy = nullptr; };
+                      const float* last_src[CONV_MAX_SRC] = {nullptr, nullptr, nullptr}; const float* last_dy = nullptr;
+                      long bn_gs[CONV_MAX_SRC] = {0, 0, 0}; const float* last_bn[CONV_MAX_SRC] = {nullptr, nullptr, nullptr}; };      // (scale, shift) tables of lazily normalised sources: one per time step
     std::vector<std::pair<ConvL*, PendingW>> pending;
     void queue_wgrad(ConvL* L, const WgradArgs& w, double flops);
     void flush_wgrad(PendingW& p);
@@ -168,12 +172,23 @@ struct caddy_ctx {
     float* falloc(size_t n);
     double* dalloc(size_t n);
     T4 conv(ConvL& L, const Seg* segs, int nseg, int act, const T4* into, bool nz_out = false, const T4* res = nullptr);
+    // BatchNorm fusion (train mode).  (1) `want_stats`: set before conv() when a BatchNorm consumes the output directly: the conv epilogue leaves per-tile partial
+    // sums behind (ConvArgs.stats) and bn_forward() finalises from them instead of re-reading the tensor.  (2) bn_act(..., lazy_for): the single consumer is a
+    // convolution that applies scale / shift / LeakyReLU while staging its input, so the normalised tensor is never written (T4::bn_*).
+    bool want_stats = false;
+    struct TileStats { const float* x = nullptr; float* part = nullptr; int tiles = 0, ldp = 0; };
+    TileStats stats_ring[2]; int stats_next = 0;      // the two most recent producers (a residual block's conv2 and its 1x1 down-sampling conv feed one bn_act call)
+    const TileStats* find_stats(const float* x) const { for (const TileStats& t : stats_ring) if (t.x == x && t.tiles > 0) return &t; return nullptr; }
+    bool lazy_bn = true, epi_stats = true, bn_small = true;      // A/B switches (CADDY_BN_LAZY=0, CADDY_BN_EPI_STATS=0, CADDY_BN_SMALL=0; tests: caddy_debug_set_bn_paths)
+    long n_bn_lazy = 0, n_bn_tile_stats = 0, n_bn_calls = 0;      // since creation: BatchNorm calls applied lazily / finalised from conv-epilogue partial sums / all train-mode calls (caddy_debug_fusion_counts)
+    bool lazy_ok(const ConvL& consumer, const T4& x) const;
     T4 pool2(const T4& x, bool act = false);
     T4 up2(const T4& x);
-    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false, bool nz2_out = false);   // nz_out: the output feeds exactly one conv; nz2_out: T4::nz2
+    T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false, bool nz2_out = false,
+              const ConvL* lazy_for = nullptr);   // nz_out: the output feeds exactly one conv; nz2_out: T4::nz2; lazy_for: that one conv (same H, W) -- candidate for the lazily applied form
     T4 resblock(ResL& R, const T4& x, const T4* into, bool nz2_out = false);
     T4 encode(const T4& obs_in, bool input_grad, const T4* into);
-    T4 lstm_step(int i, const T4& x, const T4& aux);
+    T4 lstm_step(int i, const T4& x, const T4& aux, const ConvL* next = nullptr);      // next: the convolution that consumes the cell's BatchNorm output
     T4 dynamics(const T4& state, const T4& aux, const T4* into);
     void render(const T4& hdn, int slot, int nslots);
     void action_net(const T4& x65, HeadState& hs_, const float* eps_s, const float* eps_d, const float* unif, bool first,

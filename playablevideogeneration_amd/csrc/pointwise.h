@@ -21,9 +21,15 @@ int pw_bn_small_fwd(const TV& x, const float* gamma, const float* beta, float* r
 int pw_bn_small_bwd(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const TV& dx,
                     float* dgamma, float* dbeta, const TV* dres, int assign, hipStream_t st, int res_assign = 0)      /* res_assign: dres = ... (first writer of a T4::nz2 gradient) */;
 int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x2, const float* scale2, const float* shift2, int act, const TV& out, hipStream_t st);
-int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st);
+// lazy_scale / lazy_shift: the BatchNorm output was never materialised (ConvSrc.bn_*): the LeakyReLU slope comes from x * scale + shift instead of `outm`
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st,
+                     const float* lazy_scale = nullptr, const float* lazy_shift = nullptr);
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                    const TV& dx, float* dgamma, float* dbeta, int assign /* dx = ... instead of += : dx has no other writer */, hipStream_t st);
+                    const TV& dx, float* dgamma, float* dbeta, int assign /* dx = ... instead of += : dx has no other writer */, hipStream_t st,
+                    const float* lazy_scale = nullptr, const float* lazy_shift = nullptr);
+// train-mode statistics from the per-tile partial sums of the producing convolution's epilogue (ConvArgs.stats) + finalisation: no pass over the tensor
+int pw_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
+                         float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
 int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st, int assign = 0);
 int pw_lstm_fwd(const TV& gates, const TV& cprev, const TV& h, const TV& cn, hipStream_t st, const TV* hb = nullptr, const float* scale = nullptr, const float* shift = nullptr);
 int pw_lstm_bwd(const TV& gates, const TV& cprev, const TV& cn, const TV& dh, const TV& dc, const TV& dgates, const TV& dcprev, hipStream_t st);

@@ -149,10 +149,11 @@ struct FBnApply {  // out = act(x*scale+shift + second), second = x2*scale2+shif
 };
 struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*lrelu'(out)
     TV dout, outm, x, dx; const float *mean, *invstd, *gamma; const double* sums; int HW; int act; float invM; int assign;
+    const float *scale, *shift;      // act without a materialised output (lazily applied BatchNorm, ConvSrc.bn_*): out = x * scale + shift is recomputed for the slope
     __device__ void operator()(long q, int c) const {
         float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C);
-        if (act) dz = dz * lmask4(ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
         float4 xv = ld4(x.p + tv_off(x, HW, q) + c, c, x.C);
+        if (act) dz = dz * lmask4(scale ? xv * ld4(scale + c, c, x.C) + ld4(shift + c, c, x.C) : ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
         float4 mu = ld4(mean + c, c, x.C), is = ld4(invstd + c, c, x.C), ga = ld4(gamma + c, c, x.C);
         float s1[4], s2[4];
         for (int e = 0; e < 4; e++) { bool ok = c + e < x.C; s1[e] = ok ? (float)(sums[2 * (c + e)] * invM) : 0.f; s2[e] = ok ? (float)(sums[2 * (c + e) + 1] * invM) : 0.f; }
@@ -290,6 +291,7 @@ struct RedArgs {
     TV x, dout, outm; const float *mean, *invstd; double* sums; float* outf; long out_sn; float scale; int act; int pix_per_block;
     float *dgamma, *dbeta;   // MODE 1 + partials: fused parameter gradients
     double* partials;   // MODE 0/1: when set, block b writes its sums to partials[b][2C] (no atomics); k_sum_partials folds them
+    const float *lz_scale, *lz_shift;   // MODE 1, act without a materialised output: the LeakyReLU slope is taken from x * scale + shift (lazily applied BatchNorm)
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
                     s[4] += (double)xv.x * xv.x; s[5] += (double)xv.y * xv.y; s[6] += (double)xv.z * xv.z; s[7] += (double)xv.w * xv.w;
                 } else if (MODE == 1) {
                     float4 dz = ld4(a.dout.p + tv_off(a.dout, HW, q) + c, c, C);
-                    if (a.act) dz = dz * lmask4(ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
+                    if (a.act) dz = dz * lmask4(a.lz_scale ? xv * ld4(a.lz_scale + c, c, C) + ld4(a.lz_shift + c, c, C) : ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
                     float4 xh = (xv - ld4(a.mean + c, c, C)) * ld4(a.invstd + c, c, C);
                     s[0] += dz.x; s[1] += dz.y; s[2] += dz.z; s[3] += dz.w;
                     s[4] += (double)dz.x * xh.x; s[5] += (double)dz.y * xh.y; s[6] += (double)dz.z * xh.z; s[7] += (double)dz.w * xh.w;
@@ -327,9 +329,17 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
     }
     for (int e = 0; e < 8; e++) sh[tid * 8 + e] = s[e];
     __syncthreads();
+    // fold the PT pixel rows of the block: a tree over `pt` (with 16 .. 64-channel tensors PT is 16 .. 64: one thread per channel quad walking them
+    // serially was ~10 us of dependent LDS reads at the end of every launch -- more than the streaming part of E's / D's per-time-step maps)
+    int top = 1;
+    while (top < PT) top <<= 1;
+    for (int half = top >> 1; half >= 1; half >>= 1) {
+        if (pt < half && pt + half < PT)
+            for (int e = 0; e < 8; e++) sh[tid * 8 + e] += sh[((pt + half) * C4b + j) * 8 + e];
+        __syncthreads();
+    }
     if (pt == 0 && j < C4) {
-        for (int p = 1; p < PT; p++)
-            for (int e = 0; e < 8; e++) s[e] += sh[(p * C4b + j) * 8 + e];
+        for (int e = 0; e < 8; e++) s[e] = sh[j * 8 + e];
         int c = j * 4;
         for (int e = 0; e < 4; e++) {
             if (c + e >= C) break;
@@ -383,6 +393,18 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* partials, in
         int c = blockIdx.x * 2 + threadIdx.x;
         if (threadIdx.x < 2 && c < fin.C) bn_finalize_channel(fin, c, sh[2 * threadIdx.x], sh[2 * threadIdx.x + 1], 1);
     }
+}
+
+// BatchNorm statistics from the per-tile partial sums a convolution's epilogue wrote (ConvArgs.stats: part[(tile * ldp + c) * 2 + {0, 1}] = {sum, sum of squares}
+// over the tile's valid pixels, fp32): one wave per channel, lanes stride over the tiles in a FIXED order, fp64 from here on (E[x^2] - E[x]^2), then the
+// usual finalisation (running statistics, mean / invstd / scale / shift).  Replaces a full read of the conv output (k_reduce<0>) + k_sum_partials.
+__global__ __launch_bounds__(256) void k_bn_finalize_tiles(const float* part, int ntiles, int ldp, BnFin fin) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= fin.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < ntiles; t += 64) { const float* p = part + ((long)t * ldp + c) * 2; s1 += (double)p[0]; s2 += (double)p[1]; }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) bn_finalize_channel(fin, c, s1, s2, 1);
 }
 
 template <int MODE>
@@ -636,6 +658,11 @@ int pw_bn_stats_finalize(const TV& x, double* sums, double* scratch, const float
     BnFin f = make_fin((long)x.N * x.H * x.W, gamma, beta, rmean, rvar, x.C, mean, invstd, scale, shift);
     return run_reduce<0>(a, st, &f);
 }
+int pw_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
+                         float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize_tiles, dim3(cdiv(C, 4)), dim3(256), 0, st, part, ntiles, ldp, make_fin(count, gamma, beta, rmean, rvar, C, mean, invstd, scale, shift));
+    return 0;
+}
 // measured on the MI355X: one workgroup per 4 channels streams at ~13 GB/s (per-CU memory parallelism), so the one-launch path only
 // wins below ~1024 pixels (Breakout's 13x10 maps, unit tests); BAIR's smallest map (16x16x8) stays on the multi-workgroup path
 bool pw_bn_small_pays(const TV& x) { return (long)x.N * x.H * x.W <= 1024 && x.C >= 4; }
@@ -660,14 +687,16 @@ int pw_bn_apply(const TV& x, const float* scale, const float* shift, const TV* x
     FBnApply f{x, x2 ? *x2 : x, out, scale, shift, scale2, shift2, x.H * x.W, x2 ? 1 : 0, act};
     return run_map((long)x.N * x.H * x.W, x.C, f, st);
 }
-int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st) {
-    RedArgs a{}; a.partials = scratch; if (scratch) { a.dgamma = dgamma; a.dbeta = dbeta; } a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = outm ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
+int pw_bn_bwd_reduce(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, double* sums, double* scratch, float* dgamma, float* dbeta, hipStream_t st,
+                     const float* lazy_scale, const float* lazy_shift) {
+    RedArgs a{}; a.partials = scratch; if (scratch) { a.dgamma = dgamma; a.dbeta = dbeta; } a.x = x; a.dout = dout; a.outm = outm ? *outm : dout; a.act = (outm || lazy_scale) ? 1 : 0; a.mean = mean; a.invstd = invstd; a.sums = sums;
+    a.lz_scale = lazy_scale; a.lz_shift = lazy_shift;
     return run_reduce<1>(a, st);
 }
 int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                    const TV& dx, float* dgamma, float* dbeta, int assign, hipStream_t st) {
+                    const TV& dx, float* dgamma, float* dbeta, int assign, hipStream_t st, const float* lazy_scale, const float* lazy_shift) {
     long M = (long)x.N * x.H * x.W;
-    FBnBwdApply f{dout, outm ? *outm : dout, x, dx, mean, invstd, gamma, sums, x.H * x.W, outm ? 1 : 0, (float)(1.0 / (double)M), assign};
+    FBnBwdApply f{dout, outm ? *outm : dout, x, dx, mean, invstd, gamma, sums, x.H * x.W, (outm || lazy_scale) ? 1 : 0, (float)(1.0 / (double)M), assign, lazy_scale, lazy_shift};
     run_map(M, x.C, f, st);
     if (dgamma) hipLaunchKernelGGL(k_bn_param_grad, dim3(cdiv(x.C, 64)), dim3(64), 0, st, sums, x.C, dgamma, dbeta);
     return 0;

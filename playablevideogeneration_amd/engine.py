@@ -434,6 +434,12 @@ class Engine:
         self._check(self.lib.caddy_profile_end(C.c_void_p(self.ctx), out))
         return {n: (int(out[4 * i]), out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]) for i, n in enumerate(self.CONV_FAMILIES)}
 
+    def fusion_counts(self) -> Dict[str, int]:
+        """BatchNorm fusion bookkeeping since creation (debug / tests)"""
+        out = (C.c_long * 3)()
+        self.lib.caddy_debug_fusion_counts(C.c_void_p(self.ctx), out)
+        return {"bn_calls": out[0], "stats_from_conv_epilogue": out[1], "never_materialised": out[2]}
+
     def bn_calls(self) -> Dict[str, int]:
         buf = C.create_string_buffer(128)
         res = {}

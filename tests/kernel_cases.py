@@ -601,3 +601,166 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     assert err < tol, ("hx conv", err, tol)
     assert torch.equal(out[..., out_c:].cpu(), init[..., out_c:])           # pad channels untouched
     return err
+
+
+def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big=-1, groups=1):
+    """The BatchNorm fusion of round 3 as one chain at kernel level (reference: conv -> BatchNorm2d(train) -> LeakyReLU(0.2) -> conv, e.g. conv1 / bn1 /
+    conv2 of model/layers/residual_block.py:51-61), against torch autograd in fp64:
+      x0 (raw output of a producing conv) --[statistics + finalisation]--> (mean, invstd, scale, shift)
+      y = conv3x3(act(x0 * scale + shift) [, broadcast vector])     k_conv_hx with ConvSrc.bn_* (the normalised tensor is never written)
+          + per-tile partial sums of y from the epilogue (ConvArgs.stats) -> caddy_k_bn_finalize_tiles == batch statistics of y
+      dW = wgrad(dy, act(x0 * scale + shift))                        k_wgrad_hx with ConvSrc.bn_*
+      d(x0) via the backward of the never-materialised BatchNorm      caddy_k_bn_bwd_lazy on the dgrad's output
+    groups > 1: the batch is `groups` independent BatchNorm calls (time-batched launch, ConvSrc.bn_gn / bn_gs): statistics per group."""
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    assert N % groups == 0
+    gn = N // groups
+    x0 = torch.randn(N, Cin, H, W, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    av = torch.randn(N, aux_c, generator=g) if aux_c else None
+    Ct = Cin + aux_c
+    w = torch.randn(Cout, Ct, 3, 3, generator=g) / (Ct * 9) ** 0.5
+    dy = torch.randn(N, Cout, H, W, generator=g) * 1e-3
+    # ---- reference (fp64 autograd), BatchNorm statistics per group ----
+    xr, wr, gr, br = x0.double().requires_grad_(True), w.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    parts, means, invs = [], [], []
+    for q in range(groups):
+        xg = xr[q * gn:(q + 1) * gn]
+        mu = xg.mean(dim=(0, 2, 3)); var = xg.var(dim=(0, 2, 3), unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        bnv = (xg - mu[None, :, None, None]) * (inv * gr)[None, :, None, None] + br[None, :, None, None]
+        parts.append(F.leaky_relu(bnv, 0.2) if act else bnv)
+        means.append(mu.detach()); invs.append(inv.detach())
+    a_ref = torch.cat(parts, 0)
+    full = torch.cat([a_ref, av.double()[:, :, None, None].expand(-1, -1, H, W)], 1) if aux_c else a_ref
+    y_ref = F.conv2d(full, wr, None, padding=1)
+    (y_ref * dy.double()).sum().backward()
+    # ---- device side ----
+    x_d = nhwc(x0, dev=dev)
+    cp = round_up(Cin, 4)
+    tab = torch.zeros(groups, 4 * cp, device=dev)                   # per group: mean | invstd | scale | shift (the driver's BNStash layout)
+    gam_d, bet_d = gamma.to(dev), beta.to(dev)
+    rmean, rvar = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    sums = torch.zeros(2 * Cin, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(512 * 2 * 1024, dtype=torch.float64, device=dev)
+    sn = H * W * x_d.shape[3]
+    for q in range(groups):
+        xt = TV(x_d.data_ptr() + 4 * q * gn * sn, gn, H, W, Cin, sn, x_d.shape[3])
+        t0 = tab.data_ptr() + 4 * q * 4 * cp
+        assert lib.caddy_k_bn_stats_finalize(C.byref(xt), P(sums), P(scratch), P(gam_d), P(bet_d), P(rmean), P(rvar),
+                                             C.c_void_p(t0), C.c_void_p(t0 + 4 * cp), C.c_void_p(t0 + 8 * cp), C.c_void_p(t0 + 12 * cp), st) == 0
+    sync(dev)
+    for q in range(groups):
+        assert (tab[q, :Cin].cpu().double() - means[q]).abs().max().item() < 1e-5 and (tab[q, cp:cp + Cin].cpu().double() / invs[q] - 1).abs().max().item() < 1e-5
+    segs = [(0, Cin)] + ([(Cin, aux_c)] if aux_c else [])
+    d = make_pack([w], segs, 3, lib)
+    w_d = w.contiguous().to(dev)
+    gw_d = torch.zeros_like(w_d)
+    d.w[0], d.gw[0] = w_d.data_ptr(), gw_d.data_ptr()
+    rows_pad = round_up(Cout, lib.caddy_k_hx_pick_bn(Cout))
+    wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), -1, rows_pad, 2), dtype=torch.uint8, device=dev)
+    assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, -1, PREC_F16X3, st) == 0
+    a = ConvArgs()
+    lazy = ConvSrc(x_d.data_ptr(), sn, x_d.shape[3], Cin, round_up(Cin, CONV_BK), 0, tab.data_ptr() + 8 * cp, tab.data_ptr() + 12 * cp, act,
+                   gn if groups > 1 else 0, 4 * cp if groups > 1 else 0)
+    a.src[0] = lazy
+    keep = [x_d]
+    if aux_c:
+        bb = torch.full((N, 16), 7.5); bb[:, :aux_c] = av; bb = bb.to(dev); keep.append(bb)
+        a.src[1] = ConvSrc(bb.data_ptr(), 16, 16, aux_c, round_up(aux_c, CONV_BK), 1)
+    a.nsrc, a.N, a.H, a.W, a.KS = len(segs), N, H, W, 3
+    a.wp, a.Ktot, a.Cout, a.Cout_pad = None, d.Ktot, Cout, d.Cout_pad
+    a.wq, a.precision = wq.data_ptr(), PREC_F16X3
+    out_ld = round_up(Cout, 4)
+    out = torch.full((N, H, W, out_ld), 9.0, device=dev)
+    a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
+    ldp = round_up(Cout, 4)
+    max_tiles = N * ((H + 7) // 8) * ((W + 15) // 16)
+    part = torch.full((max_tiles * ldp * 2,), float("nan"), device=dev)
+    a.stats, a.stats_ld = part.data_ptr(), ldp
+    lib.caddy_k_hx_force_big(big)
+    try:
+        assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    finally:
+        lib.caddy_k_hx_force_big(-1)
+    sync(dev)
+    y = to_nchw(out, Cout).double()
+    scale = y_ref.abs().max().item()
+    err = (y - y_ref.detach()).abs().max().item() / scale
+    assert err < 5e-6, ("conv on the lazily normalised input", err)
+    tiles = lib.caddy_k_conv_stats_tiles()
+    assert 0 < tiles <= max_tiles, tiles
+    assert groups == 1 or tiles % groups == 0
+    # statistics of y from the epilogue's partial sums == batch statistics of y, per group
+    tpg = tiles // groups
+    for q in range(groups):
+        o4 = torch.zeros(4 * ldp, device=dev)
+        rm2, rv2 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        g2, b2 = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        assert lib.caddy_k_bn_finalize_tiles(C.c_void_p(part.data_ptr() + 4 * q * tpg * ldp * 2), tpg, ldp, C.c_long(gn * H * W), P(g2), P(b2), P(rm2), P(rv2), Cout,
+                                             C.c_void_p(o4.data_ptr()), C.c_void_p(o4.data_ptr() + 4 * ldp), C.c_void_p(o4.data_ptr() + 8 * ldp), C.c_void_p(o4.data_ptr() + 12 * ldp), st) == 0
+        sync(dev)
+        yq = y[q * gn:(q + 1) * gn]
+        mu_y, var_y = yq.mean(dim=(0, 2, 3)), yq.var(dim=(0, 2, 3), unbiased=False)
+        assert (o4[:Cout].cpu().double() - mu_y).abs().max().item() < 2e-6 * max(1.0, scale), ("mean from tiles", q)
+        assert (o4[ldp:ldp + Cout].cpu().double() * torch.sqrt(var_y + 1e-5) - 1).abs().max().item() < 2e-5, ("invstd from tiles", q)
+        cnt = gn * H * W
+        assert (rv2.cpu().double() - (0.9 + 0.1 * var_y * cnt / max(1, cnt - 1))).abs().max().item() < 1e-5 * max(1.0, var_y.max().item()), "running_var"
+    # ---- weight gradient on k_wgrad_hx with the lazily normalised source ----
+    dz_d = nhwc(dy, dev=dev)
+    dwp = torch.zeros(9 * d.Cout_pad * d.Ktot, device=dev)
+    wa = WgradArgs()
+    for i in range(a.nsrc):
+        wa.src[i] = a.src[i]
+    wa.nsrc, wa.N, wa.H, wa.W, wa.KS = a.nsrc, N, H, W, 3
+    wa.dy, wa.dy_sn, wa.dy_ld = dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3]
+    wa.Cout, wa.Cout_pad, wa.Ktot, wa.dwp, wa.slabs, wa.precision = Cout, d.Cout_pad, d.Ktot, dwp.data_ptr(), 0, PREC_BF16X3
+    assert lib.caddy_k_conv_wgrad(C.byref(wa), st) == 0
+    assert lib.caddy_k_unpack_wgrad(C.byref(d), P(dwp), st) == 0
+    sync(dev)
+    e = (gw_d.cpu().double() - wr.grad).abs().max().item() / wr.grad.abs().max().item()
+    assert e < 2e-4, ("wgrad on the lazily normalised source", e)
+    if groups > 1:      # the same through the time-batched addressing: groups laid out `groups` launches apart (src_gs / dy_gs / src_bn_gs)
+        wg = WgradArgs()
+        wg.src[0] = ConvSrc(x_d.data_ptr(), sn, x_d.shape[3], Cin, round_up(Cin, CONV_BK), 0, tab.data_ptr() + 8 * cp, tab.data_ptr() + 12 * cp, act, 0, 0)
+        wg.src_gs[0], wg.src_bn_gs[0] = gn * sn, 4 * cp
+        if aux_c:
+            wg.src[1] = a.src[1]; wg.src_gs[1] = gn * 16
+        dwp2 = torch.zeros_like(dwp)
+        wg.nsrc, wg.N, wg.H, wg.W, wg.KS, wg.group_n = a.nsrc, N, H, W, 3, gn
+        wg.dy, wg.dy_sn, wg.dy_ld, wg.dy_gs = dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3], gn * H * W * dz_d.shape[3]
+        wg.Cout, wg.Cout_pad, wg.Ktot, wg.dwp, wg.slabs, wg.precision = Cout, d.Cout_pad, d.Ktot, dwp2.data_ptr(), 0, PREC_BF16X3
+        assert lib.caddy_k_conv_wgrad(C.byref(wg), st) == 0
+        sync(dev)
+        e2 = (dwp2 - dwp).abs().max().item() / dwp.abs().max().item()
+        assert e2 < 2e-4, ("time-batched wgrad with per-group BatchNorm tables", e2)
+    # ---- backward of the BatchNorm that was never materialised: dgrad -> d(normalised), then reduce + apply with the slope from x0 * scale + shift ----
+    rows_d = round_up(Cin, lib.caddy_k_hx_pick_bn(Cin))
+    wqd = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), 0, rows_d, 2), dtype=torch.uint8, device=dev)
+    assert lib.caddy_k_pack_hx(C.byref(d), P(wqd), rows_d, 0, PREC_BF16X3, st) == 0
+    da = ConvArgs()
+    da.src[0] = ConvSrc(dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3], Cout, round_up(Cout, CONV_BK), 0)
+    da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, 3
+    da.wp, da.Ktot, da.Cout, da.Cout_pad = None, round_up(Cout, CONV_BK), Cin, round_up(Cin, lib.caddy_k_conv_pick_bn(Cin))
+    da.wq, da.precision = wqd.data_ptr(), PREC_BF16X3
+    ga = torch.full((N, H, W, cp), float("nan"), device=dev)          # first-touch gradient: assigned
+    da.out, da.out_sn, da.out_ld, da.accumulate = ga.data_ptr(), H * W * cp, cp, 0
+    assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0
+    gx = torch.full((N, H, W, cp), float("nan"), device=dev)
+    dgam, dbet = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+    for q in range(groups):
+        o = 4 * q * gn * H * W * cp
+        dt = TV(ga.data_ptr() + o, gn, H, W, Cin, H * W * cp, cp)
+        xt = TV(x_d.data_ptr() + 4 * q * gn * sn, gn, H, W, Cin, sn, x_d.shape[3])
+        gt = TV(gx.data_ptr() + o, gn, H, W, Cin, H * W * cp, cp)
+        t0 = tab.data_ptr() + 4 * q * 4 * cp
+        assert lib.caddy_k_bn_bwd_lazy(C.byref(dt), C.byref(xt), C.c_void_p(t0), C.c_void_p(t0 + 4 * cp), P(gam_d), C.c_void_p(t0 + 8 * cp), C.c_void_p(t0 + 12 * cp), act,
+                                       P(sums), P(scratch), C.byref(gt), P(dgam), P(dbet), st) == 0
+    sync(dev)
+    gref = xr.grad
+    e = (to_nchw(gx, Cin).double() - gref).abs().max().item() / gref.abs().max().item()
+    assert e < 5e-4, ("d(x0) through the lazily applied BatchNorm", e)
+    assert (dgam.cpu().double() - gr.grad).abs().max().item() < 5e-4 * gr.grad.abs().max().item() and (dbet.cpu().double() - br.grad).abs().max().item() < 5e-4 * br.grad.abs().max().item()
+    return err

@@ -100,7 +100,8 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
     losses = eng.loss_backward(H.LOSS_W, smooth_mi=smooth, mi_alpha=0.2)
     assert abs(losses["total"] - float(z["loss_total"])) < 2e-5, (losses["total"], float(z["loss_total"]))
     for k in ("rec", "states", "entropy", "dir_kl", "mi", "state_kl"):
-        assert abs(losses[k] - float(z["loss_" + k])) < 1e-4 * max(1.0, abs(float(z["loss_" + k]))), (k, losses[k], float(z["loss_" + k]))  # log(var) terms are ill-conditioned
+        tol = 1e-3 if k.endswith("_kl") else 1e-4      # the KL terms contain log(variance) of a 2-sample BatchNorm'ed head: ill-conditioned (the trainer goldens use 2e-3)
+        assert abs(losses[k] - float(z["loss_" + k])) < tol * max(1.0, abs(float(z["loss_" + k]))), (k, losses[k], float(z["loss_" + k]))
     if smooth:
         assert np.allclose(eng.mi_ema.cpu().numpy(), z["mi_ema"], atol=1e-6)
     else:

@@ -130,6 +130,17 @@ def test_folded_inference_epilogues_small():
     K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(96, False)], Cout=64, bias=True, act=3, res=True, oscale=True, split=True)
 
 
+def test_batchnorm_fused_into_convolutions_small():
+    """round 3: BatchNorm statistics from the producing conv's epilogue, BatchNorm + LeakyReLU applied by the consuming conv / weight gradient while
+    staging (never materialised), backward with the slope recomputed from the raw tensor; ragged tiles, channel tails, a broadcast segment,
+    the 8-wave tile variant, and per-group tables (time-batched launches)"""
+    lib = load_emu()
+    K.hx_lazy_bn_case(lib, "cpu", N=2, H=10, W=20, Cin=40, Cout=48, aux_c=9)
+    K.hx_lazy_bn_case(lib, "cpu", N=1, H=9, W=17, Cin=64, Cout=33, act=0, seed=1)
+    K.hx_lazy_bn_case(lib, "cpu", N=1, H=20, W=18, Cin=40, Cout=130, big=1, seed=2)
+    K.hx_lazy_bn_case(lib, "cpu", N=4, H=8, W=16, Cin=32, Cout=64, groups=2, seed=3)
+
+
 def test_wgrad_hx_split_bf16_small():
     """k_wgrad_hx on the simulator (ds_read_b64_tr_b16 transposing fragment reads): ragged tiles, three segments incl. a broadcast vector,
     output-channel tail; the forward / dgrad of the same case run on the exact kernels"""

@@ -111,6 +111,18 @@ def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(N=8, H=64, W=64, Cin=128, Cout=128),                      # D residual block: conv1 -> bn1 -> LeakyReLU -> conv2, 8x16x128 tiles
+    dict(N=8, H=128, W=128, Cin=64, Cout=64, seed=1),              # 16x16x64 tiles
+    dict(N=8, H=32, W=32, Cin=128, Cout=256, aux_c=9, act=0),      # ConvLSTM 0's BatchNorm (no activation) -> SameBlock conv with the broadcast action input
+    dict(N=3, H=26, W=20, Cin=64, Cout=65, seed=2),                # Breakout state resolution: ragged tiles, channel tail
+    dict(N=40, H=64, W=64, Cin=128, Cout=128, groups=5, seed=3),   # five time steps in one launch: per-step statistics, 8-wave tiles
+    dict(N=16, H=32, W=32, Cin=64, Cout=64, groups=2, big=0, seed=4),
+])
+def test_batchnorm_fused_into_convolutions(lib, kw):
+    K.hx_lazy_bn_case(lib, "cuda", **kw)
+
+
 def test_conv_hx_fused_maxpool_epilogue(lib):
     """MaxPool2d(2, 2) written by the conv epilogue at VGG19 shapes (conv1_2 / conv3_4 / conv4_4), incl. the write-less ground-truth form and an odd map"""
     K.hx_conv_case(lib, "cuda", N=4, H=256, W=256, segs=[(64, False)], Cout=64, bias=True, act=2, pool=True)

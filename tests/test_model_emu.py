@@ -83,3 +83,18 @@ def test_full_reduced_s1_split_operand_kernels():
         M.full_case("full_reduced_s1", load_emu(), "cpu")
     finally:
         M.SIM_SPLIT = False
+
+
+def test_full_reduced_s1_fused_batchnorm_paths():
+    """round 3: with the one-launch BatchNorm for tiny maps switched off, the tiny golden geometry reaches the fused forms -- statistics from the conv epilogue,
+    BatchNorm + LeakyReLU applied by the consuming k_conv_hx / k_wgrad_hx (never materialised), backward with the slope from the raw tensor --
+    forward, losses, BN buffers and gradients against the reference golden / fp64 oracle"""
+    import ctypes as C
+    lib = load_emu()
+    M.SIM_SPLIT = True
+    try:
+        eng, _ = M.full_case("full_reduced_s1", lib, "cpu", prep=lambda e: lib.caddy_debug_set_bn_paths(C.c_void_p(e.ctx), 0, 1, 1))
+        fc = eng.fusion_counts()
+        assert fc["never_materialised"] >= 10 and fc["stats_from_conv_epilogue"] >= 10, fc
+    finally:
+        M.SIM_SPLIT = False
