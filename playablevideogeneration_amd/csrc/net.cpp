@@ -254,6 +254,12 @@ void build_layers(caddy_ctx* c) {
     c->conv_aux2 = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
     c->conv_split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
+    // private scratch of the teacher-forced decoder stream (caddy_ctx::dstream)
+    c->dsr.aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
+    c->dsr.split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
+    c->dsr.red = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
+    for (int i = 0; i < 3; i++) c->d_norm[i].deferred = true;
+    for (int i = 0; i < 2; i++) { c->d_res[i].bn1.deferred = c->d_res[i].bn2.deferred = true; if (c->d_res[i].has_down) c->d_res[i].bnd.deferred = true; }
 }
 }  // namespace
 
@@ -316,12 +322,49 @@ void caddy_ctx::ensure_side() {
     else hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
     if (!gt_done) hipEventCreateWithFlags(&gt_done, hipEventDisableTiming);
 }
-hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the main stream
+hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the compute stream(s)
     if (!use_side || !side) return stream;
     hipEvent_t e = sev();
     hipEventRecord(e, stream);
     hipStreamWaitEvent(side, e, 0);
+    if (d_forked) {      // the teacher-forced decoder branch is in flight on the other compute stream: a time-batched weight gradient may read what it produced
+        hipStream_t other = in_d ? dsr_saved.st : dsr.st;
+        hipEvent_t e2 = sev();
+        hipEventRecord(e2, other);
+        hipStreamWaitEvent(side, e2, 0);
+    }
     return side;
+}
+// switch the driver to the teacher-forced decoder stream (and its private scratch); fork: order it after everything enqueued on the main stream so far
+void caddy_ctx::enter_d(bool fork) {
+    if (!dry && !dstream && !d_done) {      // once (the simulator build hands out null streams: everything then runs in order on the caller's stream)
+        if (hipStreamCreateWithFlags(&dstream, hipStreamNonBlocking) != hipSuccess) dstream = nullptr;
+        hipEventCreateWithFlags(&d_done, hipEventDisableTiming);
+    }
+    tp = &tape2;
+    if (dry || !dstream) return;
+    if (fork) { hipEvent_t e = sev(); hipEventRecord(e, stream); hipStreamWaitEvent(dstream, e, 0); d_forked = true; }
+    dsr_saved = StreamRes{stream, conv_aux, conv_split, red_scratch};
+    dsr.st = dstream;
+    stream = dsr.st; conv_aux = dsr.aux; conv_split = dsr.split; red_scratch = dsr.red;
+    in_d = true;
+}
+void caddy_ctx::leave_d() {
+    tp = &tape;
+    if (!in_d) return;
+    stream = dsr_saved.st; conv_aux = dsr_saved.aux; conv_split = dsr_saved.split; red_scratch = dsr_saved.red;
+    in_d = false;
+}
+// backward of the teacher-forced decoder calls: concurrently on dstream (forked after the loss kernels), or inline at its place in the main tape
+void caddy_ctx::replay_tape2(bool concurrent) {
+    if (tape2.empty()) return;
+    if (concurrent) enter_d(true);
+    for (size_t i = tape2.size(); i-- > 0;) tape2[i]();
+    if (concurrent) {
+        flush_all_wgrad();      // while the decoder stream is current: the side stream is ordered behind what these chunks read
+        if (in_d) hipEventRecord(d_done, stream);
+        leave_d();
+    }
 }
 void caddy_ctx::flush_wgrad(PendingW& p) {
     if (p.count == 0) return;
@@ -421,7 +464,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             if (segs[s].bcast && segs[s].need_grad) tmp[s] = L.pd.KS == 3 ? alloc(N, 1, 1, L.pd.Cout * 9) : alloc(N, H, W, segs[s].t.C);
         }
         ConvL* Lp = &L;
-        tape.push_back([=]() {
+        tp->push_back([=]() {
             TV dzv = gv(out);
             if (actf == 1) { RUN(pw_tanh_bwd(gv(out), dv(out), dv(dz), stream)); dzv = dv(dz); }
             WgradArgs w{};
@@ -470,24 +513,28 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
 T4 caddy_ctx::pool2(const T4& x, bool actf) {
     T4 o = x.nz ? alloc_nz(x.N, x.H / 2, x.W / 2, x.C) : alloc(x.N, x.H / 2, x.W / 2, x.C);   // conv -> pool -> BatchNorm chains stay first-touch
     RUN(pw_pool2(dv(x), dv(o), stream, actf ? 1 : 0));
-    if (recording) tape.push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), x.nz ? 1 : 0, stream)); });
+    if (recording) tp->push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), x.nz ? 1 : 0, stream)); });
     return o;
 }
 T4 caddy_ctx::up2(const T4& x) {
     T4 o = alloc_nz(x.N, x.H * 2, x.W * 2, x.C);      // every up-sampled map feeds exactly one conv (UpBlock / ConvLSTM gates): its dgrad assigns, no zero-fill, no read-modify-write
     RUN(pw_up2(dv(x), dv(o), stream));
-    if (recording) tape.push_back([=]() { RUN(pw_up2_bwd(gv(o), gv(x), stream, x.nz2 ? 1 : 0)); });      // x.nz2: this is the first writer of d(x)
+    if (recording) tp->push_back([=]() { RUN(pw_up2_bwd(gv(o), gv(x), stream, x.nz2 ? 1 : 0)); });      // x.nz2: this is the first writer of d(x)
     return o;
 }
 
-struct BNStash { float *mean, *invstd, *scale, *shift; double* sums; };
+struct BNStash { float *mean, *invstd, *scale, *shift, *uvar; double* sums; };
 static BNStash bn_stash(caddy_ctx* c, BNL& bn) {
-    BNStash s; float* f = c->falloc(4 * (size_t)round_up(bn.C, 4));
+    BNStash s; float* f = c->falloc(5 * (size_t)round_up(bn.C, 4));
     int cp = round_up(bn.C, 4);
     c->dbg.push_back(T4{f, f, 1, 1, 1, 4 * cp, 4 * cp, 4 * cp});
-    s.mean = f; s.invstd = f + cp; s.scale = f + 2 * cp; s.shift = f + 3 * cp; s.sums = c->dalloc(2 * (size_t)bn.C);
+    s.mean = f; s.invstd = f + cp; s.scale = f + 2 * cp; s.shift = f + 3 * cp; s.uvar = f + 4 * cp; s.sums = c->dalloc(2 * (size_t)bn.C);
     return s;
 }
+// running statistics: updated by the finalisation itself, or (BNL::deferred) left as (mean, unbiased variance) of this call for the in-order k_bn_ema at the end of the forward
+static inline float* rm_of(BNL& bn) { return bn.deferred ? nullptr : bn.rmean; }
+static inline float* rv_of(BNL& bn, const BNStash& s) { return bn.deferred ? s.uvar : bn.rvar; }
+static inline void bn_called(caddy_ctx* c, BNL& bn, const BNStash& s) { if (!c->dry) { bn.calls++; if (bn.deferred) bn.pend.emplace_back(s.mean, s.uvar); } }
 static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
     BNStash s = bn_stash(c, bn);
     bool dry = c->dry;
@@ -496,9 +543,9 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
         if (!dry) c->n_bn_calls++;
         if (ts) c->n_bn_tile_stats++;
         if (ts)      // the producing convolution left per-tile partial sums behind: no pass over x
-            c->ck(pw_bn_finalize_tiles(ts->part, ts->tiles, ts->ldp, (long)x.N * x.H * x.W, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.C, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize_tiles");
-        else if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, bn.rmean, bn.rvar, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
-        if (!dry) bn.calls++;
+            c->ck(pw_bn_finalize_tiles(ts->part, ts->tiles, ts->ldp, (long)x.N * x.H * x.W, bn.gamma, bn.beta, rm_of(bn), rv_of(bn, s), bn.C, s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_finalize_tiles");
+        else if (!dry) c->ck(pw_bn_stats_finalize(dv(x), s.sums, c->red_scratch, bn.gamma, bn.beta, rm_of(bn), rv_of(bn, s), s.mean, s.invstd, s.scale, s.shift, c->stream), "bn_stats_finalize");
+        bn_called(c, bn, s);
         bn.eval_valid = false;
         return s;
     }
@@ -534,7 +581,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
         out.bn_scale = s1.scale; out.bn_shift = s1.shift; out.bn_act = actf ? 1 : 0;
         if (recording) {
             BNL* b1 = &bn;
-            tape.push_back([=]() {
+            tp->push_back([=]() {
                 const float* ls = actf ? s1.scale : nullptr;
                 RUN(pw_bn_bwd_reduce(gv(out), nullptr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream, ls, s1.shift));
                 RUN(pw_bn_bwd_apply(gv(out), nullptr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream, ls, s1.shift));
@@ -547,8 +594,8 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
     BNStash s1{}, s2{};
     if (small) {
         s1 = bn_stash(this, bn);
-        RUN(pw_bn_small_fwd(dv(x), bn.gamma, bn.beta, bn.rmean, bn.rvar, s1.mean, s1.invstd, s1.scale, s1.shift, x2 ? &x2v : nullptr, actf ? 1 : 0, dv(out), stream));
-        if (!dry) bn.calls++;
+        RUN(pw_bn_small_fwd(dv(x), bn.gamma, bn.beta, rm_of(bn), rv_of(bn, s1), s1.mean, s1.invstd, s1.scale, s1.shift, x2 ? &x2v : nullptr, actf ? 1 : 0, dv(out), stream));
+        bn_called(this, bn, s1);
     } else {
         s1 = bn_forward(this, x, bn);
         if (x2 && bn2) s2 = bn_forward(this, *x2, *bn2);
@@ -557,7 +604,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
     if (recording) {
         T4 x2c{}; if (x2) x2c = *x2;
         bool has2 = x2 != nullptr; BNL* b1 = &bn; BNL* b2 = bn2;
-        tape.push_back([=]() {
+        tp->push_back([=]() {
             TV om = dv(out);
             const TV* omp = actf ? &om : nullptr;
             if (small) {
@@ -621,7 +668,7 @@ T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
 
 void caddy_ctx::copy_op(const T4& src, const T4& dst) {
     RUN(pw_copy(dv(src), dv(dst), 0, stream));
-    if (recording) tape.push_back([=]() { RUN(pw_copy(gv(dst), gv(src), 1, stream)); });
+    if (recording) tp->push_back([=]() { RUN(pw_copy(gv(dst), gv(src), 1, stream)); });
 }
 
 // ConvLSTM step (convolutional_lstm.py:50-74, convolutional_lstm_cell.py:88-101) followed by its BatchNorm
@@ -636,7 +683,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
         RUN(pw_copy(dv(ih), dv(hprev), 0, stream)); RUN(pw_copy(dv(ic), dv(cprev), 0, stream));
         if (recording) {
             T4 ihg = L.ih, icg = L.ic;
-            tape.push_back([=]() {
+            tp->push_back([=]() {
                 RUN(pw_batch_sum(hprev.g, hprev.sn, hprev.sn, B, ihg.g, stream));
                 RUN(pw_batch_sum(cprev.g, cprev.sn, cprev.sn, B, icg.g, stream));
             });
@@ -655,7 +702,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
         return hb;
     }
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
-    if (recording) tape.push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
+    if (recording) tp->push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
     return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
 }
@@ -707,14 +754,14 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     T4 st = alloc(NT, hs, ws, 64);
     H.att = alloc(NT, hs, ws, 1);
     RUN(pw_attn_mul(dv(x65), dv(st), dv(H.att), stream));
-    if (recording) { T4 att = H.att; tape.push_back([=]() { TV none{}; (void)att; RUN(pw_attn_mul_bwd(dv(x65), gv(st), none, gv(x65), stream)); }); }
+    if (recording) { T4 att = H.att; tp->push_back([=]() { TV none{}; (void)att; RUN(pw_attn_mul_bwd(dv(x65), gv(st), none, gv(x65), stream)); }); }
     T4 r = resblock(a_res[0], st, nullptr, !a_res[1].has_down);
     r = resblock(a_res[1], r, nullptr);
     HeadBufs& b = H.b;
     float* feat = falloc((size_t)NT * hp.F);
     RUN(pw_gap(dv(r), feat, stream));
     b.feat = feat; b.d_feat = tw(this, feat);
-    if (recording) { float* df = b.d_feat; tape.push_back([=]() { RUN(pw_gap_bwd(df, gv(r), stream)); }); }
+    if (recording) { float* df = b.d_feat; tp->push_back([=]() { RUN(pw_gap_bwd(df, gv(r), stream)); }); }
     b.eps_s = eps_s; b.eps_d = eps_d; b.unif = unif;
     b.mu = falloc((size_t)NT * Da); b.raw = falloc((size_t)NT * Da);
     b.sdist = falloc((size_t)NT * 2 * Da); b.ssamp = falloc((size_t)NT * Da);
@@ -741,7 +788,7 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
         if (sh.fn && sh.action) { sc.mode = 2; sc.samples_in = sh.samples_buf; }             // what the backward pass must assume
         if (sh.fn && sh.variation) sc.variations_in = sh.var_buf;
     }
-    if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tape.push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
+    if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tp->push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
 void caddy_ctx::pack_all(bool with_fold) {
@@ -797,7 +844,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);      // a forward without a backward in between: the side stream may still read the old observations
-    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -821,7 +868,16 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
         T4 aux = tslice(aux_all, B, T - 1, t);
         T4 hslot = tslice(c->hidden, B, T - 1, t);
         T4 hdn = c->dynamics(state, aux, &hslot);
-        c->render(hdn, t, T - 1);
+        const bool teacher_forced = t + 1 < gt_init;      // nothing feeds this step's frames back into the model (model.py:241-243)
+        if (teacher_forced && c->use_dstream && c->recording) {
+            c->enter_d(true);      // D(t) beside R(t + 1) ...: its tape entries go to tape2
+            c->render(hdn, t, T - 1);
+            c->leave_d();
+            if (t + 2 >= gt_init || t + 2 >= T) c->tape.push_back([c]() {      // (reverse replay: runs right before R-bwd of the last teacher-forced step)
+                if (c->d_forked && !c->dry) { hipStreamWaitEvent(c->stream, c->d_done, 0); c->d_forked = false; }
+                else if (!c->tape2_done) c->replay_tape2(false);
+            });
+        } else c->render(hdn, t, T - 1);
         if (t + 1 >= gt_init) {   // feed the reconstruction back through E (model.py:249-258, compute_current_observation :499-543)
             int idx = t + 1, start = idx - S + 1;
             T4 fb;
@@ -845,7 +901,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
     c->fwd_off = c->act.off;
     if (dry && g.perceptual) { T4 gi[3]; VggLevels lv; c->alloc_gt_images(gi, T - 1); vgg_perceptual(c, 1.0, gi, &lv); c->act.off = c->fwd_off; }      // workspace sizing
-    c->have_forward = true;
+    c->end_forward();
     return finish(c);
 }
 
@@ -859,7 +915,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);
-    c->act.reset(); c->tape.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -910,8 +966,22 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
     c->fwd_off = c->act.off;
     if (dry && g.perceptual) { T4 gi[3]; VggLevels lv; c->alloc_gt_images(gi, T); vgg_perceptual(c, 1.0, gi, &lv); c->act.off = c->fwd_off; }
-    c->have_forward = true;
+    c->end_forward();
     return finish(c);
+}
+
+// end of a forward graph: join the teacher-forced decoder stream, apply the deferred running-statistics updates in call order
+void caddy_ctx::end_forward() {
+    if (!dry && d_forked) { hipEventRecord(d_done, dstream); hipStreamWaitEvent(stream, d_done, 0); d_forked = false; }
+    for (BNL* b : bns) {
+        if (!b->deferred || b->pend.empty()) continue;
+        std::vector<const float*> m, v;
+        for (auto& pr : b->pend) { m.push_back(pr.first); v.push_back(pr.second); }
+        if (!dry) ck(pw_bn_ema(m.data(), v.data(), (int)m.size(), b->C, b->rmean, b->rvar, stream), "bn_ema");
+        b->pend.clear();
+    }
+    tape2_done = false;
+    have_forward = true;
 }
 
 // resized ground-truth frames (N, H >> r, W >> r, 3) pitch 4: input of the VGG19 ground-truth branch, written by loss_l1
@@ -989,6 +1059,9 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
         return finish(c);
     }
+    // the decoder backward of the teacher-forced steps only needs the loss seeds: start it on its own stream, beside the serial BPTT chain
+    c->tape2_done = false;
+    if (!c->tape2.empty() && c->use_dstream && !dry) { c->replay_tape2(true); c->tape2_done = true; }
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     c->flush_all_wgrad();
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
@@ -1008,7 +1081,7 @@ static void rollout_body(caddy_ctx* c) {
     const caddy_config& g = c->cfg;
     const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
-    c->act.reset(); c->tape.clear(); c->training = false; c->recording = false; c->have_forward = false; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->training = false; c->recording = false; c->have_forward = false; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->fold = c->packed_fold; c->rollout = true;
     T4 o = c->alloc(1, H, W, 3 * S);
     if (!dry) c->ck(pw_nchw_to_nhwc(c->inf_obs, 0, dv(o), c->stream), "obs layout");
@@ -1217,6 +1290,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
+    if (const char* e = getenv("CADDY_D_STREAM")) c->use_dstream = atoi(e) != 0;        // A/B aid: 0 = teacher-forced decoder calls on the main stream
     if (const char* e = getenv("CADDY_BN_SMALL")) c->bn_small = atoi(e) != 0;           // A/B aid: 0 = no one-launch BatchNorm for tiny maps
     if (const char* e = getenv("CADDY_BN_LAZY")) c->lazy_bn = atoi(e) != 0;             // A/B aid: 0 = every BatchNorm output is materialised
     if (const char* e = getenv("CADDY_BN_EPI_STATS")) c->epi_stats = atoi(e) != 0;      // A/B aid: 0 = BatchNorm statistics by a separate pass over the conv output
@@ -1229,6 +1303,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
 void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
+    if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
     delete c;
 }
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }

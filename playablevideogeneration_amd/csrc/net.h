@@ -65,7 +65,10 @@ struct ConvL {
     struct BNL* fold_bn = nullptr; float* fold_bias = nullptr;
 };
 struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
-             float* eval_stash = nullptr; bool eval_valid = false; };   // eval mode: (mean, invstd, scale, shift) from the running statistics, computed once per start_inference / eval forward
+             float* eval_stash = nullptr; bool eval_valid = false;
+             // deferred running-statistics update (D's BatchNorms: their calls execute on two streams): every train-mode call leaves (mean, unbiased variance) in its
+             // stash and the momentum updates are applied in CALL order by one kernel at the end of the forward
+             bool deferred = false; std::vector<std::pair<const float*, const float*>> pend; };   // eval mode: (mean, invstd, scale, shift) from the running statistics, computed once per start_inference / eval forward
 struct ResL { ConvL conv1, conv2, down; BNL bn1, bn2, bnd; bool has_down = false; int ds = 1; };
 struct LstmL { ConvL gates; BNL bn; float *init_h, *init_c, *ginit_h, *ginit_c;   // boundary (C,h,w) params + grads
                T4 ih, ic;        // HWC copies (1,h,w,C) in the persistent arena (data + grad)
@@ -89,6 +92,22 @@ struct caddy_ctx {
     Arena persist, act;
     size_t grad_delta = 0;           // byte distance between an activation and its gradient
     std::vector<std::function<void()>> tape;
+    // ---- the decoder of the teacher-forced time steps on its own stream ----
+    // For t + 1 < gt_init nothing feeds D(t)'s frames back into the model (model.py:241-243): D(t) only depends on R(t), and in the backward pass D-bwd(t) only on
+    // the loss seeds.  Those decoder calls (a third of D's work at gt_init = 6, T = 16) run on `dstream`, beside the serial R -> D -> E chain of the closed-loop
+    // steps whose small grids leave most of the chip idle: forward forked after R(t), joined at the end of the forward; backward forked right after the loss
+    // kernels, joined before R-bwd of the last teacher-forced step.  Their tape entries live in `tape2`; the stream-private scratch buffers are swapped with
+    // the stream (enter_d / leave_d).  BatchNorm running statistics of D are applied in call order at the end of the forward (BNL::deferred), whatever the
+    // execution order of the two streams was.
+    std::vector<std::function<void()>> tape2;
+    std::vector<std::function<void()>>* tp = &tape;      // tape the ops currently record into
+    hipStream_t dstream = nullptr; bool use_dstream = true, in_d = false, d_forked = false; hipEvent_t d_done = nullptr;
+    struct StreamRes { hipStream_t st; float* aux; float* split; double* red; } dsr{}, dsr_saved{};
+    void enter_d(bool fork);
+    void leave_d();
+    void replay_tape2(bool concurrent);
+    void end_forward();
+    bool tape2_done = false;
     std::vector<T4> dbg;             // every alloc() of the current forward (debug introspection, caddy_debug_*)
     std::vector<ConvL*> convs;
     std::vector<BNL*> bns;

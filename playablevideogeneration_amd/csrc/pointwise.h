@@ -28,6 +28,9 @@ int pw_bn_bwd_apply(const TV& dout, const TV* outm, const TV& x, const float* me
                     const TV& dx, float* dgamma, float* dbeta, int assign /* dx = ... instead of += : dx has no other writer */, hipStream_t st,
                     const float* lazy_scale = nullptr, const float* lazy_shift = nullptr);
 // train-mode statistics from the per-tile partial sums of the producing convolution's epilogue (ConvArgs.stats) + finalisation: no pass over the tensor
+// rmean == nullptr in any of the train-mode finalisations above / below: deferred running statistics -- `rvar` then receives the unbiased variance of this call
+// and pw_bn_ema applies the momentum updates of `n` calls in order
+int pw_bn_ema(const float* const* means, const float* const* uvars, int n, int C, float* rmean, float* rvar, hipStream_t st);
 int pw_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
                          float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
 int pw_act_bwd_add(const TV& dout, const TV& outm, const TV& dres, hipStream_t st, int assign = 0);

@@ -365,8 +365,10 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, doubl
         m = (float)mu;
         is = (float)(1.0 / sqrt(var + (double)f.eps));
         double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
-        f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * m;
-        f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unb;
+        if (f.rmean) {
+            f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * m;
+            f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unb;
+        } else if (f.rvar) f.rvar[c] = (float)unb;      // deferred running statistics (rmean == nullptr): leave the unbiased variance of THIS call for k_bn_ema
     } else {
         m = f.rmean[c];
         is = 1.f / sqrtf(f.rvar[c] + f.eps);
@@ -532,6 +534,16 @@ __global__ void k_bn_finalize(const double* sums, BnFin f, int training) {
     if (c >= f.C) return;
     bn_finalize_channel(f, c, training ? sums[2 * c] : 0.0, training ? sums[2 * c + 1] : 0.0, training);
 }
+// deferred momentum updates of one BatchNorm layer, applied in call order (same float arithmetic as bn_finalize_channel, so the result is bit-identical to
+// updating inside every call): the calls of D's BatchNorms execute on two streams (caddy_ctx::dstream) and must not race on / reorder the running statistics
+struct EmaArgs { const float* mean[32]; const float* uvar[32]; int n, C; float momentum; float *rmean, *rvar; };
+__global__ void k_bn_ema(EmaArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    float m = a.rmean[c], v = a.rvar[c];
+    for (int i = 0; i < a.n; i++) { m = (1.f - a.momentum) * m + a.momentum * a.mean[i][c]; v = (1.f - a.momentum) * v + a.momentum * a.uvar[i][c]; }
+    a.rmean[c] = m; a.rvar[c] = v;
+}
 __global__ void k_bn_param_grad(const double* sums, int C, float* dgamma, float* dbeta) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -657,6 +669,14 @@ int pw_bn_stats_finalize(const TV& x, double* sums, double* scratch, const float
     RedArgs a{}; a.x = x; a.sums = sums; a.partials = scratch;
     BnFin f = make_fin((long)x.N * x.H * x.W, gamma, beta, rmean, rvar, x.C, mean, invstd, scale, shift);
     return run_reduce<0>(a, st, &f);
+}
+int pw_bn_ema(const float* const* means, const float* const* uvars, int n, int C, float* rmean, float* rvar, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += 32) {
+        EmaArgs a{}; a.n = n - i0 < 32 ? n - i0 : 32; a.C = C; a.momentum = 0.1f; a.rmean = rmean; a.rvar = rvar;
+        for (int i = 0; i < a.n; i++) { a.mean[i] = means[i0 + i]; a.uvar[i] = uvars[i0 + i]; }
+        hipLaunchKernelGGL(k_bn_ema, dim3(cdiv(C, 64)), dim3(64), 0, st, a);
+    }
+    return 0;
 }
 int pw_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
                          float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
