@@ -56,7 +56,7 @@ def load(path=None):
     global _lib
     if path is None and _lib is not None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("CADDY_HIP_LIB") or LIB_PATH      # (CADDY_HIP_LIB: timing experiments with an alternative build of the same library)
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: the HIP extension is not built (run __graft_entry__.build()); "
                            "playablevideogeneration_amd has no CPU fallback")

@@ -634,11 +634,17 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     for (int s = 0; s < a.nsrc; s++) { if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return -1; kq += round_up(a.src[s].C, HX_KC); }
     a.Kq = kq;
     a.out_scale = (a.precision == PREC_F16X3 || a.precision == PREC_F16X1) ? 1.0f / HX_WSCALE : 1.0f;
-    const int bn = hx_pick_bn(a.Cout);
-    a.Cout_pad = round_up(a.Cout, bn);
+    int bn = hx_pick_bn(a.Cout);
+    a.Cout_pad = round_up(a.Cout, bn);      // (row padding of the packed weights: independent of the tile width chosen below)
     if (a.mask && a.accumulate) return -1;
     if (a.pool_out && (a.accumulate || a.mask)) return -1;
     const int nchunks = kq / HX_KC;
+    // under-filled wide layers (R's gate / SameBlock convolutions on 16x16 .. 32x32 maps, A, D's first stage at batch 8): 64-channel tiles on the same
+    // 128-row packed weights -> twice the workgroups, two co-resident per CU hiding each other's barrier / LDS latencies (one 4-wave workgroup per CU
+    // runs its serial chain of (tap, chunk) steps at ~30 % of the MFMA rate).  Measured, E/R/A/D step: 79.5 -> 78.2 ms, flat for thresholds 256 / 512 / 1024.
+    static const int env_r64 = getenv("CADDY_HX_R64") ? atoi(getenv("CADDY_HX_R64")) : 256;      // A/B aid: workgroup threshold (0 = off)
+    if (env_r64 > 0 && bn == 128 && g_hx_big_override < 0 && !a.pool_out && !a.skip_out && !a.mask &&
+        (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 8) * (a.Cout_pad / 128) <= env_r64) bn = 64;
     // tiles: 128-channel layers -> 16x16 pixels x 128 channels on 8 waves with the 3-deep weight-tile ring when that fills the chip, else
     // 8x16 pixels on 4 waves (R's small feature maps); 16x16 x 64 / 32 channels for the narrower layers
     static const int env_big = getenv("CADDY_HX_BIG") ? atoi(getenv("CADDY_HX_BIG")) : -1;      // A/B aid: 0 never, 1 always (128-channel layers)
