@@ -335,6 +335,24 @@ hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everyth
     }
     return side;
 }
+hipStream_t caddy_ctx::aux_grad_stream() {
+    static const bool off = getenv("CADDY_AUX_STREAM") && atoi(getenv("CADDY_AUX_STREAM")) == 0;      // A/B aid
+    if (dry || off) return stream;
+    if (!astream && !a_tried) { a_tried = true; if (hipStreamCreateWithFlags(&astream, hipStreamNonBlocking) != hipSuccess) astream = nullptr; }
+    if (!astream) return stream;
+    hipEvent_t e = sev();
+    hipEventRecord(e, stream);
+    hipStreamWaitEvent(astream, e, 0);
+    a_dirty = true;
+    return astream;
+}
+void caddy_ctx::join_aux(hipStream_t onto) {
+    if (!astream || !a_dirty || dry) return;
+    hipEvent_t e = sev();
+    hipEventRecord(e, astream);
+    hipStreamWaitEvent(onto, e, 0);
+    if (onto == stream && !in_d) a_dirty = false;
+}
 // switch the driver to the teacher-forced decoder stream (and its private scratch); fork: order it after everything enqueued on the main stream so far
 void caddy_ctx::enter_d(bool fork) {
     if (!dry && !dstream && !d_done) {      // once (the simulator build hands out null streams: everything then runs in order on the caller's stream)
@@ -474,12 +492,15 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             w.precision = (Lp->wq && prec_bwd != PREC_FP32) ? PREC_BF16X3 : PREC_FP32;
             queue_wgrad(Lp, w, px_taps * Lp->pd.Cin * Lp->pd.Cout);
             bool bias_done = !Lp->dbias;
+            bool any_aux = !bias_done;
+            for (int s = 0; s < nseg; s++) any_aux = any_aux || (sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3);
+            hipStream_t as = any_aux ? aux_grad_stream() : stream;      // off the BPTT chain: nothing before the action network's backward / the optimiser reads these
             for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
                 if (!(sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3)) continue;
-                RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, bias_done ? nullptr : Lp->dbias, stream));
+                RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, bias_done ? nullptr : Lp->dbias, as));
                 bias_done = true;
             }
-            if (!bias_done) RUN(pw_colsum(dzv, Lp->dbias, stream));
+            if (!bias_done) RUN(pw_colsum(dzv, Lp->dbias, as));
             for (int s = 0; s < nseg; s++) {
                 if (!sg[s].need_grad) continue;
                 if (sg[s].bcast && Lp->pd.KS == 3) continue;
@@ -788,7 +809,8 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
         if (sh.fn && sh.action) { sc.mode = 2; sc.samples_in = sh.samples_buf; }             // what the backward pass must assume
         if (sh.fn && sh.variation) sc.variations_in = sh.var_buf;
     }
-    if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tp->push_back([=]() { RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
+    if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tp->push_back([=]() { if (first) join_aux(stream);      // d(action / variation inputs) of every time step
+                                                                               RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
 void caddy_ctx::pack_all(bool with_fold) {
@@ -825,6 +847,7 @@ void caddy_ctx::unpack_all() {
 void caddy_ctx::early_gradient_buckets() {
     if (!grads_hook || dry) return;
     hipStream_t s2 = wgrad_stream();
+    join_aux(s2);      // the conv bias gradients of R / D are part of the bucket ranges
     for (ConvL* L : convs) if (L->early_bucket) { RUN(unpack_wgrad(L->pd, L->dwp, s2)); L->early_done = true; }
     for (int i = 0; i < 3; i++) {
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, s2));
@@ -1064,6 +1087,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     if (!c->tape2.empty() && c->use_dstream && !dry) { c->replay_tape2(true); c->tape2_done = true; }
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     c->flush_all_wgrad();
+    c->join_aux(st);
     if (!dry && c->use_side && c->side) {      // join: the packed weight gradients must be complete before they are unpacked
         hipEvent_t e = c->sev();
         hipEventRecord(e, c->side);
@@ -1303,6 +1327,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
 void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
+    if (c && c->astream) { hipStreamSynchronize(c->astream); hipStreamDestroy(c->astream); }
     if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
     delete c;
 }

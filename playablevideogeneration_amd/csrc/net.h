@@ -175,6 +175,12 @@ struct caddy_ctx {
     std::vector<hipEvent_t> sev_pool; size_t sev_used = 0;
     hipEvent_t sev() { if (sev_used == sev_pool.size()) { hipEvent_t e; hipEventCreate(&e); sev_pool.push_back(e); } return sev_pool[sev_used++]; }
     hipStream_t wgrad_stream();
+    // gradients that nothing in the BPTT chain reads -- those of the broadcast action / variation inputs of R's convolutions (consumed by the action network's
+    // backward after the time loop) and the conv bias gradients (consumed by the optimiser) -- leave the critical path: a fourth stream, ordered behind the
+    // compute stream per call, joined before the action network's backward / the gradient buckets / the final unpack
+    hipStream_t astream = nullptr; bool a_tried = false, a_dirty = false;
+    hipStream_t aux_grad_stream();
+    void join_aux(hipStream_t onto);
     void ensure_side();
     // weight gradients of a layer are queued over consecutive BPTT time steps and launched as ONE time-batched kernel (WgradArgs.group_n)
     struct PendingW { WgradArgs first{}; int count = 0; long src_gs[CONV_MAX_SRC] = {0, 0, 0}; long dy_gs = 0; double flops = 0;
