@@ -121,6 +121,18 @@ int caddy_set_stream(caddy_ctx* ctx, void* hip_stream);
  * for its collective.  The remaining ranges are valid when caddy_loss_backward returns (on the ctx stream), as before. */
 typedef void (*caddy_grads_ready_hook)(float* grads, long offset, long count, void* stream, void* user);
 int caddy_set_grads_ready_hook(caddy_ctx* ctx, caddy_grads_ready_hook hook, void* user);
+/* Native data parallelism: the same three reductions issued from C into RCCL (ncclAllReduce over xGMI) on a communicator owned by the context -- replaces
+ * nn.DataParallel's per-step replicate / gather / reduce-add (train.py:67-68).  One process per GPU:
+ *   rank 0: caddy_dp_unique_id(id) -> the 128 bytes travel to every rank (any out-of-band channel, e.g. a torch.distributed broadcast) ->
+ *   every rank: caddy_dp_init(ctx, id, world_size, rank, overlap) [overlap = 1: R / D gradient buckets behind the side stream during the backward] ->
+ *   per step: caddy_forward_full, caddy_loss_backward, caddy_allreduce_grads (the rest + join), caddy_adam_step(..., grad_scale = 1 / world_size).
+ * RCCL is resolved with dlopen at the first call (CADDY_RCCL_LIB, librccl.so of the process, /opt/rocm/lib): caddy_dp_available() says whether one was found. */
+int caddy_dp_available(void);
+int caddy_dp_unique_id(char* out128);
+int caddy_dp_init(caddy_ctx* ctx, const char* id128, int world_size, int rank, int overlap);
+int caddy_allreduce_grads(caddy_ctx* ctx);
+long caddy_dp_bucket_floats(caddy_ctx* ctx);
+int caddy_dp_shutdown(caddy_ctx* ctx);
 /* Evaluation samplers (evaluation/action_sampler.py:14,63; evaluation/action_variation_sampler.py:14), consumed mid-forward exactly where
  * model/main_model/model.py:171-173,189-190 call them.  The hook runs stream-ordered on device pointers inside the workspace:
  *   stage 0 (if provides_samples):    write samples (n, K)    given log_probs (n, K)                      [n = batch * (seq_len - 1)]

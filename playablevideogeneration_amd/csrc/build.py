@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["conv_mfma.hip", "conv_hx.hip", "conv_thin.hip", "conv_narrow.hip", "pointwise.hip", "pack.hip", "head.hip", "perceptual.hip", "net.cpp", "capi_kernels.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_hx.hip", "conv_thin.hip", "conv_narrow.hip", "pointwise.hip", "pack.hip", "head.hip", "perceptual.hip", "net.cpp", "capi_kernels.cpp", "dp_rccl.cpp"]
 LIB = os.path.join(HERE, "libcaddy_hip.so")
 
 
@@ -47,7 +47,7 @@ def build(force=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip",
              "-I", HERE, "-I", os.path.join(ROOT, "include")]
     objs = _compile_objects([hipcc] + flags, os.path.join(HERE, "build"), srcs, headers)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

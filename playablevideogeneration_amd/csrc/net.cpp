@@ -1324,7 +1324,9 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     }
     return c;
 }
+extern "C" int caddy_dp_shutdown(caddy_ctx* c);
 void caddy_ctx_destroy(caddy_ctx* c) {
+    if (c && c->comm) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
     if (c && c->astream) { hipStreamSynchronize(c->astream); hipStreamDestroy(c->astream); }

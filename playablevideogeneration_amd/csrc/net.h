@@ -1,6 +1,7 @@
 // Host-side driver of the CADDY hot path: owns the packed weights, the activation / gradient arenas carved out of the
 // caller's workspace, and a tape that replays the forward graph in reverse for BPTT.
 #pragma once
+#include <algorithm>
 #include <functional>
 #include <string>
 #include <vector>
@@ -133,6 +134,8 @@ struct caddy_ctx {
     long bucket_lo[2] = {0, 0}, bucket_hi[2] = {0, 0}; bool lstm_early_done = false;
     long s2h_lo = 0, s2h_hi = 0;     // state_to_hidden_state_layer: unused by forward_full_model -> its .grad is None there and torch's Adam skips it (no weight decay either)
     void early_gradient_buckets();   // data-parallel reductions of the K x K MI matrix / centroid sums
+    // native data parallelism (dp_rccl.cpp): a communicator owned by the context; the hooks above then point at ncclAllReduce wrappers
+    void* comm = nullptr; int comm_world = 1; std::vector<std::pair<long, long>> comm_buckets; hipStream_t comm_bucket_stream = nullptr;
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)

@@ -64,6 +64,12 @@ def _bind(lib):
     lib.caddy_load_vgg.argtypes = [C.c_void_p, C.c_void_p]
     lib.caddy_set_vgg_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_set_perceptual_prefetch.argtypes = [C.c_void_p, C.c_int]
+    lib.caddy_dp_unique_id.argtypes = [C.c_char_p]
+    lib.caddy_dp_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    lib.caddy_allreduce_grads.argtypes = [C.c_void_p]
+    lib.caddy_dp_bucket_floats.argtypes = [C.c_void_p]
+    lib.caddy_dp_bucket_floats.restype = C.c_long
+    lib.caddy_dp_shutdown.argtypes = [C.c_void_p]
     lib.caddy_set_rollout_fold.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_set_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
@@ -138,8 +144,12 @@ class Engine:
         self._check(self.lib.caddy_set_sampler_hook(self.ctx, C.cast(self._sampler_keepalive, C.c_void_p), None,
                                                     int(action_sampler is not None), int(action_variation_sampler is not None)))
 
-    def enable_data_parallel(self, process_group=None, force=False, overlap=True):
-        """Data parallelism over torch.distributed (RCCL on the MI355X, gloo in the CPU tests), one process per GPU.
+    def enable_data_parallel(self, process_group=None, force=False, overlap=True, native=None):
+        """Data parallelism, one process per GPU.  native (default on the GPU when the library finds an RCCL): the three reductions are issued from C straight
+        into ncclAllReduce on a communicator the context owns (caddy_dp_init; the 128-byte unique id travels through torch.distributed once) -- no Python on the
+        per-step path.  Otherwise torch.distributed hooks (gloo in the CPU tests, or RCCL through torch):
+
+        Data parallelism over torch.distributed (RCCL on the MI355X, gloo in the CPU tests), one process per GPU.
         Registers (a) the all-reduce hook of the small global-batch reductions (centroid sums, MI joint matrix) and (b) with
         `overlap`, the gradient-bucket hook: the dynamics / rendering ranges of the flat gradient buffer (~91 % of the bytes) are
         all-reduced asynchronously as soon as the time loop's backward is done, behind the side HIP stream, while the backward of A
@@ -148,8 +158,23 @@ class Engine:
         world = dist.get_world_size(process_group)
         self._dp_group = process_group
         self._dp_active = True
+        self._dp_native = False
         self._early = []                     # (offset, count, work) of the buckets already in flight
         if world == 1 and not force:
+            return
+        if native is None:
+            native = self.device.type == "cuda" and hasattr(self.lib, "caddy_dp_available") and self.lib.caddy_dp_available() == 1
+        if native:
+            rank = dist.get_rank(process_group)
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                self._check(self.lib.caddy_dp_unique_id(buf))
+            box = [buf.raw if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            self._stream()
+            self._check(self.lib.caddy_dp_init(self.ctx, box[0], world, rank, int(bool(overlap))))
+            self._dp_native = True
             return
         base = self._ws_raw.data_ptr()
 
@@ -189,6 +214,10 @@ class Engine:
     def allreduce_gradients(self):
         """Sum the flat gradient buffer over the ranks: waits for the buckets started during `loss_backward` (the current stream
         waits, not the host) and all-reduces what is left (E, A, state_to_hidden_state)."""
+        if getattr(self, "_dp_native", False):
+            self._stream()
+            self._check(self.lib.caddy_allreduce_grads(self.ctx))
+            return
         import torch.distributed as dist
         group = getattr(self, "_dp_group", None)
         early = sorted(getattr(self, "_early", []), key=lambda e: e[0])

@@ -85,7 +85,12 @@ def _dp_worker(rank, world, port, out, gpu=False):
     local = eng.grads.clone()
     dist.all_reduce(eng.grads)
     eng2 = fresh(overlap=True)                      # bench.py's path: R / D buckets start during loss_backward, the rest afterwards
-    assert len(eng2._early) == 2 and sum(c for _, c, _ in eng2._early) > 0.5 * eng2.grads.numel()
+    if getattr(eng2, "_dp_native", False):          # MI355X: the library's own RCCL communicator (dp_rccl.cpp) -- no Python on the per-step path
+        eng2.lib.caddy_dp_bucket_floats.restype = __import__("ctypes").c_long
+        assert eng2.lib.caddy_dp_bucket_floats(eng2.ctx) > 0.5 * eng2.grads.numel()
+        eng2.hook_host_seconds, eng2.hook_calls = 0.0, 0
+    else:
+        assert len(eng2._early) == 2 and sum(c for _, c, _ in eng2._early) > 0.5 * eng2.grads.numel()
     eng2.allreduce_gradients()
     eng.adam_step(1, grad_scale=1.0 / world)
     if gpu:

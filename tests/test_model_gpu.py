@@ -83,7 +83,7 @@ def test_allreduce_hook_over_rccl_world1(lib):
         calls = []
 
         def prep(eng):
-            eng.enable_data_parallel(force=True)
+            eng.enable_data_parallel(force=True, native=False)      # the torch.distributed hook path (the native one: test_native_rccl_data_parallel_world1)
             inner = eng._hook_keepalive
             calls.append(inner)
         eng, _ = M.full_case("full_main_s1", lib, "cuda", prep=prep)
@@ -99,6 +99,43 @@ def test_allreduce_hook_over_rccl_world1(lib):
         per_call_us = 1e6 * eng.hook_host_seconds / max(1, eng.hook_calls)
         print("bucket hook host cost per call [us]:", per_call_us)
         assert eng.hook_calls == 2 and per_call_us < 5000
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_data_parallel_world1(lib):
+    """The C-level data-parallel path (dp_rccl.cpp: communicator owned by the context, ncclAllReduce for the centroid sums / MI joint matrix inside the
+    kernels' stream order, gradient buckets behind the side stream, caddy_allreduce_grads for the rest) on a real RCCL communicator of size 1: results must
+    still equal the reference golden, the buckets must have gone through RCCL during the backward, and the sum over one rank is the identity."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=0, world_size=1)      # only carries the unique id; the collectives themselves are the library's own
+    try:
+        assert lib.caddy_dp_available() == 1
+        eng, _ = M.full_case("full_main_s1", lib, "cuda", prep=lambda e: e.enable_data_parallel(force=True, native=True))
+        assert eng._dp_native
+        n_bucket = lib.caddy_dp_bucket_floats(eng.ctx)
+        assert n_bucket > 0.5 * eng.grads.numel(), n_bucket
+        torch.cuda.synchronize()
+        before = eng.grads.clone()
+        eng.allreduce_gradients()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, before) and lib.caddy_dp_bucket_floats(eng.ctx) == 0
+        eng.adam_step(1)
+        # a second step through the same communicator (stream / event reuse)
+        c, _z = M.H.load_case("full_main_s1")
+        d, P, obs = M.H.inputs_of(c)
+        g = torch.Generator().manual_seed(3)
+        noise = {"eps_states": torch.randn(c["B"] * c["T"], c["Da"], generator=g), "eps_dirs": torch.randn(c["B"] * (c["T"] - 1), c["Da"], generator=g),
+                 "gumbel_uniform": torch.rand(c["B"] * (c["T"] - 1), c["K"], generator=g),
+                 "eps_states_rec": torch.randn(c["B"] * c["T"], c["Da"], generator=g), "eps_dirs_rec": torch.randn(c["B"] * (c["T"] - 1), c["Da"], generator=g)}
+        eng.forward_full(obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
+        l = eng.loss_backward(M.H.LOSS_W)
+        eng.allreduce_gradients()
+        eng.adam_step(2)
+        torch.cuda.synchronize()
+        assert l["total"] == l["total"] and torch.isfinite(eng.params).all()
     finally:
         dist.destroy_process_group()
 
