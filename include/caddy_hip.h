@@ -195,6 +195,9 @@ int caddy_profile_end(caddy_ctx* ctx, double* out /* 4 * CADDY_PROFILE_FAMILIES 
 /* per-launch records since caddy_profile_begin (call before caddy_profile_end): 7 doubles each
  * {kind 0 fwd / 1 dgrad / 2 wgrad / 3 VGG19 forward / 4 VGG19 dgrad, output pixels, K (padded input channels), Cout, kernel size, algorithmic FLOPs, ms} */
 int caddy_profile_records(caddy_ctx* ctx, double* out, int max_records);
+/* phase marks recorded on the ctx stream during profiled steps (forward: pack / E on the ground truth / A / teacher-forced steps / closed-loop steps / A on the
+ * reconstructions; backward in reverse): names_out = max x 48 bytes, ms_out[i] = time since the previous mark.  Call before caddy_profile_end. */
+int caddy_profile_phases(caddy_ctx* ctx, char* names_out, float* ms_out, int max);
 
 /* --- introspection (debug / tests): the i-th intermediate activation (grad=0) or its gradient (grad=1) of the last
  *     forward, converted to (N,C,H,W) --- */

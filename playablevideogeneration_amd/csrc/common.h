@@ -135,6 +135,8 @@ struct WgradArgs {
 enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW,
        CK_HX_128, CK_HX_64, CK_HX_32, CK_WGRAD_HX, CK_HX_128_8W, CK_COUNT };      // CK_HX_128_8W: the 16x16x128 tile on 8 waves (VGG19, wide well-filled layers); CK_HX_128: 8x16x128 on 4 waves
 extern thread_local int g_last_conv_kernel;
+// rows a caller must provide in ConvArgs.stats: the smallest pixel tile (8 x 16) of the epilogue path, at least the 512 workgroups of the slab-reduce path
+static inline long conv_stats_tiles_cap(int N, int H, int W) { long t = (long)N * cdiv(H, 8) * cdiv(W, 16); return t > 512 ? t : 512; }
 extern thread_local int g_last_conv_stats_tiles;      // pixel tiles of the last conv_fwd_launch that wrote ConvArgs.stats (0 = none written)
 bool conv_src_lazy_ok(const ConvArgs& a);             // will conv_fwd_launch run this launch on a kernel that applies ConvSrc.bn_* ?
 bool wgrad_src_lazy_ok(const WgradArgs& a);           // ... conv_wgrad_launch ?
@@ -151,7 +153,7 @@ int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
 extern int g_hx_big_override;
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
-                             const float* res, long res_sn, int res_ld, hipStream_t st);
+                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

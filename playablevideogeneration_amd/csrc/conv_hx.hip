@@ -677,7 +677,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     }
     static const int env_xcd = getenv("CADDY_HX_XCD") ? atoi(getenv("CADDY_HX_XCD")) : 1;      // A/B aid
     a.xcd_map = env_xcd;
-    // BatchNorm partial sums from the epilogue: EP = 0 instances with the whole K range in one workgroup only (split launches: the caller falls back to its own reduction)
+    // BatchNorm partial sums: from the epilogue of EP = 0 instances when one workgroup holds the whole K range, from the slab reduce of a split launch otherwise
+    float* const stats_req = a.stats; const int stats_req_ld = a.stats_ld;
+    const long stats_cap = conv_stats_tiles_cap(a.N, a.H, a.W);                // tiles the caller sized the buffer for
     if (a.stats && (a.splitk != 1 || a.mask || a.pool_out || a.skip_out || a.precision == PREC_F16X1 || a.precision == PREC_BF16X1)) a.stats = nullptr;
     g_last_conv_stats_tiles = a.stats ? (int)((long)a.N * tx * ty) : 0;
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
@@ -725,7 +727,8 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
 #undef HX_LAUNCH
 #undef HX_LAUNCH_DEEP
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
-    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
+    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
+                                                 stats_req, stats_req_ld, stats_cap);
     return 1;
 }
 

@@ -352,6 +352,43 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long str
     }
 }
 
+// the same with the BatchNorm partial sums of the reduced tensor (ConvArgs.stats): a workgroup owns PPB consecutive pixels, thread = (pixel row tid / C4, channel quad
+// tid % C4) with C4 | 256, so that every thread keeps one channel quad; the pixel rows are folded through LDS and workgroup b writes stats[(b * stats_ld + c) * 2 + {0, 1}]
+// -- the layout k_bn_finalize_tiles reads, with "tiles" = workgroups.  (Split launches are exactly the under-filled ones -- R's 16x16 / 32x32 maps, E / A on one time
+// step's frames -- where a separate statistics pass costs as much as the convolution.)
+__global__ __launch_bounds__(256) void k_split_reduce_stats(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld,
+                                                            int ppb, float* stats, int stats_ld) {
+    __shared__ float sh[256 * 8];
+    const int C4 = ldc >> 2, rows = 256 / C4;
+    const int tid = threadIdx.x, pr = tid / C4, c = (tid - pr * C4) * 4;
+    const long p0 = (long)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pr < rows)
+        for (long p = p0 + pr; p < p1; p += rows) {
+            const float* q = scr + p * ldc + c;
+            float4 v = *reinterpret_cast<const float4*>(q);
+            for (int z = 1; z < splits; z++) { float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+            const long n = p / HW;
+            float* o = out + n * out_sn + (p - n * HW) * (long)out_ld + c;
+            if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
+            else { if (c < C) o[0] = v.x; if (c + 1 < C) o[1] = v.y; if (c + 2 < C) o[2] = v.z; }
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            s[4] = fmaf(v.x, v.x, s[4]); s[5] = fmaf(v.y, v.y, s[5]); s[6] = fmaf(v.z, v.z, s[6]); s[7] = fmaf(v.w, v.w, s[7]);
+        }
+    for (int e = 0; e < 8; e++) sh[tid * 8 + e] = s[e];
+    __syncthreads();
+    int top = 1;
+    while (top < rows) top <<= 1;
+    for (int half = top >> 1; half >= 1; half >>= 1) {
+        if (pr < half && pr + half < rows)
+            for (int e = 0; e < 8; e++) sh[tid * 8 + e] += sh[((pr + half) * C4 + (tid - pr * C4)) * 8 + e];
+        __syncthreads();
+    }
+    if (pr == 0)
+        for (int e = 0; e < 4; e++)
+            if (c + e < C) { float* o = stats + ((long)blockIdx.x * stats_ld + c + e) * 2; o[0] = sh[tid * 8 + e]; o[1] = sh[tid * 8 + 4 + e]; }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // wgrad.  GEMM-M = output channels o, GEMM-N = concatenated input channels k (one tap per workgroup), reduction over
 // pixels in steps of 16; LDS tiles are [pixel][channel] so global->LDS is a straight float4 copy and the MFMA operand
@@ -776,7 +813,19 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     return 0;
 }
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
-                             const float* res, long res_sn, int res_ld, hipStream_t st) {
+                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats, int stats_ld, long stats_cap_tiles) {
+    const int C4 = ldc >> 2;
+    if (stats && !bias && !act && !res && C4 <= 256 && 256 % C4 == 0) {      // BatchNorm partial sums of the reduced tensor (conv -> BatchNorm chains carry no bias / activation)
+        const int rows = 256 / C4;
+        long ppb = rows * 4;                                                  // >= 4 pixels per thread ...
+        while (cdiv(P, ppb) > 512) ppb *= 2;                                  // ... and at most 512 workgroups
+        const long nb = cdiv(P, ppb);
+        if (nb <= stats_cap_tiles) {
+            hipLaunchKernelGGL(k_split_reduce_stats, dim3((unsigned)nb), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, (int)ppb, stats, stats_ld);
+            g_last_conv_stats_tiles = (int)nb;
+            return 0;
+        }
+    }
     long items = P * (ldc >> 2);
     hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, bias, act,
                        res, res_sn, res_ld);

@@ -465,7 +465,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
         want_stats = false;
         if (epi_stats && training && !into && a.wq) {
             const int ldp = round_up(L.pd.Cout, 4);
-            float* part = falloc((size_t)N * cdiv(H, 8) * cdiv(W, 16) * ldp * 2);
+            float* part = falloc((size_t)conv_stats_tiles_cap(N, H, W) * ldp * 2);
             a.stats = part; a.stats_ld = ldp;
             ts_slot = &stats_ring[stats_next]; stats_next ^= 1;
             *ts_slot = TileStats{out.d, part, 0, ldp};
@@ -871,7 +871,9 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
+    c->mark("fwd:begin");
     c->pack_all();
+    c->mark("fwd:packed");
     caddy_noise z{}; if (nz) z = *nz;
     // observations -> NHWC
     c->obs = c->alloc(B * T, H, W, 3 * S);
@@ -879,14 +881,17 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     if (g.perceptual && training) vgg_gt_prefetch(c, T - 1, 1);      // VGG19 features of the ground-truth frames: side stream, beside the forward pass
     else c->gt_prefetched = false;
     c->x65_gt = c->encode(c->obs, false, nullptr);
+    c->mark("fwd:E(gt)");
     c->action_net(c->x65_gt, c->head1, z.eps_states, z.eps_dirs, z.gumbel_uniform, true, samples_in, variations_in);
+    c->mark("fwd:A1");
     c->rec_x65 = c->alloc(B * T, c->hs, c->ws, 65, 68);
     c->hidden = c->alloc(B * (T - 1), c->hs, c->ws, g.hidden);
     for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(B * (T - 1), H >> r, W >> r, 3);
     for (int t = 0; t < gt_init && t < T; t++) c->copy_op(tslice(c->x65_gt, B, T, t), tslice(c->rec_x65, B, T, t));
     T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
-    if (c->recording) c->tape.push_back([c]() { c->flush_all_wgrad(); c->early_gradient_buckets(); });      // runs AFTER the time loop's backward: the queued chunks (and the R / D gradient buckets) overlap with the A / E tail
+    if (c->recording) c->tape.push_back([c]() { c->mark("bwd:time loop"); c->flush_all_wgrad(); c->early_gradient_buckets(); });      // runs AFTER the time loop's backward: the queued chunks (and the R / D gradient buckets) overlap with the A / E tail
     for (int t = 0; t < T - 1; t++) {
+        if (t == gt_init - 1) { c->mark("fwd:teacher-forced steps"); if (c->recording) c->tape.push_back([c]() { c->mark("bwd:closed-loop steps"); }); }
         T4 state = chan(tslice(c->rec_x65, B, T, t), 0, 64);
         T4 aux = tslice(aux_all, B, T - 1, t);
         T4 hslot = tslice(c->hidden, B, T - 1, t);
@@ -920,11 +925,14 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
             c->encode(fb, true, &dst);
         }
     }
+    c->mark("fwd:closed-loop steps");
+    if (c->recording) c->tape.push_back([c]() { c->mark("bwd:A2"); });
     c->action_net(c->rec_x65, c->head2, z.eps_states_rec, z.eps_dirs_rec, nullptr, false, nullptr, nullptr);
     c->q_prob = c->falloc((size_t)B * (T - 1) * g.actions + 256);
     c->fwd_off = c->act.off;
     if (dry && g.perceptual) { T4 gi[3]; VggLevels lv; c->alloc_gt_images(gi, T - 1); vgg_perceptual(c, 1.0, gi, &lv); c->act.off = c->fwd_off; }      // workspace sizing
     c->end_forward();
+    c->mark("fwd:A2 + join");
     return finish(c);
 }
 
@@ -1022,6 +1030,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     const int B = g.batch, T = g.seq_len, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
     hipStream_t st = c->stream;
+    c->mark("bwd:begin");
     const bool perc = c->cfg.perceptual && (lc->perceptual != 0.0 || lc->perceptual_log);
     if (lc->perceptual != 0.0 && !c->cfg.perceptual) { set_error("caddy_loss_cfg.perceptual != 0 needs a context created with caddy_config.perceptual = 1"); return -2; }
     if (perc && !c->vgg.loaded) { set_error("perceptual loss requested but no VGG19 weights were loaded (caddy_load_vgg)"); return -2; }
@@ -1082,6 +1091,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
         return finish(c);
     }
+    c->mark("bwd:losses (+ VGG19)");
     // the decoder backward of the teacher-forced steps only needs the loss seeds: start it on its own stream, beside the serial BPTT chain
     c->tape2_done = false;
     if (!c->tape2.empty() && c->use_dstream && !dry) { c->replay_tape2(true); c->tape2_done = true; }
@@ -1093,7 +1103,9 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         hipEventRecord(e, c->side);
         hipStreamWaitEvent(st, e, 0);
     }
+    c->mark("bwd:A1 + E(gt)");
     c->unpack_all();
+    c->mark("bwd:join + unpack");
     if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
     return finish(c);
 }
@@ -1392,7 +1404,19 @@ int caddy_generate_next(caddy_ctx* c, const float* observation, int action, cons
     if (c->lstm[0].h.d != c->lstm[0].ph.d || c->lstm[0].h.d == nullptr) { set_error("call caddy_start_inference first"); return -2; }
     return generate_next(c, observation, action, variation, frame_out, obs_out);
 }
-int caddy_profile_begin(caddy_ctx* c) { c->prof = true; c->prof_recs.clear(); c->ev_used = 0; return 0; }
+int caddy_profile_begin(caddy_ctx* c) { c->prof = true; c->prof_recs.clear(); c->phases.clear(); c->ev_used = 0; return 0; }
+// phase marks of the profiled steps: names_out receives `max` x 48-byte names, ms_out the time since the previous mark on the main stream; returns the count
+int caddy_profile_phases(caddy_ctx* c, char* names_out, float* ms_out, int max) {
+    hipStreamSynchronize(c->stream);
+    int n = 0;
+    for (size_t i = 0; i < c->phases.size() && n < max; i++, n++) {
+        float ms = 0.f;
+        if (i > 0) hipEventElapsedTime(&ms, c->phases[i - 1].e, c->phases[i].e);
+        snprintf(names_out + 48 * n, 48, "%s", c->phases[i].name);
+        ms_out[n] = ms;
+    }
+    return n;
+}
 int caddy_profile_records(caddy_ctx* c, double* out, int max_records) {   // per launch: {kind, P, K, Cout, KS, flops, ms}; returns count
     hipStreamSynchronize(c->stream);
     if (c->side) hipStreamSynchronize(c->side);

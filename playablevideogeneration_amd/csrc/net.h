@@ -171,6 +171,10 @@ struct caddy_ctx {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     hipEvent_t ev() { if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); } return ev_pool[ev_used++]; }
+    // phase marks on the main stream while profiling (caddy_profile_phases): where the wall time of a step goes
+    struct PhaseMark { const char* name; hipEvent_t e; };
+    std::vector<PhaseMark> phases;
+    void mark(const char* name) { if (prof && !dry && !in_d) { hipEvent_t e = ev(); hipEventRecord(e, stream); phases.push_back({name, e}); } }
     int timed_conv_fwd(const ConvArgs& a, double flops);
     int timed_conv_wgrad(const WgradArgs& a, double flops);
     // weight gradients run on a side stream, off the BPTT critical path (dgrad chain); joined before unpack_all()

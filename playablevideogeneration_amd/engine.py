@@ -457,6 +457,13 @@ class Engine:
         n = self.lib.caddy_profile_records(C.c_void_p(self.ctx), buf, max_records)
         return [tuple(buf[7 * i + j] for j in range(7)) for i in range(n)]
 
+    def profile_phases(self, max_marks=256):
+        """[(phase, ms since the previous mark on the main stream)] of the profiled steps; call before profile_end()"""
+        names = C.create_string_buffer(48 * max_marks)
+        ms = (C.c_float * max_marks)()
+        n = self.lib.caddy_profile_phases(C.c_void_p(self.ctx), names, ms, max_marks)
+        return [(names.raw[48 * i:48 * (i + 1)].split(b"\0")[0].decode(), ms[i]) for i in range(n)]
+
     def profile_end(self):
         """-> {kernel: (launches, algorithmic FLOPs, milliseconds, algorithmic bytes)}, HIP events on the launch stream."""
         out = (C.c_double * (4 * len(self.CONV_FAMILIES)))()

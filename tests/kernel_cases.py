@@ -603,7 +603,7 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     return err
 
 
-def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big=-1, groups=1):
+def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big=-1, groups=1, split=False):
     """The BatchNorm fusion of round 3 as one chain at kernel level (reference: conv -> BatchNorm2d(train) -> LeakyReLU(0.2) -> conv, e.g. conv1 / bn1 /
     conv2 of model/layers/residual_block.py:51-61), against torch autograd in fp64:
       x0 (raw output of a producing conv) --[statistics + finalisation]--> (mean, invstd, scale, shift)
@@ -611,7 +611,8 @@ def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big
           + per-tile partial sums of y from the epilogue (ConvArgs.stats) -> caddy_k_bn_finalize_tiles == batch statistics of y
       dW = wgrad(dy, act(x0 * scale + shift))                        k_wgrad_hx with ConvSrc.bn_*
       d(x0) via the backward of the never-materialised BatchNorm      caddy_k_bn_bwd_lazy on the dgrad's output
-    groups > 1: the batch is `groups` independent BatchNorm calls (time-batched launch, ConvSrc.bn_gn / bn_gs): statistics per group."""
+    groups > 1: the batch is `groups` independent BatchNorm calls (time-batched launch, ConvSrc.bn_gn / bn_gs): statistics per group.
+    split: give the launcher slab scratch -- an under-filled launch then splits K and the partial sums come from the slab reduce (k_split_reduce_stats)."""
     lib.caddy_k_hx_weight_bytes.restype = C.c_long
     g = torch.Generator().manual_seed(seed)
     st = stream(dev)
@@ -677,9 +678,12 @@ def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big
     out = torch.full((N, H, W, out_ld), 9.0, device=dev)
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
     ldp = round_up(Cout, 4)
-    max_tiles = N * ((H + 7) // 8) * ((W + 15) // 16)
+    max_tiles = max(512, N * ((H + 7) // 8) * ((W + 15) // 16))          # common.h: conv_stats_tiles_cap
     part = torch.full((max_tiles * ldp * 2,), float("nan"), device=dev)
     a.stats, a.stats_ld = part.data_ptr(), ldp
+    if split:
+        scr = torch.zeros(16 * N * H * W * round_up(Cout, 4), device=dev)
+        a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
     lib.caddy_k_hx_force_big(big)
     try:
         assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0

@@ -139,6 +139,7 @@ def test_batchnorm_fused_into_convolutions_small():
     K.hx_lazy_bn_case(lib, "cpu", N=1, H=9, W=17, Cin=64, Cout=33, act=0, seed=1)
     K.hx_lazy_bn_case(lib, "cpu", N=1, H=20, W=18, Cin=40, Cout=130, big=1, seed=2)
     K.hx_lazy_bn_case(lib, "cpu", N=4, H=8, W=16, Cin=32, Cout=64, groups=2, seed=3)
+    K.hx_lazy_bn_case(lib, "cpu", N=2, H=8, W=16, Cin=96, Cout=64, split=True, seed=4)       # under-filled: split K, statistics from the slab reduce
 
 
 def test_wgrad_hx_split_bf16_small():

@@ -118,6 +118,8 @@ def test_conv_hx_forward(lib, kw):
     dict(N=3, H=26, W=20, Cin=64, Cout=65, seed=2),                # Breakout state resolution: ragged tiles, channel tail
     dict(N=40, H=64, W=64, Cin=128, Cout=128, groups=5, seed=3),   # five time steps in one launch: per-step statistics, 8-wave tiles
     dict(N=16, H=32, W=32, Cin=64, Cout=64, groups=2, big=0, seed=4),
+    dict(N=8, H=16, W=16, Cin=256, Cout=128, aux_c=9, split=True, seed=5),      # R's middle block on 16x16 maps: split K, statistics from the slab reduce
+    dict(N=8, H=32, W=32, Cin=64, Cout=64, split=True, seed=6),                 # E on one time step's frames, 32x32
 ])
 def test_batchnorm_fused_into_convolutions(lib, kw):
     K.hx_lazy_bn_case(lib, "cuda", **kw)

@@ -19,7 +19,10 @@ def step():
     eng.loss_backward(dict(configs.LOSS_WEIGHTS, perceptual=0.0))      # model layers only (the VGG19 groups are reported by bench.py)
 step(); step()
 eng.profile_begin(); step()
-recs = eng.profile_records(); eng.profile_end()
+recs = eng.profile_records()
+for name, ms in eng.profile_phases():
+    print(f"phase {name:32s} {ms:8.2f} ms")
+eng.profile_end()
 agg = collections.OrderedDict()
 for kind, P, Kc, Cout, KS, fl, ms in recs:
     k = (int(kind), int(P), int(Kc), int(Cout), int(KS))
