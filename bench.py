@@ -428,8 +428,8 @@ def run(a, dev, lib=None, backend="nccl"):
             res["rollout"] = rollout_fps(dev)
             log(f"roll-out: {res['rollout']['value']:.1f} frames/s")
         if world == 1 and extra and not getattr(a, "no_plugin", False) and on_gpu:
-            # (after the roll-out: a roll-out measured in the same process AFTER this leg ran at a quarter of its rate on the round-3 boxes -- an
-            #  interaction between the leg's leftovers and the graph-replay path that is not understood yet; play.py is its own process)
+            # (after the roll-out: the ROCm runtime multiplexes HIP streams onto 4 hardware queues; with this leg's streams -- prefetcher, side, decoder -- still alive
+            #  in the process, the roll-out's graph stream shares a queue with one of them and ran at a quarter of its rate.  play.py is its own process.)
             res["plugin"] = plugin_leg(wl, dev, a.steps, a.warmup, perc)
             res["plugin"]["vs_engine_step"] = res["plugin"]["ms_per_step"] / ms_step
             log(f"plugin path: {res['plugin']['ms_per_step']:.1f} ms/step ({res['plugin']['vs_engine_step']:.3f} x the engine-level step)")

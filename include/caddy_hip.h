@@ -63,6 +63,8 @@ typedef struct caddy_loss_cfg {
     int update_mi_ema;
     double perceptual;
     int perceptual_log;
+    int diagnostics;    /* != 0: also evaluate the logging-only scalars of the reference's loss_info (trainer.py:475-491, :358-375) on the device, into
+                           losses_host[CADDY_DIAG_0 ...]: no tensor leaves the GPU and no extra host synchronisation is needed for them */
 } caddy_loss_cfg;
 
 /* losses_host slots.  CADDY_LOSS_PERCEPTUAL = avg_perceptual_loss, _TERM = loss_component_perceptual_loss (trainer.py:505,512);
@@ -70,7 +72,11 @@ typedef struct caddy_loss_cfg {
  * reference logs it (in-place aliasing at training/losses.py:483-487, which also makes levels 1..4 count twice in the term). */
 enum { CADDY_LOSS_TOTAL = 0, CADDY_LOSS_REC, CADDY_LOSS_STATES, CADDY_LOSS_ENTROPY, CADDY_LOSS_DIRKL, CADDY_LOSS_MI,
        CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2,
-       CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12, CADDY_LOSS_PERC_R0 = 16, CADDY_LOSS_SLOTS = 40 };
+       CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12, CADDY_LOSS_PERC_R0 = 16,
+       /* caddy_loss_cfg.diagnostics: samples_entropy, action_distribution_entropy, states_magnitude, hidden_states_magnitude, action_directions_{mean,variance}_magnitude,
+        * reconstructed_action_directions_{mean,variance}_magnitude, action_directions_reconstruction_error, reconstructed_action_directions_kl_loss,
+        * centroids_mean_magnitude, average_centroids_distance, average_action_variations_norm_l2, action_variations_mean -- in this order */
+       CADDY_DIAG_0 = 40, CADDY_DIAG_COUNT = 14, CADDY_LOSS_SLOTS = 56 };
 
 /* Output ids of caddy_get_output: 0..19 = positions of the 20-tuple returned by Model.forward_full_model
  * (model/main_model/model.py:280-286); 100+r = r-th entry of the multi-resolution list (tuple position 1). */

@@ -5,7 +5,7 @@
 
 // LOSS_PERC_R0 + 6 r: perceptual_loss_r{r}; + 1 + l: perceptual_loss_r{r}_l{l} (l = 0 aliases the total, as in the reference -- perceptual.hip)
 enum { LOSS_TOTAL = 0, LOSS_REC, LOSS_STATES, LOSS_ENTROPY, LOSS_DIRKL, LOSS_MI, LOSS_STATEKL, LOSS_HIDDEN, LOSS_L1_R0, LOSS_L1_R1, LOSS_L1_R2,
-       LOSS_PERCEPTUAL = 11, LOSS_PERCEPTUAL_TERM = 12, LOSS_PERC_R0 = 16, LOSS_SLOTS = 40 };
+       LOSS_PERCEPTUAL = 11, LOSS_PERCEPTUAL_TERM = 12, LOSS_PERC_R0 = 16, LOSS_DIAG_0 = 40, LOSS_SLOTS = 56 };
 
 struct LossWeights { double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda, perceptual; };
 
@@ -53,7 +53,8 @@ struct SmallLossArgs {
     double* acc;
 };
 
-int head_set_aux(float* aux, int action, const float* variation /* nullable: zeros */, int K, int Da, hipStream_t st);   // [one-hot(action) | variation | 0]
+int head_rollout_in(const float* obs, float* o_nhwc, int HW, int C, int ld, float* aux, int action, const float* variation, int K, int Da, hipStream_t st);
+int head_rollout_out(const float* f_nhwc, int fld, const float* obs, float* frame_out, float* obs_out, int HW, int C, hipStream_t st);
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st);
 int head_forward(const HeadBufs& h, const HeadParams& p, int B, int T, hipStream_t st);
 int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int NS, float* cen_sums, allreduce_hook_t hook, void* user, const SamplerHooks* sh, hipStream_t st);
@@ -61,5 +62,8 @@ int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, in
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out /* nullable: resized ground truth (N,H,W,3) pitch 4 */, hipStream_t st);
 int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, hipStream_t st);
 int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStream_t st);
+// logging-only scalars of the reference's loss_info (trainer.py:475-491) into acc[LOSS_DIAG_0 ...]; a = first A call, r = second (reconstructed states)
+struct DiagArgs { const float *samples, *ddist, *rdist, *variations, *centroids; int NS, K, Da; double* acc; };
+int loss_diagnostics(const DiagArgs& d, const TV& states, const TV& hidden, hipStream_t st);
 struct VggLevels;
 int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, const VggLevels* lv /* nullable */, hipStream_t st);

@@ -398,12 +398,37 @@ __global__ void k_softmax_rows(const float* logits, float* prob, float* logp, in
 }
 }  // namespace
 
-__global__ void k_set_aux(float* aux, int action, const float* variation, int K, int Da) {
-    const int i = threadIdx.x;
-    if (i < AUX_LD) aux[i] = i == action ? 1.f : ((variation && i >= K && i < K + Da) ? variation[i - K] : 0.f);
+// Roll-out boundary kernels (model.py:570-607): ONE launch in front of the captured per-frame graph -- the caller's (3S, H, W) observation into the static NHWC
+// buffer the graph reads, and the one-hot action + variation row -- and ONE behind it -- the (H, W, 3|pitch 4) frame into the caller's (3, H, W) frame and
+// obs' = cat[frame, observation[:-3]] (model.py:605).  They replace three device-to-device copies, the two layout kernels, two copy kernels and k_set_aux.
+__global__ __launch_bounds__(256) void k_rollout_in(const float* obs, float* o, int HW, int C, int ld, float* aux, int action, const float* variation, int K, int Da) {
+    if (blockIdx.x == 0 && threadIdx.x < AUX_LD) {
+        const int i = threadIdx.x;
+        aux[i] = i == action ? 1.f : ((variation && i >= K && i < K + Da) ? variation[i - K] : 0.f);
+    }
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        float* q = o + p * ld;
+        for (int c = 0; c < C; c++) q[c] = obs[(long)c * HW + p];
+        for (int c = C; c < ld; c++) q[c] = 0.f;
+    }
 }
-int head_set_aux(float* aux, int action, const float* variation, int K, int Da, hipStream_t st) {
-    hipLaunchKernelGGL(k_set_aux, dim3(1), dim3(64), 0, st, aux, action, variation, K, Da);
+__global__ __launch_bounds__(256) void k_rollout_out(const float* f, int fld, const float* obs, float* frame_out, float* obs_out, int HW, int C) {
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const float* q = f + p * fld;
+        const float r = q[0], g = q[1], b = q[2];
+        frame_out[p] = r; frame_out[HW + p] = g; frame_out[2L * HW + p] = b;
+        if (obs_out) {
+            obs_out[p] = r; obs_out[HW + p] = g; obs_out[2L * HW + p] = b;
+            for (int c = 3; c < C; c++) obs_out[(long)c * HW + p] = obs[(long)(c - 3) * HW + p];
+        }
+    }
+}
+int head_rollout_in(const float* obs, float* o_nhwc, int HW, int C, int ld, float* aux, int action, const float* variation, int K, int Da, hipStream_t st) {
+    hipLaunchKernelGGL(k_rollout_in, dim3(cdiv(HW, 256)), dim3(256), 0, st, obs, o_nhwc, HW, C, ld, aux, action, variation, K, Da);
+    return 0;
+}
+int head_rollout_out(const float* f_nhwc, int fld, const float* obs, float* frame_out, float* obs_out, int HW, int C, hipStream_t st) {
+    hipLaunchKernelGGL(k_rollout_out, dim3(cdiv(HW, 256)), dim3(256), 0, st, f_nhwc, fld, obs, frame_out, obs_out, HW, C);
     return 0;
 }
 int head_softmax(const float* logits, float* prob, float* logp, int NS, int K, hipStream_t st) {
@@ -449,6 +474,75 @@ int loss_mse(const TV& a, const TV& b, const TV& db, float gscale, double* acc, 
     long items = (long)a.N * a.H * a.W * a.C;
     long blocks = (items + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_loss_mse, dim3((unsigned)blocks), dim3(256), 0, st, a, b, db, gscale, acc);
+    return 0;
+}
+// sum |x| over a view -> acc (atomic, one per block)
+__global__ __launch_bounds__(256) void k_abs_sum(TV a, double* acc) {
+    __shared__ double sh[8];
+    const int HW = a.H * a.W, C = a.C;
+    const long items = (long)a.N * HW * C;
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        long q = i / C; int c = (int)(i - q * C);
+        long n = q / HW; long pix = q - n * HW;
+        s += (double)fabsf(a.p[n * a.sn + pix * a.ld + c]);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+// the small action tensors: one block, thread-strided rows, block sums in fp64.  (log p of EntropyProbabilityLoss carries no epsilon, as in the reference: losses.py:359-376)
+__global__ __launch_bounds__(256) void k_diag_small(DiagArgs d, double n_states, double n_hidden) {
+    __shared__ double sh[8];
+    __shared__ double colsum[16];
+    const int K = d.K, Da = d.Da, NS = d.NS, tid = threadIdx.x;
+    double ent = 0, dm = 0, dv_ = 0, rm = 0, rv = 0, err = 0, kl = 0, vn = 0, vm = 0;
+    if (tid < 16) colsum[tid] = 0.0;
+    __syncthreads();
+    double cs[16];
+    for (int k = 0; k < K; k++) cs[k] = 0.0;
+    for (int n = tid; n < NS; n += 256) {
+        for (int k = 0; k < K; k++) { const float p = d.samples[n * K + k]; ent -= (double)(p * logf(p)); cs[k] += p; }
+        double nrm = 0.0, klr = 0.0;
+        for (int j = 0; j < Da; j++) {
+            const float m = d.ddist[n * 2 * Da + j], v = d.ddist[n * 2 * Da + Da + j], m2 = d.rdist[n * 2 * Da + j], v2 = d.rdist[n * 2 * Da + Da + j];
+            dm += fabsf(m); dv_ += fabsf(v); rm += fabsf(m2); rv += fabsf(v2); err += (double)(m2 - m) * (m2 - m);
+            klr += 1.0 + (double)logf(v2) - (double)m2 * m2 - (double)v2;
+            const float x = d.variations[n * Da + j];
+            nrm += (double)x * x; vm += x;
+        }
+        kl += -0.5 * klr; vn += sqrt(nrm);
+    }
+    for (int k = 0; k < K; k++) atomicAdd(&colsum[k], cs[k]);
+    double* o = d.acc + LOSS_DIAG_0;
+    double t;
+    t = block_sum(ent, sh); if (tid == 0) o[0] = t / NS; __syncthreads();
+    t = block_sum(dm, sh); if (tid == 0) o[4] = t / ((double)NS * Da); __syncthreads();
+    t = block_sum(dv_, sh); if (tid == 0) o[5] = t / ((double)NS * Da); __syncthreads();
+    t = block_sum(rm, sh); if (tid == 0) o[6] = t / ((double)NS * Da); __syncthreads();
+    t = block_sum(rv, sh); if (tid == 0) o[7] = t / ((double)NS * Da); __syncthreads();
+    t = block_sum(err, sh); if (tid == 0) o[8] = t / ((double)NS * Da); __syncthreads();
+    t = block_sum(kl, sh); if (tid == 0) o[9] = t / NS; __syncthreads();
+    t = block_sum(vn, sh); if (tid == 0) o[12] = t / NS; __syncthreads();
+    t = block_sum(vm, sh); if (tid == 0) o[13] = t / ((double)NS * Da); __syncthreads();
+    if (tid == 0) {
+        double e2 = 0.0;
+        for (int k = 0; k < K; k++) { const float p = (float)(colsum[k] / NS); e2 -= (double)(p * logf(p)); }      // entropy of the batch-mean assignment (one row)
+        o[1] = e2;
+        o[2] = o[2] / n_states; o[3] = o[3] / n_hidden;                       // (sums of |x| accumulated by k_abs_sum before this kernel)
+        double cm = 0.0, cd = 0.0;
+        for (int i = 0; i < K; i++) {
+            for (int j = 0; j < Da; j++) cm += fabsf(d.centroids[i * Da + j]);
+            for (int i2 = 0; i2 < K; i2++) { double q = 0.0; for (int j = 0; j < Da; j++) { const double df = (double)d.centroids[i * Da + j] - d.centroids[i2 * Da + j]; q += df * df; } cd += sqrt(q); }
+        }
+        o[10] = cm / ((double)K * Da); o[11] = K > 1 ? cd / ((double)K * (K - 1)) : 0.0;
+    }
+}
+int loss_diagnostics(const DiagArgs& d, const TV& states, const TV& hidden, hipStream_t st) {
+    if (d.K > 16 || d.Da > 8) return -1;
+    auto blocks = [](const TV& t) { long items = (long)t.N * t.H * t.W * t.C; long b = (items + 255) / 256; return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); };
+    hipLaunchKernelGGL(k_abs_sum, dim3(blocks(states)), dim3(256), 0, st, states, d.acc + LOSS_DIAG_0 + 2);
+    hipLaunchKernelGGL(k_abs_sum, dim3(blocks(hidden)), dim3(256), 0, st, hidden, d.acc + LOSS_DIAG_0 + 3);
+    hipLaunchKernelGGL(k_diag_small, dim3(1), dim3(256), 0, st, d, (double)states.N * states.H * states.W * states.C, (double)hidden.N * hidden.H * hidden.W * hidden.C);
     return 0;
 }
 int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStream_t st) {

@@ -226,13 +226,7 @@ void build_layers(caddy_ctx* c) {
         for (int i = 0; i < 3; i++) { c->d_up[i].early_bucket = true; c->d_final[i].early_bucket = true; }
         for (int i = 0; i < 2; i++) { c->d_res[i].conv1.early_bucket = c->d_res[i].conv2.early_bucket = true; if (c->d_res[i].has_down) c->d_res[i].down.early_bucket = true; }
     }
-    {   // static roll-out buffers (reference layouts: (3S,H,W) observation, (3,H,W) frame)
-        const size_t px = (size_t)g.height * g.width;
-        c->inf_obs = (float*)c->persist.alloc(px * 3 * g.stacking * 4);
-        c->inf_next = (float*)c->persist.alloc(px * 3 * g.stacking * 4);
-        c->inf_frame = (float*)c->persist.alloc(px * 3 * 4);
-        c->inf_aux = (float*)c->persist.alloc(AUX_LD * 4);
-    }
+    c->inf_aux = (float*)c->persist.alloc(AUX_LD * 4);      // roll-out: one-hot action + variation row read by the captured per-frame kernel sequence
     if (g.perceptual) vgg_build(c);
     {   // zero pool: packed weight gradients of every layer + the (1,h,w,C) gradients of the learned ConvLSTM initial states + the loss accumulators,
         // contiguous so that loss_backward clears them with a single memset
@@ -335,30 +329,36 @@ hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everyth
     }
     return side;
 }
+// (The auxiliary work shares the decoder stream instead of owning one: the ROCm runtime multiplexes HIP streams onto 4 hardware queues by default, and with
+//  a fifth stream in the process -- e.g. the input prefetcher of the training loop -- two of them land on one queue, where a packet waiting for an event of the main
+//  stream stalls the packets of the other stream behind it: measured +44 ms per step.  The decoder stream is idle once the teacher-forced decoder backward, which is
+//  enqueued first, has run.)
+void caddy_ctx::ensure_dstream() {
+    if (dry || dstream || d_done) return;      // once (the simulator build hands out null streams: everything then runs in order on the caller's stream)
+    if (hipStreamCreateWithFlags(&dstream, hipStreamNonBlocking) != hipSuccess) dstream = nullptr;
+    hipEventCreateWithFlags(&d_done, hipEventDisableTiming);
+}
 hipStream_t caddy_ctx::aux_grad_stream() {
     static const bool off = getenv("CADDY_AUX_STREAM") && atoi(getenv("CADDY_AUX_STREAM")) == 0;      // A/B aid
     if (dry || off) return stream;
-    if (!astream && !a_tried) { a_tried = true; if (hipStreamCreateWithFlags(&astream, hipStreamNonBlocking) != hipSuccess) astream = nullptr; }
-    if (!astream) return stream;
+    ensure_dstream();
+    if (!dstream || in_d) return stream;       // (already on the decoder stream: its own ops are off the chain anyway)
     hipEvent_t e = sev();
     hipEventRecord(e, stream);
-    hipStreamWaitEvent(astream, e, 0);
+    hipStreamWaitEvent(dstream, e, 0);
     a_dirty = true;
-    return astream;
+    return dstream;
 }
 void caddy_ctx::join_aux(hipStream_t onto) {
-    if (!astream || !a_dirty || dry) return;
+    if (!dstream || !a_dirty || dry || onto == dstream) return;
     hipEvent_t e = sev();
-    hipEventRecord(e, astream);
+    hipEventRecord(e, dstream);
     hipStreamWaitEvent(onto, e, 0);
     if (onto == stream && !in_d) a_dirty = false;
 }
 // switch the driver to the teacher-forced decoder stream (and its private scratch); fork: order it after everything enqueued on the main stream so far
 void caddy_ctx::enter_d(bool fork) {
-    if (!dry && !dstream && !d_done) {      // once (the simulator build hands out null streams: everything then runs in order on the caller's stream)
-        if (hipStreamCreateWithFlags(&dstream, hipStreamNonBlocking) != hipSuccess) dstream = nullptr;
-        hipEventCreateWithFlags(&d_done, hipEventDisableTiming);
-    }
+    ensure_dstream();
     tp = &tape2;
     if (dry || !dstream) return;
     if (fork) { hipEvent_t e = sev(); hipEventRecord(e, stream); hipStreamWaitEvent(dstream, e, 0); d_forked = true; }
@@ -1087,6 +1087,10 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     a.mi_grad_scale = (float)(c->hook ? c->world : 1);
     if (!dry) c->ck(loss_small(a, c->hook, c->hook_user, st), "loss_small");
     if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize");
+    if (lc->diagnostics && !dry) {      // logging-only scalars (trainer.py:475-491): states = output 3, hidden states = output 4 (5 in pretraining): R's hidden states
+        DiagArgs dg{c->head1.b.samples, c->head1.b.ddist, c->head2.b.ddist, c->head1.b.variations, c->centroids, B * (T - 1), K, Da, c->loss_acc};
+        c->ck(loss_diagnostics(dg, dv(sa), dv(c->hidden), st), "loss_diagnostics");
+    }
     if (c->seeds_only) {      // test aid (caddy_debug_set_seeds_only): stop after the loss kernels -- the gradient arena holds d(loss)/d(output) of the direct loss terms only
         if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
         return finish(c);
@@ -1111,27 +1115,20 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
 }
 
 // Model.generate_next (model/main_model/model.py:570-607), batch 1, eval mode, persistent ConvLSTM state.
-// The per-frame kernel sequence reads inf_obs / inf_aux and writes inf_frame / inf_next (static buffers), so that it can be captured once and
-// replayed as one graph launch per frame; observation, action and the outputs move through small stream-ordered copies around it.
-static void rollout_body(caddy_ctx* c) {
+// The per-frame kernel sequence reads the NHWC observation (first allocation of the frame: the same address every frame) and inf_aux and writes the
+// full-resolution frame (NHWC), so that it can be captured once and replayed as one graph launch per frame; one boundary kernel in front of it (the caller's
+// observation -> NHWC, action -> one-hot) and one behind it (frame -> (3, H, W), obs' = cat[frame, observation[:-3]]) are all the data movement there is.
+static void rollout_body(caddy_ctx* c, const T4& o) {
     const caddy_config& g = c->cfg;
-    const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
-    bool dry = c->dry;
-    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->training = false; c->recording = false; c->have_forward = false; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    const int H = g.height, W = g.width, K = g.actions, Da = g.action_dim;
+    c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->training = false; c->recording = false; c->have_forward = false; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->fold = c->packed_fold; c->rollout = true;
-    T4 o = c->alloc(1, H, W, 3 * S);
-    if (!dry) c->ck(pw_nchw_to_nhwc(c->inf_obs, 0, dv(o), c->stream), "obs layout");
     T4 x65 = c->encode(o, false, nullptr);
     T4 auxv{c->inf_aux, c->inf_aux, 1, 1, 1, K + Da, AUX_LD, AUX_LD};
     T4 hdn = c->dynamics(chan(x65, 0, 64), auxv, nullptr);
     for (int r = 0; r < 3; r++) c->frames[r] = c->alloc(1, H >> r, W >> r, 3);
     c->render(hdn, 0, 1);
-    if (!dry) {
-        c->ck(pw_nhwc_to_nchw(dv(c->frames[0]), c->inf_frame, (long)3 * H * W, 0, c->stream), "frame out");
-        // obs' = cat[frame, obs[:-3]] (model.py:605) -- copy KERNELS, not memcpy nodes (a captured D2D memcpy costs tens of microseconds per replay)
-        c->ck(pw_copy(TV{c->inf_frame, 1, 1, 3 * H * W / 4, 4, 0, 4}, TV{c->inf_next, 1, 1, 3 * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
-        if (S > 1) c->ck(pw_copy(TV{c->inf_obs, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, TV{c->inf_next + 3 * H * W, 1, 1, 3 * (S - 1) * H * W / 4, 4, 0, 4}, 0, c->stream), "next obs");
-    }
+    c->roll_frame = c->frames[0];      // (static: the arena is walked in the same order every frame; the boundary kernel behind the graph reads it)
     c->fold = false; c->rollout = false;
 }
 void caddy_ctx::drop_graph() {
@@ -1157,16 +1154,15 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
     const bool graphed = try_graph && !c->graph_failed;
     hipStream_t st = graphed ? c->gstream : user;
     if (graphed) { hipEventRecord(c->gev_in, user); hipStreamWaitEvent(st, c->gev_in, 0); }      // inputs were produced on the caller's stream
-    if (!dry) {
-        hipMemcpyAsync(c->inf_obs, observation, sizeof(float) * 3 * S * H * W, hipMemcpyDeviceToDevice, st);
-        c->ck(head_set_aux(c->inf_aux, action, variation, K, Da, st), "one-hot action + variation");
-    }
+    c->act.reset();
+    T4 o = c->alloc(1, H, W, 3 * S);      // NHWC observation the per-frame kernel sequence reads: first allocation of the frame -> the same address every frame
+    if (!dry) c->ck(head_rollout_in(observation, o.d, H * W, 3 * S, o.ld, c->inf_aux, action, variation, K, Da, st), "observation layout + one-hot action + variation");
     if (graphed) {
         if (!c->graph_valid && !c->graph_failed_soft) {      // first frame after start_inference: capture the kernel sequence (the capture itself executes nothing)
             c->stream = st;
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                rollout_body(c);
+                rollout_body(c, o);
                 ok = hipStreamEndCapture(st, &c->graph) == hipSuccess && c->graph != nullptr && !c->fail;
                 if (ok) ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) == hipSuccess;
             }
@@ -1175,12 +1171,9 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
             else { c->drop_graph(); c->graph_failed = true; hipGetLastError(); c->fail = false; }
         }
         if (c->graph_valid) { if (hipGraphLaunch(c->graph_exec, st) != hipSuccess) { c->graph_valid = false; c->graph_failed = true; } }
-        if (!c->graph_valid) { c->stream = st; rollout_body(c); c->stream = user; }      // capture failed: run this frame eagerly (still on the internal stream)
-    } else rollout_body(c);
-    if (!dry) {
-        hipMemcpyAsync(frame_out, c->inf_frame, sizeof(float) * 3 * H * W, hipMemcpyDeviceToDevice, st);
-        if (obs_out) hipMemcpyAsync(obs_out, c->inf_next, sizeof(float) * 3 * S * H * W, hipMemcpyDeviceToDevice, st);
-    }
+        if (!c->graph_valid) { c->stream = st; rollout_body(c, o); c->stream = user; }      // capture failed: run this frame eagerly (still on the internal stream)
+    } else rollout_body(c, o);
+    if (!dry) c->ck(head_rollout_out(c->roll_frame.d, c->roll_frame.ld, observation, frame_out, obs_out, H * W, 3 * S, st), "frame + next observation");
     if (graphed) { hipEventRecord(c->gev_out, st); hipStreamWaitEvent(user, c->gev_out, 0); }
     return c->fail ? -1 : 0;
 }
@@ -1341,7 +1334,6 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->comm) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
-    if (c && c->astream) { hipStreamSynchronize(c->astream); hipStreamDestroy(c->astream); }
     if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
     delete c;
 }

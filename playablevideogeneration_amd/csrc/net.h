@@ -151,7 +151,8 @@ struct caddy_ctx {
     int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1
     // roll-out (generate_next) as ONE graph launch per frame: static input / output / action buffers, the per-frame kernel sequence captured on
     // an internal stream after start_inference and replayed afterwards (host cost of ~90 launches -> 1); eager fallback when capture fails
-    float *inf_obs = nullptr, *inf_frame = nullptr, *inf_next = nullptr, *inf_aux = nullptr;
+    float* inf_aux = nullptr;
+    T4 roll_frame{};                 // full-resolution frame (NHWC, pitch 4) of the per-frame kernel sequence
     hipStream_t gstream = nullptr; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     bool graph_valid = false, graph_failed = false, graph_failed_soft = false, use_graph = true;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
@@ -183,9 +184,10 @@ struct caddy_ctx {
     hipEvent_t sev() { if (sev_used == sev_pool.size()) { hipEvent_t e; hipEventCreate(&e); sev_pool.push_back(e); } return sev_pool[sev_used++]; }
     hipStream_t wgrad_stream();
     // gradients that nothing in the BPTT chain reads -- those of the broadcast action / variation inputs of R's convolutions (consumed by the action network's
-    // backward after the time loop) and the conv bias gradients (consumed by the optimiser) -- leave the critical path: a fourth stream, ordered behind the
-    // compute stream per call, joined before the action network's backward / the gradient buckets / the final unpack
-    hipStream_t astream = nullptr; bool a_tried = false, a_dirty = false;
+    // backward after the time loop) and the conv bias gradients (consumed by the optimiser) -- leave the critical path: onto the decoder stream (dstream), ordered
+    // behind the compute stream per call, joined before the action network's backward / the gradient buckets / the final unpack
+    bool a_dirty = false;
+    void ensure_dstream();
     hipStream_t aux_grad_stream();
     void join_aux(hipStream_t onto);
     void ensure_side();

@@ -27,6 +27,7 @@ __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
 __device__ __forceinline__ float lrelu1(float v) { return v > 0.f ? v : 0.2f * v; }
 __device__ __forceinline__ float4 lrelu4(float4 v) { return make_float4(lrelu1(v.x), lrelu1(v.y), lrelu1(v.z), lrelu1(v.w)); }
 __device__ __forceinline__ float4 lmask4(float4 o) { return make_float4(o.x > 0.f ? 1.f : 0.2f, o.y > 0.f ? 1.f : 0.2f, o.z > 0.f ? 1.f : 0.2f, o.w > 0.f ? 1.f : 0.2f); }
@@ -137,10 +138,12 @@ struct FUp2Bwd {  // q indexes INPUT pixels: din (+)= sum_{a,b} w_a w_b dout[cla
 struct FBnApply {  // out = act(x*scale+shift + second), second = x2*scale2+shift2 | x2 | 0   (residual_block.py:57-68)
     TV x, x2, out; const float *scale, *shift, *scale2, *shift2; int HW; int has2; int act;
     __device__ void operator()(long q, int c) const {
-        float4 v = ld4(x.p + tv_off(x, HW, q) + c, c, x.C) * ld4(scale + c, c, x.C) + ld4(shift + c, c, x.C);
+        // (one fused multiply-add per element, exactly what a consuming convolution computes when it applies the BatchNorm itself -- ConvSrc.bn_*: the two forms
+        //  of a layer are bit-identical)
+        float4 v = fma4(ld4(x.p + tv_off(x, HW, q) + c, c, x.C), ld4(scale + c, c, x.C), ld4(shift + c, c, x.C));
         if (has2) {
             float4 r = ld4(x2.p + tv_off(x2, HW, q) + c, c, x2.C);
-            if (scale2) r = r * ld4(scale2 + c, c, x.C) + ld4(shift2 + c, c, x.C);
+            if (scale2) r = fma4(r, ld4(scale2 + c, c, x.C), ld4(shift2 + c, c, x.C));
             v = v + r;
         }
         if (act) v = lrelu4(v);
@@ -153,7 +156,7 @@ struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*l
     __device__ void operator()(long q, int c) const {
         float4 dz = ld4(dout.p + tv_off(dout, HW, q) + c, c, dout.C);
         float4 xv = ld4(x.p + tv_off(x, HW, q) + c, c, x.C);
-        if (act) dz = dz * lmask4(scale ? xv * ld4(scale + c, c, x.C) + ld4(shift + c, c, x.C) : ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
+        if (act) dz = dz * lmask4(scale ? fma4(xv, ld4(scale + c, c, x.C), ld4(shift + c, c, x.C)) : ld4(outm.p + tv_off(outm, HW, q) + c, c, outm.C));
         float4 mu = ld4(mean + c, c, x.C), is = ld4(invstd + c, c, x.C), ga = ld4(gamma + c, c, x.C);
         float s1[4], s2[4];
         for (int e = 0; e < 4; e++) { bool ok = c + e < x.C; s1[e] = ok ? (float)(sums[2 * (c + e)] * invM) : 0.f; s2[e] = ok ? (float)(sums[2 * (c + e) + 1] * invM) : 0.f; }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
                     s[4] += (double)xv.x * xv.x; s[5] += (double)xv.y * xv.y; s[6] += (double)xv.z * xv.z; s[7] += (double)xv.w * xv.w;
                 } else if (MODE == 1) {
                     float4 dz = ld4(a.dout.p + tv_off(a.dout, HW, q) + c, c, C);
-                    if (a.act) dz = dz * lmask4(a.lz_scale ? xv * ld4(a.lz_scale + c, c, C) + ld4(a.lz_shift + c, c, C) : ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
+                    if (a.act) dz = dz * lmask4(a.lz_scale ? fma4(xv, ld4(a.lz_scale + c, c, C), ld4(a.lz_shift + c, c, C)) : ld4(a.outm.p + tv_off(a.outm, HW, q) + c, c, C));
                     float4 xh = (xv - ld4(a.mean + c, c, C)) * ld4(a.invstd + c, c, C);
                     s[0] += dz.x; s[1] += dz.y; s[2] += dz.z; s[3] += dz.w;
                     s[4] += (double)dz.x * xh.x; s[5] += (double)dz.y * xh.y; s[6] += (double)dz.z * xh.z; s[7] += (double)dz.w * xh.w;

@@ -13,7 +13,11 @@ import torch
 from . import _lib
 
 LOSS_NAMES = ["total", "rec", "states", "entropy", "dir_kl", "mi", "state_kl", "hidden", "l1_r0", "l1_r1", "l1_r2", "perceptual", "perceptual_term"]
-LOSS_SLOTS, LOSS_PERC_R0 = 40, 16          # include/caddy_hip.h: CADDY_LOSS_SLOTS, CADDY_LOSS_PERC_R0
+LOSS_SLOTS, LOSS_PERC_R0, DIAG_0 = 56, 16, 40          # include/caddy_hip.h: CADDY_LOSS_SLOTS, CADDY_LOSS_PERC_R0, CADDY_DIAG_0
+DIAG_NAMES = ["samples_entropy", "action_distribution_entropy", "states_magnitude", "hidden_states_magnitude", "action_directions_mean_magnitude",
+              "action_directions_variance_magnitude", "reconstructed_action_directions_mean_magnitude", "reconstructed_action_directions_variance_magnitude",
+              "action_directions_reconstruction_error", "reconstructed_action_directions_kl_loss", "centroids_mean_magnitude", "average_centroids_distance",
+              "average_action_variations_norm_l2", "action_variations_mean"]      # logging-only entries of the reference's loss_info (trainer.py:475-491)
 
 
 class CaddyConfig(C.Structure):
@@ -36,7 +40,7 @@ class LossCfg(C.Structure):
     _fields_ = [("rec", C.c_double), ("states", C.c_double), ("entropy", C.c_double), ("dir_kl", C.c_double), ("mi", C.c_double),
                 ("state_kl", C.c_double), ("hidden", C.c_double), ("mi_entropy_lambda", C.c_double),
                 ("mi_ema", C.c_void_p), ("mi_ema_alpha", C.c_float), ("update_mi_ema", C.c_int),
-                ("perceptual", C.c_double), ("perceptual_log", C.c_int)]
+                ("perceptual", C.c_double), ("perceptual_log", C.c_int), ("diagnostics", C.c_int)]
 
 
 def _bind(lib):
@@ -402,17 +406,19 @@ class Engine:
         return g
 
     # ---- losses + backward (Trainer.compute_losses terms + loss.backward()) ----
-    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True, perceptual_log=False) -> Dict[str, float]:
+    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True, perceptual_log=False, diagnostics=False) -> Dict[str, float]:
         if smooth_mi and self.mi_ema is None:
             self.mi_ema = torch.full((self.K, self.K), 1.0 / (self.K * self.K), dtype=torch.float32, device=self.device)
         lc = LossCfg(weights.get("rec", 0.0), weights.get("states", 0.0), weights.get("entropy", 0.0), weights.get("dir_kl", 0.0),
                      weights.get("mi", 0.0), weights.get("state_kl", 0.0), weights.get("hidden", 0.0), weights.get("mi_entropy", 1.0),
                      self.mi_ema.data_ptr() if smooth_mi else None, mi_alpha, int(update_mi_ema),
-                     weights.get("perceptual", 0.0), int(perceptual_log))
+                     weights.get("perceptual", 0.0), int(perceptual_log), int(diagnostics))
         host = (C.c_double * LOSS_SLOTS)()
         self._stream()
         self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), host))
         res = {n: host[i] for i, n in enumerate(LOSS_NAMES)}
+        if diagnostics:      # evaluated on the device inside the same call: no tensor fetch, no extra synchronisation
+            res["diagnostics"] = {n: host[DIAG_0 + i] for i, n in enumerate(DIAG_NAMES)}
         if self.perceptual and self.vgg_loaded and (lc.perceptual != 0.0 or perceptual_log):      # loss_info keys of trainer.py:459-462
             for r in range(3):
                 res[f"perceptual_loss_r{r}"] = host[LOSS_PERC_R0 + 6 * r]

@@ -115,9 +115,11 @@ class Trainer:
         return w
 
     # ---- logging-only diagnostics of the reference's loss_info (trainer.py:475-491, :358-375), from the small outputs of the forward ----
-    def diagnostics(self, model, eng, pretraining=False) -> Dict[str, float]:
+    def diagnostics(self, model, eng, pretraining=False, li=None) -> Dict[str, float]:
         if not self.config["training"].get("loss_diagnostics", True):
             return {}
+        if li is not None and "diagnostics" in li:      # computed on the device by caddy_loss_backward (caddy_loss_cfg.diagnostics): one host buffer per step
+            return dict(li["diagnostics"])
         o = (lambda i: eng.output(i, pretraining))
         s = 1 if pretraining else 0                       # forward_pretraining's tuple has one extra entry before the logits / samples
         with torch.no_grad():
@@ -153,7 +155,8 @@ class Trainer:
         self._to_engine_device(eng)              # BEFORE the engine takes the raw pointer of the MI estimator (a checkpoint loaded before model.cuda() left it on the CPU)
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
-        li = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None)
+        li = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
+                               diagnostics=self.config["training"].get("loss_diagnostics", True))
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema
         w = self.loss_weights()
@@ -166,7 +169,7 @@ class Trainer:
                      "observations_rec_loss_r0": li["l1_r0"], "observations_rec_loss_r1": li["l1_r1"], "observations_rec_loss_r2": li["l1_r2"],
                      "ground_truth_observations": gt, "gumbel_temperature": tau, "observations_count": observations_count}
         loss_info.update({k: v for k, v in li.items() if k.startswith("perceptual_loss_r")})      # trainer.py:459-462
-        loss_info.update(self.diagnostics(model, eng))
+        loss_info.update(self.diagnostics(model, eng, li=li))
         return li["total"], loss_info, {}
 
     # ---- Trainer.compute_losses_pretraining (trainer.py:241-398) ----
@@ -179,7 +182,8 @@ class Trainer:
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
         w = self.loss_weights(pretraining=True)
-        li = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None)
+        li = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
+                               diagnostics=self.config["training"].get("loss_diagnostics", True))
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema
         loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
@@ -191,7 +195,7 @@ class Trainer:
                      "action_directions_kl_loss": li["dir_kl"], "action_mutual_information_loss": li["mi"], "action_state_distribution_kl_loss": li["state_kl"],
                      "gumbel_temperature": tau, "observations_count": observations_count}
         loss_info.update({k: v for k, v in li.items() if k.startswith("perceptual_loss_r")})
-        loss_info.update(self.diagnostics(model, eng, pretraining=True))
+        loss_info.update(self.diagnostics(model, eng, pretraining=True, li=li))
         return li["total"], loss_info, {}
 
     def optimizer_step(self, model, world_size: int = 1):
