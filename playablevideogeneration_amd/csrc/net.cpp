@@ -517,8 +517,19 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                     // first-touch inputs (this conv is their only consumer): dgrad assigns -- plain stores, or the deterministic slab split-K when under-filled
                     const bool assign = sg[s].t.nz && !sg[s].t.nz2;      // nz2: a point-wise writer (residual add / up-sampling backward) assigned before this dgrad runs
                     d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = assign ? 0 : 1;
-                    if (assign) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
-                    RUN(timed_conv_fwd(d, dfl));
+                    // d(h_{t-1}) of a ConvLSTM's gate convolution: first read by the previous time step's cell backward, a whole R -> E -> D backward later.  The launch
+                    // (under-filled: 16x16 / 32x32 maps) goes to the decoder stream, beside the chain; lstm_step's BatchNorm backward joins it.
+                    hipStream_t as = (sg[s].off_chain && !assign) ? aux_grad_stream() : stream;
+                    if (as != stream) {
+                        StreamRes keep{stream, conv_aux, conv_split, red_scratch};
+                        stream = as; conv_aux = dsr.aux; conv_split = dsr.split; d.aux = conv_aux;
+                        RUN(timed_conv_fwd(d, dfl));
+                        if (!dry) { if (!Lp->off_ev) hipEventCreateWithFlags(&Lp->off_ev, hipEventDisableTiming); hipEventRecord(Lp->off_ev, as); Lp->off_pending = true; }
+                        stream = keep.st; conv_aux = keep.aux; conv_split = keep.split;
+                    } else {
+                        if (assign) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
+                        RUN(timed_conv_fwd(d, dfl));
+                    }
                 }
                 else {
                     d.out = tmp[s].d; d.out_sn = tmp[s].sn; d.out_ld = tmp[s].ld; d.accumulate = 0;
@@ -704,13 +715,16 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
         RUN(pw_copy(dv(ih), dv(hprev), 0, stream)); RUN(pw_copy(dv(ic), dv(cprev), 0, stream));
         if (recording) {
             T4 ihg = L.ih, icg = L.ic;
+            ConvL* Lg = &L.gates;
             tp->push_back([=]() {
+                if (Lg->off_pending && !dry) { hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; }      // d(initial h) comes from the first step's gate-convolution dgrad on the decoder stream
                 RUN(pw_batch_sum(hprev.g, hprev.sn, hprev.sn, B, ihg.g, stream));
                 RUN(pw_batch_sum(cprev.g, cprev.sn, cprev.sn, B, icg.g, stream));
             });
         }
     } else { hprev = L.h; cprev = L.c; }
     Seg sg[3] = {{x, 0, true}, {aux, 1, true}, {hprev, 0, true}};
+    sg[2].off_chain = true;
     T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     T4 hn, cn;
     if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
@@ -725,7 +739,10 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
     if (recording) tp->push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
-    return bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
+    T4 hb = bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
+    if (recording) { ConvL* Lg = &L.gates;      // (reverse replay: first thing of this step's cell) d(h_t) also receives the NEXT step's gate-convolution dgrad, from the decoder stream
+        tp->push_back([=]() { if (Lg->off_pending && !dry) { hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; } }); }
+    return hb;
 }
 
 // ConvDynamicsNetwork.forward (model/main_model/conv_dynamics_network.py:111-133)
@@ -1334,6 +1351,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->comm) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
+    if (c) for (ConvL* L : c->convs) if (L->off_ev) hipEventDestroy(L->off_ev);
     if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
     delete c;
 }

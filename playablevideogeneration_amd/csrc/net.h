@@ -64,6 +64,8 @@ struct ConvL {
     // roll-out: the eval-mode BatchNorm that follows this conv (with nothing but an average pool in between) is folded into the packed forward
     // weights (PackDesc.oscale) and into fold_bias = bias * scale + shift by pack_all(true)
     struct BNL* fold_bn = nullptr; float* fold_bias = nullptr;
+    // off-chain dgrad of this layer (Seg::off_chain: d(h_{t-1}) of a ConvLSTM gate convolution on the decoder stream): event behind the last launch
+    hipEvent_t off_ev = nullptr; bool off_pending = false;
 };
 struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
              float* eval_stash = nullptr; bool eval_valid = false;
@@ -76,7 +78,7 @@ struct LstmL { ConvL gates; BNL bn; float *init_h, *init_c, *ginit_h, *ginit_c; 
                T4 h, c;          // current state
                T4 ph, pc;        // persistent inference state (B,h,w,C)
                int C, Hs, Ws; };
-struct Seg { T4 t; int bcast; bool need_grad; };
+struct Seg { T4 t; int bcast; bool need_grad; bool off_chain = false; };      // off_chain: the gradient of this input is not read before the previous time step's backward (h_{t-1} of a ConvLSTM): its dgrad leaves the BPTT chain (decoder stream)
 
 struct HeadState { HeadBufs b{}; SampleCfg sc{}; T4 x65; T4 att; };
 
