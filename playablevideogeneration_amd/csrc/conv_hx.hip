@@ -685,8 +685,10 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
     // launches of at most one workgroup per CU (batch-1 roll-out, R's side branches): every workgroup is a serial chain of (tap, chunk) steps whose
     // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame
-    static const int env_deep = getenv("CADDY_HX_DEEP") ? atoi(getenv("CADDY_HX_DEEP")) : 1;      // A/B aid
-    const bool deep = env_deep && !big && (a.precision == PREC_F16X3 || a.precision == PREC_BF16X3) && blocks * a.splitk <= 256;
+    // (measured, E/R/A/D step: ring on launches of <= 256 / 512 / 1024 workgroups / always: 77.2 / 75.5 / 75.8 / 75.5 ms -- with one step of prefetch the next weight tile
+    //  has ~0.4 us to arrive from L2, less than its latency under load, in every 4-wave launch)
+    static const int env_deep = getenv("CADDY_HX_DEEP") ? atoi(getenv("CADDY_HX_DEEP")) : 1 << 30;      // A/B aid: workgroup threshold of the 3-deep weight-tile register ring (0 = never)
+    const bool deep = env_deep > 0 && !big && (a.precision == PREC_F16X3 || a.precision == PREC_BF16X3) && blocks * a.splitk <= (env_deep == 1 ? 256 : env_deep);
 #define HX_LAUNCH_DEEP(T_, EP_)                                                                                                   \
     do {                                                                                                                          \
         if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 128, 2, 2, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);       \

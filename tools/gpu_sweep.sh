@@ -1,7 +1,7 @@
-# environment-variable A/B sweep of the training step on one box (each line: 5 timed steps incl. the VGG19 loss): are the defaults still the best?
+#!/bin/bash
+# sweep one environment switch on the E/R/A/D-only step:  bash tools/gpu_sweep.sh VAR v1 v2 ...
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-run() { echo -n "$* : "; env "$@" timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rollout --profile-steps 0 2>&1 | grep "timed region" | sed 's/.*done: //'; echo; }
-run X=0
-for v in ${SWEEP:-CADDY_BN_SMALL=0 CADDY_FWD_SPLIT=0 CADDY_NARROW=0 CADDY_C4=0 CADDY_WGRAD_TILE=0 CADDY_FIRST_TOUCH=0 CADDY_HX_XCD=0 CADDY_VGG_FUSE_POOL=0 CADDY_WGRAD_HX=0 CADDY_SIDE_STREAM=0}; do run $v; done
-run X=1
+VAR=$1; shift
+B="python bench.py --no-perceptual --no-cpu-baseline --no-rollout --no-extra-legs --profile-steps 0 --steps 10 --warmup 3"
+for i in 1 2; do for v in "$@"; do echo "$VAR=$v"; env $VAR=$v timeout 300 $B 2>&1 | grep "timed region"; done; done
