@@ -675,8 +675,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
             }
         }
     }
-    static const int env_xcd = getenv("CADDY_HX_XCD") ? atoi(getenv("CADDY_HX_XCD")) : 1;      // A/B aid
-    a.xcd_map = env_xcd;
+    a.xcd_map = 1;
     // BatchNorm partial sums: from the epilogue of EP = 0 instances when one workgroup holds the whole K range, from the slab reduce of a split launch otherwise
     float* const stats_req = a.stats; const int stats_req_ld = a.stats_ld;
     const long stats_cap = conv_stats_tiles_cap(a.N, a.H, a.W);                // tiles the caller sized the buffer for

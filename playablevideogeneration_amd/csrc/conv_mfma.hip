@@ -758,10 +758,6 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     // remaining deficit of accumulating launches (dgrad) is covered by splitting K across blockIdx.z (fp32 atomics).
     long blocks128 = (long)cdiv(P, 128) * (a.Cout_pad / bn);
     bool small = (bn >= 64) && blocks128 < 512;
-    static const int force_tile = getenv("CADDY_FORCE_TILE") ? atoi(getenv("CADDY_FORCE_TILE")) : 0;   // tuning aid: 1 = 128-row tiles, 2 = 64x64
-    if (force_tile == 1) small = false;
-    if (force_tile == 2 && bn >= 64) small = true;
-    static const int force_splitk = getenv("CADDY_FORCE_SPLITK") ? atoi(getenv("CADDY_FORCE_SPLITK")) : 0;
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
@@ -769,14 +765,12 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         int want = (int)((512 + blocks - 1) / blocks);
         a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
     }
-    if (force_splitk > 0 && a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && !a.res && a.KS * a.KS % force_splitk == 0) a.splitk = force_splitk;
     // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
     // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
     a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     const float* real_res = a.res;
-    static const bool no_fsplit = getenv("CADDY_FWD_SPLIT") && atoi(getenv("CADDY_FWD_SPLIT")) == 0;
-    if (!a.accumulate && a.split_scratch && !no_fsplit && !generic_only && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
+    if (!a.accumulate && a.split_scratch && !generic_only && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
         int want = (int)((512 + blocks - 1) / blocks);
         int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
         int ldc = round_up(a.Cout, 4);
@@ -785,18 +779,8 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
             a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr;
         }
     }
-    static const int force_prec = getenv("CADDY_FP32_PLANES") ? atoi(getenv("CADDY_FP32_PLANES")) : -1;   // tuning / A-B aid: 2 | 3 = in-loop split-bf16 planes of k_conv_fwd
-    if (force_prec >= 0) a.precision = force_prec;
-    const int ns = (a.precision == 2 || a.precision == 3) ? a.precision : 0;
-    static const int force_cps = getenv("CADDY_CPS") ? atoi(getenv("CADDY_CPS")) : 0;
-    const int cps = force_cps == 2 ? 2 : 1;    // 32 channels per barrier measured +-3% (not the limiter): kept selectable, default 16
-#define LAUNCH_CONV(TM_, TN_, WM_, WN_)                                                                              \
-    do {                                                                                                              \
-        if (ns == 3) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 3, 1>), grid, dim3(256), 0, st, a);           \
-        else if (ns == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 2, 1>), grid, dim3(256), 0, st, a);      \
-        else if (cps == 2) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0, 2>), grid, dim3(256), 0, st, a);     \
-        else hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0, 1>), grid, dim3(256), 0, st, a);                   \
-    } while (0)
+    // (the exact-fp32 kernel: the in-loop split-bf16 planes / 32-channel steps of round 1 are no longer instantiated -- conv_hx.hip is the 16-bit path)
+#define LAUNCH_CONV(TM_, TN_, WM_, WN_) hipLaunchKernelGGL((k_conv_fwd<TM_, TN_, WM_, WN_, 0, 1>), grid, dim3(256), 0, st, a)
     if (small) {
         dim3 grid(cdiv(P, 64), a.Cout_pad / 64, a.splitk);
         LAUNCH_CONV(1, 1, 2, 2);
@@ -860,8 +844,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
     long P = (long)a.N * a.H * a.W;
     int taps = a.KS * a.KS;
-    static const int narrow_tile = getenv("CADDY_WGRAD_NARROW_TILE") ? atoi(getenv("CADDY_WGRAD_NARROW_TILE")) : 1;   // A/B aid: K = 64 narrow layers -> tile-resident kernel
-    if (a.nsrc == 1 && !a.src[0].bcast && a.Cout <= 32 && a.Ktot <= 64 && a.KS <= 3 && P >= 4096 && !(narrow_tile && a.Ktot > 32 && a.KS == 3)) {   // narrow layers
+    if (a.nsrc == 1 && !a.src[0].bcast && a.Cout <= 32 && a.Ktot <= 64 && a.KS <= 3 && P >= 4096 && !(a.Ktot > 32 && a.KS == 3)) {   // narrow layers (K = 64, 3x3: the tile-resident kernel below)
         int tx = cdiv(a.W, STW), ty = cdiv(a.H, STH);
         long ntiles = (long)a.N * tx * ty;
         int grid = (int)(ntiles < 512 ? ntiles : 512);
@@ -872,8 +855,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
         g_last_conv_kernel = CK_WGRAD_SMALL;
         return 0;
     }
-    static const int no_tile = getenv("CADDY_WGRAD_TILE") ? !atoi(getenv("CADDY_WGRAD_TILE")) : 0;     // A/B aid: 0 disables the tile-resident kernel
-    if (a.KS == 3 && !no_tile && a.W >= 8 && a.H >= 2) {
+    if (a.KS == 3 && a.W >= 8 && a.H >= 2) {
         int tx = cdiv(a.W, WT_W), ty = cdiv(a.H, WT_H);
         long ntiles = (long)a.N * tx * ty;
         int kt = cdiv(a.Ktot, WT_KC);

@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, in
 
 // returns 1 if handled, 0 if the shape does not qualify
 int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st) {
-    static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;      // A/B aid
-    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || (a.act != 0 && a.act != 3) || a.splitk > 1) return 0;
+    if (a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || (a.act != 0 && a.act != 3) || a.splitk > 1) return 0;
     if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
     if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.out_ld & 3) || (a.out_sn & 3) || a.Cout_pad < 16 * ((a.Cout + 15) / 16)) return 0;
     if ((long)a.N * a.H * a.W < 4096) return 0;                    // tiny maps: the generic kernel's split-K paths do better
@@ -265,8 +264,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int tiles_x, 
 }  // namespace
 
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
-    static const bool off = getenv("CADDY_NARROW") && atoi(getenv("CADDY_NARROW")) == 0;
-    if (off || a.nsrc != 1 || a.src[0].bcast || a.KS != 3) return 0;
+    if (a.nsrc != 1 || a.src[0].bcast || a.KS != 3) return 0;
     if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
     const int ci = a.Ktot / 16, co = (a.Cout + 15) / 16;
     if (ci == 2 && co == 2) return 0;                              // 32 x 32: no padding in the 32x32x2 kernel
@@ -396,8 +394,7 @@ __global__ __launch_bounds__(256) void k_conv_c4(ConvArgs a, int tiles_x, int ti
 }  // namespace
 
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st) {
-    static const bool off = getenv("CADDY_C4") && atoi(getenv("CADDY_C4")) == 0;      // A/B aid
-    if (off || a.nsrc != 1 || a.src[0].bcast || a.act != 0 || a.splitk > 1 || (a.KS != 3 && a.KS != 7)) return 0;
+    if (a.nsrc != 1 || a.src[0].bcast || a.act != 0 || a.splitk > 1 || (a.KS != 3 && a.KS != 7)) return 0;
     if (a.src[0].C > 4 || a.src[0].ld != 4 || (a.src[0].sn & 3) || a.Ktot != 16 || a.Cout < 8 || (a.out_ld & 3) || (a.out_sn & 3)) return 0;
     const int mt = (a.Cout + 15) / 16;                       // 16-channel output tiles
     if (a.Cout_pad < mt * 16) return 0;
@@ -520,8 +517,7 @@ __global__ __launch_bounds__(256) void k_wgrad_c4(const float* thin, long thin_s
 }  // namespace
 
 int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st, bool dry) {
-    static const bool off = getenv("CADDY_C4") && atoi(getenv("CADDY_C4")) == 0;
-    if (off || w.nsrc != 1 || w.src[0].bcast || (w.KS != 3 && w.KS != 7)) return 0;
+    if (w.nsrc != 1 || w.src[0].bcast || (w.KS != 3 && w.KS != 7)) return 0;
     const float *thin, *wide; long thin_sn, wide_sn; int TC, WC, wide_ld, swap;
     if (w.Cout <= 4 && w.dy_ld == 4 && w.src[0].C >= 16) {            // FinalBlocks: thin = dY
         swap = 0; thin = w.dy; thin_sn = w.dy_sn; TC = w.Cout; wide = w.src[0].p; wide_sn = w.src[0].sn; wide_ld = w.src[0].ld; WC = w.src[0].C;

@@ -268,8 +268,6 @@ T4 caddy_ctx::alloc(int N, int H, int W, int C, int ld) {
     return t;
 }
 T4 caddy_ctx::alloc_nz(int N, int H, int W, int C, bool second_writer_is_conv) {
-    static const bool off = getenv("CADDY_FIRST_TOUCH") && atoi(getenv("CADDY_FIRST_TOUCH")) == 0;      // A/B aid: everything zero-filled + accumulated
-    if (off) return alloc(N, H, W, C);
     int ld = round_up(C, 4);
     float* d = (float*)act.alloc_top((size_t)N * H * W * ld * 4);
     T4 t{d, (float*)((char*)d + grad_delta), N, H, W, C, (long)H * W * ld, ld, true};
@@ -309,11 +307,9 @@ void caddy_ctx::ensure_side() {
     if (off) { use_side = false; return; }
     // lowest priority: weight-gradient workgroups fill the compute units the BPTT chain leaves idle (R's small feature maps,
     // point-wise kernels) instead of competing with it
-    static const bool prio = !(getenv("CADDY_SIDE_PRIORITY") && atoi(getenv("CADDY_SIDE_PRIORITY")) == 0);
     int least = 0, greatest = 0;
     hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (prio) hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
-    else hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
     if (!gt_done) hipEventCreateWithFlags(&gt_done, hipEventDisableTiming);
 }
 hipStream_t caddy_ctx::wgrad_stream() {   // order the side stream after everything already enqueued on the compute stream(s)
@@ -1060,8 +1056,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
             hipMemsetAsync(gm, 0, c->gt_lo, st);
             if (c->act.off > c->gt_hi) hipMemsetAsync(gm + c->gt_hi, 0, c->act.off - c->gt_hi, st);
         } else hipMemsetAsync(gm, 0, c->act.off, st);
-        static const bool poison_env = getenv("CADDY_POISON_NZ") != nullptr;   // test aid: NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
-        if ((poison_env || c->poison_nz) && c->act.top < c->act.cap) hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
+        if (c->poison_nz && c->act.top < c->act.cap)      // test aid (caddy_debug_set_poison): NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
             hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
         hipMemsetAsync(c->zero_pool, 0, c->zero_pool_bytes, st);      // every layer's packed weight gradient, the ConvLSTM initial-state gradients, the loss accumulators
     }

@@ -243,8 +243,7 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
         // MaxPool2d(2, 2) in front of the next conv: written by THIS conv's epilogue on the split-operand kernel (the window's four pixels sit in
         // one lane) -- no separate pass over the full-resolution map; a branch that is never back-propagated (keep_all = false: the ground truth)
         // does not even store the full-resolution map of such a layer (it is no tap: the taps are the first convs AFTER a pool)
-        static const bool no_fuse = getenv("CADDY_VGG_FUSE_POOL") && atoi(getenv("CADDY_VGG_FUSE_POOL")) == 0;      // A/B aid
-        if (!no_fuse && i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && conv_hx_pool_ok(x.N, x.H, x.W, VGG[i].cout)) {
+        if (i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && conv_hx_pool_ok(x.N, x.H, x.W, VGG[i].cout)) {
             pooled = valloc(c, x.N, x.H / 2, x.W / 2, VGG[i].cout);
             a.pool_out = pooled.d; a.pool_sn = pooled.sn; a.pool_ld = pooled.ld;
             a.skip_out = (!keep_all && VGG[i].tap < 0) ? 1 : 0;

@@ -9,7 +9,7 @@ from playablevideogeneration_amd._lib import ConvArgs, ConvSrc, WgradArgs, round
 lib = _lib.load()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 import os
-print("CADDY_FORCE_TILE =", os.environ.get("CADDY_FORCE_TILE"), "CADDY_FORCE_SPLITK =", os.environ.get("CADDY_FORCE_SPLITK"))
+pass
 ONLY = os.environ.get("BENCH_ONLY")
 KIND = os.environ.get("BENCH_KIND")
 SHAPES = [  # name, N, H, W, Cin, Cout, KS   (names starting with "dgrad" run the forward kernel in accumulate mode)
