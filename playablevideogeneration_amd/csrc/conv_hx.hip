@@ -21,6 +21,7 @@
 // 2x2 max-pool written by the epilogue of the layer in front of it; dgrad with the fused ReLU mask / L1 seed epilogue).
 #include "common.h"
 #include "pack.h"
+#include "pack_elems.h"
 #include <cstdlib>
 
 namespace {
@@ -544,35 +545,55 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
 
 // ---- weight packing: OIHW fp32 (reference state_dict layout) -> split 16-bit tiles [tap][chunk][Cout_pad][hi 32 | lo 32] ----
 template <typename T, int NPL>
-__global__ void k_pack_hx(PackDesc d, T* wq, int Cout_pad, int dgrad_seg) {
+__device__ __forceinline__ void pk_hx_elem(const PackDesc& d, T* wq, int Cout_pad, int dgrad_seg, int nch, long i) {
     // forward (dgrad_seg < 0): rows = output channels, k = concatenated input segments, each padded to KC.
     // dgrad of segment s: rows = input channels of s, k = output channels (padded to KC), taps flipped.
     const int taps = d.KS * d.KS;
+    const int kk = (int)(i % KC); long r = i / KC; const int row = (int)(r % Cout_pad); r /= Cout_pad; const int ch = (int)(r % nch); const int tap = (int)(r / nch);
+    const int k = ch * KC + kk;
+    float v = 0.f;
+    if (dgrad_seg < 0) {
+        int base = 0, cin = -1;
+        for (int s = 0; s < d.nseg; s++) {
+            const int pad = (d.seg_C[s] + KC - 1) / KC * KC;
+            if (k < base + pad) { if (k - base < d.seg_C[s]) cin = d.seg_off[s] + k - base; break; }
+            base += pad;
+        }
+        if (row < d.Cout && cin >= 0) v = d.w[row / d.Co_each][((long)(row % d.Co_each) * d.Cin + cin) * taps + tap] * (d.oscale ? d.oscale[row] : 1.f);
+    } else {
+        if (row < d.seg_C[dgrad_seg] && k < d.Cout) v = d.w[k / d.Co_each][((long)(k % d.Co_each) * d.Cin + d.seg_off[dgrad_seg] + row) * taps + (taps - 1 - tap)];
+    }
+    if (sizeof(T) == 2 && !is_bf16<T>::value) v *= HX_WSCALE;      // f16 forms only (see HX_WSCALE)
+    const T hi = (T)v;
+    T* o = wq + (((long)tap * nch + ch) * Cout_pad + row) * (NPL * KC) + kk;
+    o[0] = hi;
+    if (NPL == 2) o[KC] = (T)(v - (float)hi);
+}
+__device__ __forceinline__ int pk_hx_nch(const PackDesc& d, int dgrad_seg) {
     int Kq = 0;
     if (dgrad_seg < 0) { for (int s = 0; s < d.nseg; s++) Kq += (d.seg_C[s] + KC - 1) / KC * KC; }
     else Kq = (d.Cout + KC - 1) / KC * KC;
-    const int nch = Kq / KC;
-    const long total = (long)taps * nch * Cout_pad * KC;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kk = (int)(i % KC); long r = i / KC; const int row = (int)(r % Cout_pad); r /= Cout_pad; const int ch = (int)(r % nch); const int tap = (int)(r / nch);
-        const int k = ch * KC + kk;
-        float v = 0.f;
-        if (dgrad_seg < 0) {
-            int base = 0, cin = -1;
-            for (int s = 0; s < d.nseg; s++) {
-                const int pad = (d.seg_C[s] + KC - 1) / KC * KC;
-                if (k < base + pad) { if (k - base < d.seg_C[s]) cin = d.seg_off[s] + k - base; break; }
-                base += pad;
-            }
-            if (row < d.Cout && cin >= 0) v = d.w[row / d.Co_each][((long)(row % d.Co_each) * d.Cin + cin) * taps + tap] * (d.oscale ? d.oscale[row] : 1.f);
-        } else {
-            if (row < d.seg_C[dgrad_seg] && k < d.Cout) v = d.w[k / d.Co_each][((long)(k % d.Co_each) * d.Cin + d.seg_off[dgrad_seg] + row) * taps + (taps - 1 - tap)];
-        }
-        if (sizeof(T) == 2 && !is_bf16<T>::value) v *= HX_WSCALE;      // f16 forms only (see HX_WSCALE)
-        const T hi = (T)v;
-        T* o = wq + (((long)tap * nch + ch) * Cout_pad + row) * (NPL * KC) + kk;
-        o[0] = hi;
-        if (NPL == 2) o[KC] = (T)(v - (float)hi);
+    return Kq / KC;
+}
+template <typename T, int NPL>
+__global__ void k_pack_hx(PackDesc d, T* wq, int Cout_pad, int dgrad_seg) {
+    const int nch = pk_hx_nch(d, dgrad_seg);
+    const long total = (long)d.KS * d.KS * nch * Cout_pad * KC;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) pk_hx_elem<T, NPL>(d, wq, Cout_pad, dgrad_seg, nch, i);
+}
+
+// one launch over a job table (pack.h): workgroup -> job by binary search over the jobs' first blocks
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackJob* jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PackJob& j = jobs[lo];
+    const long first = ((long)blockIdx.x - j.block0) * 256 + threadIdx.x, stride = (long)j.nblocks * 256;
+    switch (j.kind) {
+        case PJ_FWD: for (long i = first; i < j.total; i += stride) pk_fwd_elem(j.d, (float*)j.buf, i); break;
+        case PJ_DGRAD: for (long i = first; i < j.total; i += stride) pk_dgrad_elem(j.d, j.seg, (float*)j.buf, j.p0, j.p1, i); break;
+        case PJ_UNPACK: for (long i = first; i < j.total; i += stride) pk_unpack_elem(j.d, (const float*)j.buf, i); break;
+        case PJ_HX_FWD_F16: { const int nch = pk_hx_nch(j.d, -1); for (long i = first; i < j.total; i += stride) pk_hx_elem<_Float16, 2>(j.d, (_Float16*)j.buf, j.p0, -1, nch, i); break; }
+        case PJ_HX_DGRAD_BF16: { const int nch = pk_hx_nch(j.d, j.seg); for (long i = first; i < j.total; i += stride) pk_hx_elem<__bf16, 2>(j.d, (__bf16*)j.buf, j.p0, j.seg, nch, i); break; }
     }
 }
 
@@ -601,6 +622,11 @@ int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg, int precision, h
         case PREC_BF16X1: hipLaunchKernelGGL((k_pack_hx<__bf16, 1>), dim3(grid), dim3(256), 0, st, d, (__bf16*)wq, rows_pad, seg); break;
         default: return -1;
     }
+    return 0;
+}
+int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t st) {
+    if (njobs <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_dev, njobs);
     return 0;
 }
 int hx_pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }

@@ -248,6 +248,9 @@ void build_layers(caddy_ctx* c) {
     c->conv_aux2 = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
     c->conv_split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
+    // device tables of the one-launch (un)packing jobs
+    c->pack_jobs.cap = 8 * (int)c->convs.size() + 8; c->pack_jobs.dev = (PackJob*)c->persist.alloc(sizeof(PackJob) * c->pack_jobs.cap);
+    for (int i = 0; i < 3; i++) { c->unpack_jobs[i].cap = (int)c->convs.size() + 8; c->unpack_jobs[i].dev = (PackJob*)c->persist.alloc(sizeof(PackJob) * c->unpack_jobs[i].cap); }
     // private scratch of the teacher-forced decoder stream (caddy_ctx::dstream)
     c->dsr.aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->dsr.split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
@@ -826,8 +829,40 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
                                                                                RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
+void caddy_ctx::add_job(JobList& jl, const PackDesc& d, void* buf, int kind, int seg, int p0, int p1, long total) {
+    PackJob j{};
+    j.d = d; j.buf = buf; j.kind = kind; j.seg = seg; j.p0 = p0; j.p1 = p1; j.total = total;
+    long nb = (total + 2047) / 2048;      // ~8 elements per thread
+    j.nblocks = (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    j.block0 = jl.blocks; jl.blocks += j.nblocks;
+    jl.host.push_back(j);
+}
+void caddy_ctx::upload_jobs(JobList& jl, hipStream_t st) {
+    if ((int)jl.host.size() > jl.cap) { fail = true; set_error("internal: pack job table overflow"); return; }
+    hipMemcpyAsync(jl.dev, jl.host.data(), sizeof(PackJob) * jl.host.size(), hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);      // (once per mode: the host vector is pageable)
+}
 void caddy_ctx::pack_all(bool with_fold) {
     packed_fold = with_fold;
+    if (!with_fold && merged_pack && !dry) {      // training / evaluation graphs: every layer's forms in ONE launch
+        const int key = (prec_fwd != PREC_FP32 ? 1 : 0) | ((prec_bwd != PREC_FP32 && recording) ? 2 : 0);
+        JobList& jl = pack_jobs;
+        if (jl.key != key) {
+            jl.host.clear(); jl.blocks = 0;
+            for (ConvL* L : convs) {
+                const PackDesc& d = L->pd;
+                const long taps = (long)d.KS * d.KS;
+                add_job(jl, d, L->wp, PJ_FWD, -1, 0, 0, taps * d.Cout_pad * d.Ktot);
+                for (int s = 0; s < d.nseg; s++) add_job(jl, d, L->wpd[s], PJ_DGRAD, s, L->cd_pad[s], L->kd, taps * L->cd_pad[s] * L->kd);
+                if (L->wq && (key & 1)) { const int rp = round_up(d.Cout, hx_pick_bn(d.Cout)); add_job(jl, d, L->wq, PJ_HX_FWD_F16, -1, rp, 0, taps * hx_kq(d, -1) * rp); }
+                for (int s = 0; s < d.nseg; s++)
+                    if (L->wqd[s] && (key & 2)) { const int rp = round_up(d.seg_C[s], hx_pick_bn(d.seg_C[s])); add_job(jl, d, L->wqd[s], PJ_HX_DGRAD_BF16, s, rp, 0, taps * hx_kq(d, s) * rp); }
+            }
+            upload_jobs(jl, stream);
+            jl.key = key;
+        }
+        RUN(pack_jobs_launch(jl.dev, (int)jl.host.size(), jl.blocks, stream));
+    } else
     for (ConvL* L : convs) {
         PackDesc fpd = L->pd;      // forward forms: optionally with the following eval-mode BatchNorm folded in (roll-out)
         if (with_fold && L->fold_bn) {
@@ -846,8 +881,27 @@ void caddy_ctx::pack_all(bool with_fold) {
         RUN(pw_nchw_to_nhwc(lstm[i].init_c, 0, dv(lstm[i].ic), stream));
     }
 }
+// packed weight gradients -> the flat gradient buffer (reference layout): which = 0 every layer, 1 the early-bucket layers, 2 the others
+static void unpack_layers(caddy_ctx* c, int which, hipStream_t st) {
+    bool dry = c->dry;
+    if (c->merged_pack && !dry) {
+        caddy_ctx::JobList& jl = c->unpack_jobs[which];
+        if (jl.key != 1) {
+            jl.host.clear(); jl.blocks = 0;
+            for (ConvL* L : c->convs)
+                if (which == 0 || (which == 1) == L->early_bucket) c->add_job(jl, L->pd, L->dwp, PJ_UNPACK, -1, 0, 0, (long)L->pd.KS * L->pd.KS * L->pd.Cout_pad * L->pd.Ktot);
+            c->upload_jobs(jl, st);
+            jl.key = 1;
+        }
+        c->ck(pack_jobs_launch(jl.dev, (int)jl.host.size(), jl.blocks, st), "unpack jobs");
+        return;
+    }
+    for (ConvL* L : c->convs) if (which == 0 || (which == 1) == L->early_bucket) { if (!dry) c->ck(unpack_wgrad(L->pd, L->dwp, st), "unpack_wgrad"); }
+}
 void caddy_ctx::unpack_all() {
-    for (ConvL* L : convs) { if (!L->early_done) RUN(unpack_wgrad(L->pd, L->dwp, stream)); L->early_done = false; }
+    bool early = false;
+    for (ConvL* L : convs) { early = early || L->early_done; L->early_done = false; }
+    unpack_layers(this, early ? 2 : 0, stream);
     for (int i = 0; i < 3 && !lstm_early_done; i++) {
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, stream));
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ic), lstm[i].ginit_c, 0, 0, stream));
@@ -861,7 +915,8 @@ void caddy_ctx::early_gradient_buckets() {
     if (!grads_hook || dry) return;
     hipStream_t s2 = wgrad_stream();
     join_aux(s2);      // the conv bias gradients of R / D are part of the bucket ranges
-    for (ConvL* L : convs) if (L->early_bucket) { RUN(unpack_wgrad(L->pd, L->dwp, s2)); L->early_done = true; }
+    unpack_layers(this, 1, s2);
+    for (ConvL* L : convs) if (L->early_bucket) L->early_done = true;
     for (int i = 0; i < 3; i++) {
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ih), lstm[i].ginit_h, 0, 0, s2));
         RUN(pw_nhwc_to_nchw(gv(lstm[i].ic), lstm[i].ginit_c, 0, 0, s2));
@@ -1056,7 +1111,8 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
             hipMemsetAsync(gm, 0, c->gt_lo, st);
             if (c->act.off > c->gt_hi) hipMemsetAsync(gm + c->gt_hi, 0, c->act.off - c->gt_hi, st);
         } else hipMemsetAsync(gm, 0, c->act.off, st);
-        if (c->poison_nz && c->act.top < c->act.cap)      // test aid (caddy_debug_set_poison): NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
+        // test aid (caddy_debug_set_poison): NaN-fill the first-touch gradient region so that a read-before-assign cannot go unnoticed
+        if (c->poison_nz && c->act.top < c->act.cap) hipMemsetAsync((char*)c->act.base + c->grad_delta + c->act.top, 0xFF, c->act.cap - c->act.top, st);
             hipMemsetAsync(c->G, 0, sizeof(float) * c->n_train, st);
         hipMemsetAsync(c->zero_pool, 0, c->zero_pool_bytes, st);      // every layer's packed weight gradient, the ConvLSTM initial-state gradients, the loss accumulators
     }
@@ -1331,6 +1387,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
+    if (const char* e = getenv("CADDY_PACK_MERGED")) c->merged_pack = atoi(e) != 0;     // A/B aid: 0 = one (un)packing launch per layer and form
     if (const char* e = getenv("CADDY_D_STREAM")) c->use_dstream = atoi(e) != 0;        // A/B aid: 0 = teacher-forced decoder calls on the main stream
     if (const char* e = getenv("CADDY_BN_SMALL")) c->bn_small = atoi(e) != 0;           // A/B aid: 0 = no one-launch BatchNorm for tiny maps
     if (const char* e = getenv("CADDY_BN_LAZY")) c->lazy_bn = atoi(e) != 0;             // A/B aid: 0 = every BatchNorm output is materialised

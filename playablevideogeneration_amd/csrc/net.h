@@ -233,6 +233,12 @@ struct caddy_ctx {
     void alloc_gt_images(T4* gi, int Trec);
     void pack_all(bool fold = false);
     void unpack_all();
+    // one-launch (un)packing (pack.h: PackJob): job tables in the persistent arena, rebuilt when the precision / recording mode changes
+    struct JobList { std::vector<PackJob> host; PackJob* dev = nullptr; int cap = 0, blocks = 0, key = -1; };
+    JobList pack_jobs, unpack_jobs[3];      // unpack: 0 every layer, 1 the early-bucket layers (R / D), 2 the rest
+    void add_job(JobList& jl, const PackDesc& d, void* buf, int kind, int seg, int p0, int p1, long total);
+    void upload_jobs(JobList& jl, hipStream_t st);
+    bool merged_pack = true;
     void ck(int rc, const char* what);
 };
 

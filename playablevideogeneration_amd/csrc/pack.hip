@@ -3,44 +3,20 @@
 // Runs once per optimiser step (weights change every step); ~2 x 39 MB of traffic for BAIR-main: HBM-bound, negligible.
 #include "common.h"
 #include "pack.h"
+#include "pack_elems.h"
 
 namespace {
-__device__ __forceinline__ bool k_to_cin(const PackDesc& d, int k, int* cin) {
-    int base = 0;
-    for (int s = 0; s < d.nseg; s++) {
-        if (k < base + d.seg_Cpad[s]) { int c = k - base; if (c >= d.seg_C[s]) return false; *cin = d.seg_off[s] + c; return true; }
-        base += d.seg_Cpad[s];
-    }
-    return false;
-}
 __global__ void k_pack_fwd(PackDesc d, float* wp) {
     long total = (long)d.KS * d.KS * d.Cout_pad * d.Ktot;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int k = (int)(i % d.Ktot); long r = i / d.Ktot; int o = (int)(r % d.Cout_pad); int tap = (int)(r / d.Cout_pad);
-        float v = 0.f; int cin;
-        if (o < d.Cout && k_to_cin(d, k, &cin)) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * d.KS * d.KS + tap] * (d.oscale ? d.oscale[o] : 1.f);
-        wp[i] = v;
-    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) pk_fwd_elem(d, wp, i);
 }
-// dgrad weights of segment `seg`: wpd[tap'][c][o] = W[o][seg_off+c][KS*KS-1-tap']   (flip both spatial axes)
 __global__ void k_pack_dgrad(PackDesc d, int seg, float* wpd, int Cd_pad, int Kd) {
     long total = (long)d.KS * d.KS * Cd_pad * Kd;
-    int taps = d.KS * d.KS;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int o = (int)(i % Kd); long r = i / Kd; int c = (int)(r % Cd_pad); int tap = (int)(r / Cd_pad);
-        float v = 0.f;
-        if (o < d.Cout && c < d.seg_C[seg]) v = d.w[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + d.seg_off[seg] + c) * taps + (taps - 1 - tap)];
-        wpd[i] = v;
-    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) pk_dgrad_elem(d, seg, wpd, Cd_pad, Kd, i);
 }
 __global__ void k_unpack_wgrad(PackDesc d, const float* dwp) {
-    int taps = d.KS * d.KS;
-    long total = (long)taps * d.Cout_pad * d.Ktot;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int k = (int)(i % d.Ktot); long r = i / d.Ktot; int o = (int)(r % d.Cout_pad); int tap = (int)(r / d.Cout_pad);
-        int cin;
-        if (o < d.Cout && k_to_cin(d, k, &cin)) d.gw[o / d.Co_each][((long)(o % d.Co_each) * d.Cin + cin) * taps + tap] = dwp[i];
-    }
+    long total = (long)d.KS * d.KS * d.Cout_pad * d.Ktot;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) pk_unpack_elem(d, dwp, i);
 }
 // fused Adam (torch.optim.Adam semantics, L2 weight decay folded into the gradient; training/trainer.py:36,584-587)
 __global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale) {
