@@ -487,7 +487,9 @@ def property_case(lib, dev, c, seed=3, perceptual=False):
     g2 = eng.grads.clone()
     assert abs(l2["total"] - 2 * l1["total"]) <= 1e-6 * max(1.0, abs(l1["total"]))
     rel = ((g2 - 2 * g1).double().norm() / (2 * g1).double().norm()).item()
-    assert rel < 1e-4, ("backward not linear in the loss weights", rel)
+    # bound from a distribution, not one sample: tools/probes/linearity_noise.py on the MI355X gives 2e-5 .. 3e-4 for BOTH the repeat of the same backward and the
+    # x2 run at BAIR 256x256 T=16 B=8 (fp32 atomics of the split-K dgrads in arrival order, amplified through the 10 closed-loop steps); small geometries: < 1e-6
+    assert rel < 1e-3, ("backward not linear in the loss weights", rel)
     # (2) eval-mode batch permutation
     if B > 1:
         eng.params.copy_(saved)
