@@ -96,3 +96,21 @@ def test_evaluator_mirror_on_gpu():
     """headless Evaluator (per-position losses, entropies, MI, Hungarian accuracy) on the real kernels, vs the oracle"""
     from tests import test_host_api_emu as TE
     TE.headless_evaluator_case(_build, "cuda")
+
+
+def test_headless_drivers_cli_train_play_interpolate(tmp_path):
+    """`python -m playablevideogeneration_amd.drivers train|play|interpolate --config ...` (train.py:76-108, play.py:115-207, interpolate.py:102-158) end to end on
+    the real library: factories from the YAML, model.cuda(), DataLoader over the on-disk video format, checkpoints, evaluation, roll-out frames as PNGs"""
+    import os
+    from playablevideogeneration_amd import drivers as D
+    from tests.test_drivers_emu import _yaml_config
+    path = _yaml_config(tmp_path)
+    assert D.main(["train", "--config", path, "--max-steps", "2"]) == 0
+    cfg = D.load_configuration(path)
+    assert os.path.isfile(os.path.join(cfg["logging"]["save_root_directory"], "latest.pth.tar"))
+    out = str(tmp_path / "play_results")
+    assert D.main(["play", "--config", path, "--actions", "1,2,3,3", "--out", out, "--sample", "1:0"]) == 0
+    assert sorted(os.listdir(os.path.join(out, "0"))) == ["0.png", "1.png", "2.png", "3.png", "4.png", "play_metadata.pkl"]
+    assert D.main(["interpolate", "--config", path, "--first", "0", "--second", "1", "--steps", "2", "--frames", "3"]) == 0
+    seqs = cfg["logging"]["interpolated_sequences"]
+    assert sorted(os.listdir(seqs)) == ["0", "1", "2"] and len(os.listdir(os.path.join(seqs, "0"))) == 4
