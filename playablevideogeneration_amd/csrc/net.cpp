@@ -1209,40 +1209,42 @@ static int generate_next(caddy_ctx* c, const float* observation, int action, con
     const int H = g.height, W = g.width, S = g.stacking, K = g.actions, Da = g.action_dim;
     bool dry = c->dry;
     if (action < 0 || action >= K) { set_error("action out of range"); return -2; }
-    static const int graph_env = getenv("CADDY_ROLLOUT_GRAPH") ? atoi(getenv("CADDY_ROLLOUT_GRAPH")) : 1;      // A/B aid: 0 eager on the caller's stream, 2 eager on the internal stream
+    static const int graph_env = getenv("CADDY_ROLLOUT_GRAPH") ? atoi(getenv("CADDY_ROLLOUT_GRAPH")) : 1;      // A/B aid: 0 eager launches, 2 the graph launched on the internal stream (events to / from the caller's stream every frame)
     static const bool graph_off = graph_env == 0;
-    if (graph_env == 2) c->graph_failed_soft = true;
-    if (c->use_fold && !c->packed_fold) { if (c->gstream) hipStreamSynchronize(c->gstream); c->drop_graph(); c->prepare_inference_weights(); }      // a forward pass re-packed the plain weights since start_inference
     hipStream_t user = c->stream;
+    if (c->use_fold && !c->packed_fold) { if (c->graph_exec) { hipStreamSynchronize(user); if (c->gstream) hipStreamSynchronize(c->gstream); } c->drop_graph(); c->prepare_inference_weights(); }      // a forward pass re-packed the plain weights since start_inference
     const bool try_graph = c->use_graph && !graph_off && !c->graph_failed && !dry;
-    if (try_graph && !c->gstream) {
+    if (try_graph && !c->gstream) {      // internal stream: the frame's kernel sequence is CAPTURED there (the caller's stream may be the legacy default stream, which cannot be captured)
         if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { c->graph_failed = true; c->gstream = nullptr; }
         else { hipEventCreateWithFlags(&c->gev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->gev_out, hipEventDisableTiming); }
     }
     const bool graphed = try_graph && !c->graph_failed;
-    hipStream_t st = graphed ? c->gstream : user;
-    if (graphed) { hipEventRecord(c->gev_in, user); hipStreamWaitEvent(st, c->gev_in, 0); }      // inputs were produced on the caller's stream
+    // The graph is LAUNCHED on the caller's stream, between the two boundary kernels: launching it on the internal stream costs an event record + cross-queue wait in
+    // each direction per frame -- measured 682 vs 590 us per frame with identical kernels (CADDY_ROLLOUT_GRAPH=2 keeps that form for A/B runs).
+    const bool on_internal = graphed && graph_env == 2;
+    hipStream_t st = on_internal ? c->gstream : user;
+    if (on_internal) { hipEventRecord(c->gev_in, user); hipStreamWaitEvent(st, c->gev_in, 0); }
     c->act.reset();
     T4 o = c->alloc(1, H, W, 3 * S);      // NHWC observation the per-frame kernel sequence reads: first allocation of the frame -> the same address every frame
     if (!dry) c->ck(head_rollout_in(observation, o.d, H * W, 3 * S, o.ld, c->inf_aux, action, variation, K, Da, st), "observation layout + one-hot action + variation");
     if (graphed) {
-        if (!c->graph_valid && !c->graph_failed_soft) {      // first frame after start_inference: capture the kernel sequence (the capture itself executes nothing)
-            c->stream = st;
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (!c->graph_valid) {      // first frame after start_inference: capture the kernel sequence (the capture itself executes nothing)
+            c->stream = c->gstream;
+            bool ok = hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 rollout_body(c, o);
-                ok = hipStreamEndCapture(st, &c->graph) == hipSuccess && c->graph != nullptr && !c->fail;
+                ok = hipStreamEndCapture(c->gstream, &c->graph) == hipSuccess && c->graph != nullptr && !c->fail;
                 if (ok) ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) == hipSuccess;
             }
             c->stream = user;
             if (ok) c->graph_valid = true;
             else { c->drop_graph(); c->graph_failed = true; hipGetLastError(); c->fail = false; }
         }
-        if (c->graph_valid) { if (hipGraphLaunch(c->graph_exec, st) != hipSuccess) { c->graph_valid = false; c->graph_failed = true; } }
-        if (!c->graph_valid) { c->stream = st; rollout_body(c, o); c->stream = user; }      // capture failed: run this frame eagerly (still on the internal stream)
+        if (c->graph_valid) { if (hipGraphLaunch(c->graph_exec, st) != hipSuccess) { c->graph_valid = false; c->graph_failed = true; hipGetLastError(); } }
+        if (!c->graph_valid) { c->stream = st; rollout_body(c, o); c->stream = user; }      // capture / launch failed: run this frame (and the following ones) eagerly
     } else rollout_body(c, o);
     if (!dry) c->ck(head_rollout_out(c->roll_frame.d, c->roll_frame.ld, observation, frame_out, obs_out, H * W, 3 * S, st), "frame + next observation");
-    if (graphed) { hipEventRecord(c->gev_out, st); hipStreamWaitEvent(user, c->gev_out, 0); }
+    if (on_internal) { hipEventRecord(c->gev_out, st); hipStreamWaitEvent(user, c->gev_out, 0); }
     return c->fail ? -1 : 0;
 }
 
@@ -1262,7 +1264,7 @@ void caddy_ctx::prepare_inference_weights() {
 static int start_inference(caddy_ctx* c) {
     bool dry = c->dry;
     c->training = false; c->recording = false;
-    if (c->gstream) hipStreamSynchronize(c->gstream);  // a graph launch of the previous roll-out may still be executing: never destroy its exec object under it
+    if (c->graph_exec && !dry) { hipStreamSynchronize(c->stream); if (c->gstream) hipStreamSynchronize(c->gstream); }  // a graph launch of the previous roll-out may still be executing: never destroy its exec object under it
     c->drop_graph();                                   // weights / state may have changed: re-capture on the next frame
     c->prepare_inference_weights();
     for (int i = 0; i < 3; i++) {
@@ -1402,7 +1404,7 @@ extern "C" int caddy_dp_shutdown(caddy_ctx* c);
 void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && c->comm) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
-    if (c && c->gstream) { hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
+    if (c && c->gstream) { if (c->graph_exec) hipStreamSynchronize(c->stream); hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
     if (c) for (ConvL* L : c->convs) if (L->off_ev) hipEventDestroy(L->off_ev);
     if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
     delete c;

@@ -156,7 +156,7 @@ struct caddy_ctx {
     float* inf_aux = nullptr;
     T4 roll_frame{};                 // full-resolution frame (NHWC, pitch 4) of the per-frame kernel sequence
     hipStream_t gstream = nullptr; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
-    bool graph_valid = false, graph_failed = false, graph_failed_soft = false, use_graph = true;
+    bool graph_valid = false, graph_failed = false, use_graph = true;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     void drop_graph();
     // BatchNorm folding for the roll-out (weights are constant between start_inference calls): `fold` switches encode / dynamics / render to the
