@@ -65,6 +65,9 @@ typedef struct caddy_loss_cfg {
     int perceptual_log;
     int diagnostics;    /* != 0: also evaluate the logging-only scalars of the reference's loss_info (trainer.py:475-491, :358-375) on the device, into
                            losses_host[CADDY_DIAG_0 ...]: no tensor leaves the GPU and no extra host synchronisation is needed for them */
+    int no_sync;        /* != 0: losses_host (PINNED host memory) is filled by an asynchronous copy on the stream and the call returns without waiting for it -- the caller
+                           reads it after its own event / stream synchronisation, typically once the NEXT step has been enqueued (reference: the .item() calls of
+                           training/trainer.py:503-530 wait for the GPU every step) */
 } caddy_loss_cfg;
 
 /* losses_host slots.  CADDY_LOSS_PERCEPTUAL = avg_perceptual_loss, _TERM = loss_component_perceptual_loss (trainer.py:505,512);

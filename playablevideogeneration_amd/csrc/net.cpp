@@ -1178,7 +1178,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     c->mark("bwd:A1 + E(gt)");
     c->unpack_all();
     c->mark("bwd:join + unpack");
-    if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
+    if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); if (!lc->no_sync) hipStreamSynchronize(st); }
     return finish(c);
 }
 

@@ -40,7 +40,34 @@ class LossCfg(C.Structure):
     _fields_ = [("rec", C.c_double), ("states", C.c_double), ("entropy", C.c_double), ("dir_kl", C.c_double), ("mi", C.c_double),
                 ("state_kl", C.c_double), ("hidden", C.c_double), ("mi_entropy_lambda", C.c_double),
                 ("mi_ema", C.c_void_p), ("mi_ema_alpha", C.c_float), ("update_mi_ema", C.c_int),
-                ("perceptual", C.c_double), ("perceptual_log", C.c_int), ("diagnostics", C.c_int)]
+                ("perceptual", C.c_double), ("perceptual_log", C.c_int), ("diagnostics", C.c_int), ("no_sync", C.c_int)]
+
+
+def _losses_dict(host, diagnostics: bool, with_perceptual: bool) -> Dict[str, float]:
+    """losses_host slots of caddy_loss_backward -> the names the trainer mirror uses"""
+    res = {n: float(host[i]) for i, n in enumerate(LOSS_NAMES)}
+    if diagnostics:      # evaluated on the device inside the same call: no tensor fetch, no extra synchronisation
+        res["diagnostics"] = {n: float(host[DIAG_0 + i]) for i, n in enumerate(DIAG_NAMES)}
+    if with_perceptual:      # loss_info keys of trainer.py:459-462
+        for r in range(3):
+            res[f"perceptual_loss_r{r}"] = float(host[LOSS_PERC_R0 + 6 * r])
+            for l in range(5):
+                res[f"perceptual_loss_r{r}_l{l}"] = float(host[LOSS_PERC_R0 + 6 * r + 1 + l])
+    return res
+
+
+class PendingLosses:
+    """loss values of a caddy_loss_backward call issued with caddy_loss_cfg.no_sync: on their way into a pinned host buffer"""
+
+    def __init__(self, buf, event, diagnostics, with_perceptual):
+        self._buf, self._event, self._diag, self._perc, self._res = buf, event, diagnostics, with_perceptual, None
+
+    def result(self) -> Dict[str, float]:
+        if self._res is None:
+            self._event.synchronize()
+            self._res = _losses_dict(self._buf.tolist(), self._diag, self._perc)
+            self._buf = None
+        return self._res
 
 
 def _bind(lib):
@@ -122,6 +149,7 @@ class Engine:
             raise CaddyError(self._err())
         self.adam_m = self.adam_v = None
         self.mi_ema = None
+        self._pinned_losses, self._pinned_next = None, 0      # two pinned host buffers of loss_backward(deferred=True)
         self._keep = []
 
     def set_samplers(self, action_sampler=None, action_variation_sampler=None, gt_actions: Optional[torch.Tensor] = None):
@@ -406,25 +434,31 @@ class Engine:
         return g
 
     # ---- losses + backward (Trainer.compute_losses terms + loss.backward()) ----
-    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True, perceptual_log=False, diagnostics=False) -> Dict[str, float]:
+    def loss_backward(self, weights: Dict[str, float], smooth_mi=True, mi_alpha=0.2, update_mi_ema=True, perceptual_log=False, diagnostics=False, deferred=False):
+        """fused losses + BPTT backward.  -> {name: value} after the GPU has finished the call; with `deferred=True` (GPU only) -> a PendingLosses whose
+        `.result()` gives the same dict: the values travel by an asynchronous copy into pinned memory and the host does not wait for the backward pass"""
         if smooth_mi and self.mi_ema is None:
             self.mi_ema = torch.full((self.K, self.K), 1.0 / (self.K * self.K), dtype=torch.float32, device=self.device)
+        deferred = bool(deferred) and self.device.type == "cuda"
         lc = LossCfg(weights.get("rec", 0.0), weights.get("states", 0.0), weights.get("entropy", 0.0), weights.get("dir_kl", 0.0),
                      weights.get("mi", 0.0), weights.get("state_kl", 0.0), weights.get("hidden", 0.0), weights.get("mi_entropy", 1.0),
                      self.mi_ema.data_ptr() if smooth_mi else None, mi_alpha, int(update_mi_ema),
-                     weights.get("perceptual", 0.0), int(perceptual_log), int(diagnostics))
+                     weights.get("perceptual", 0.0), int(perceptual_log), int(diagnostics), int(deferred))
+        with_perc = bool(self.perceptual and self.vgg_loaded and (lc.perceptual != 0.0 or perceptual_log))
+        if deferred:
+            if self._pinned_losses is None:
+                self._pinned_losses = [torch.zeros(LOSS_SLOTS, dtype=torch.float64).pin_memory() for _ in range(2)]
+            buf = self._pinned_losses[self._pinned_next]
+            self._pinned_next ^= 1
+            self._stream()
+            self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), C.c_void_p(buf.data_ptr())))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return PendingLosses(buf, ev, bool(diagnostics), with_perc)
         host = (C.c_double * LOSS_SLOTS)()
         self._stream()
         self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), host))
-        res = {n: host[i] for i, n in enumerate(LOSS_NAMES)}
-        if diagnostics:      # evaluated on the device inside the same call: no tensor fetch, no extra synchronisation
-            res["diagnostics"] = {n: host[DIAG_0 + i] for i, n in enumerate(DIAG_NAMES)}
-        if self.perceptual and self.vgg_loaded and (lc.perceptual != 0.0 or perceptual_log):      # loss_info keys of trainer.py:459-462
-            for r in range(3):
-                res[f"perceptual_loss_r{r}"] = host[LOSS_PERC_R0 + 6 * r]
-                for l in range(5):
-                    res[f"perceptual_loss_r{r}_l{l}"] = host[LOSS_PERC_R0 + 6 * r + 1 + l]
-        return res
+        return _losses_dict(host, bool(diagnostics), with_perc)
 
     def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0):
         if self.adam_m is None:

@@ -145,6 +145,11 @@ class Trainer:
 
     # ---- Trainer.compute_losses (trainer.py:400-550): forward + fused losses + backward ----
     def compute_losses(self, model, batch, observations_count: int):
+        return self._compute_losses(model, batch, observations_count)()
+
+    def _compute_losses(self, model, batch, observations_count: int, deferred=False):
+        """enqueue forward + fused losses + backward; -> a function that returns compute_losses' triple (with `deferred` the GPU may still be running when this
+        returns: the loss values arrive by an asynchronous copy and only the returned function waits for them)"""
         gt = self.get_ground_truth_observations_count()
         if gt >= observations_count:
             gt = observations_count - 1
@@ -155,11 +160,14 @@ class Trainer:
         self._to_engine_device(eng)              # BEFORE the engine takes the raw pointer of the MI estimator (a checkpoint loaded before model.cuda() left it on the CPU)
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
-        li = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
-                               diagnostics=self.config["training"].get("loss_diagnostics", True))
+        pending = eng.loss_backward(self.loss_weights(), smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
+                                    diagnostics=self.config["training"].get("loss_diagnostics", True), deferred=deferred)
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema
         w = self.loss_weights()
+        return lambda: self._loss_info(model, eng, pending.result() if hasattr(pending, "result") else pending, w, gt, tau, observations_count)
+
+    def _loss_info(self, model, eng, li, w, gt, tau, observations_count):
         loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
                      "loss_component_perceptual_loss": li.get("perceptual_term", 0.0), "avg_perceptual_loss": li.get("perceptual", 0.0),
                      "loss_component_entropy": w["entropy"] * li["entropy"], "loss_component_action_directions_kl_divergence": w["dir_kl"] * li["dir_kl"],
@@ -174,6 +182,9 @@ class Trainer:
 
     # ---- Trainer.compute_losses_pretraining (trainer.py:241-398) ----
     def compute_losses_pretraining(self, model, batch, observations_count: int):
+        return self._compute_losses_pretraining(model, batch, observations_count)()
+
+    def _compute_losses_pretraining(self, model, batch, observations_count: int, deferred=False):
         tau = self.get_gumbel_temperature()
         batch_tuple = batch.to_tuple() if hasattr(batch, "to_tuple") else batch
         model(batch_tuple, pretraining=True, gumbel_temperature=tau, fetch_outputs=False)
@@ -182,10 +193,13 @@ class Trainer:
         if self.SMOOTH_MI and self.mi_ema is not None:
             eng.mi_ema = self.mi_ema
         w = self.loss_weights(pretraining=True)
-        li = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
-                               diagnostics=self.config["training"].get("loss_diagnostics", True))
+        pending = eng.loss_backward(w, smooth_mi=self.SMOOTH_MI, mi_alpha=self.mi_alpha, perceptual_log=self.vgg_state is not None,
+                                    diagnostics=self.config["training"].get("loss_diagnostics", True), deferred=deferred)
         if self.SMOOTH_MI:
             self.mi_ema = eng.mi_ema
+        return lambda: self._loss_info_pretraining(model, eng, pending.result() if hasattr(pending, "result") else pending, w, tau, observations_count)
+
+    def _loss_info_pretraining(self, model, eng, li, w, tau, observations_count):
         loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
                      "loss_component_perceptual_loss": li.get("perceptual_term", 0.0), "avg_perceptual_loss": li.get("perceptual", 0.0),
                      "loss_component_hidden_states_rec": w["hidden"] * li["hidden"], "loss_component_entropy": w["entropy"] * li["entropy"],
@@ -227,6 +241,7 @@ class Trainer:
         if hasattr(self.dataset, "set_observations_count"):
             self.dataset.set_observations_count(observations_count)
         performed = 0
+        pending_log = None
         if dataloader is None:
             dataloader = self.dataloader if self.dataloader is not None else self.dataset
         for batch in dataloader:
@@ -236,15 +251,26 @@ class Trainer:
             performed += 1
             if self.get_observations_count() != observations_count:
                 break
+            # the loss values of a step are only logged: they come back through an asynchronous copy and are read AFTER the next step has been enqueued, so the GPU never
+            # waits for the host between steps (the reference's .item() calls, trainer.py:503-530, stall it every step)
             if self.global_step <= self.config["training"].get("pretraining_steps", 0):
-                loss, loss_info, _ = self.compute_losses_pretraining(model, batch, observations_count)
+                finish = self._compute_losses_pretraining(model, batch, observations_count, deferred=True)
             else:
-                loss, loss_info, _ = self.compute_losses(model, batch, observations_count)
+                finish = self._compute_losses(model, batch, observations_count, deferred=True)
             self.optimizer_step(model)
-            loss_info["loss"] = loss
-            if self.logger is not None:
-                self.logger.print(f"step: {self.global_step} " + " ".join(f"{k}:{v:.3f}" for k, v in loss_info.items()) + f" lr: {self._get_current_lr():.4f}")
+            if pending_log is not None:
+                self._log_step(*pending_log)
+            pending_log = (finish, self.global_step, self._get_current_lr())
+        if pending_log is not None:
+            self._log_step(*pending_log)
         return performed
+
+    def _log_step(self, finish, step, lr):
+        loss, loss_info, _ = finish()
+        loss_info["loss"] = loss
+        self.last_loss_info = loss_info
+        if self.logger is not None:
+            self.logger.print(f"step: {step} " + " ".join(f"{k}:{v:.3f}" for k, v in loss_info.items()) + f" lr: {lr:.4f}")
 
     # ---- checkpoints in the reference's format (training/trainer.py:80-122, smooth_mi_trainer.py:23-68): "model" (state_dict), "optimizer"
     # (torch.optim.Adam.state_dict layout), "lr_scheduler" (MultiStepLR.state_dict layout), "mi_estimator", "step" -- a checkpoint written

@@ -114,3 +114,51 @@ def test_headless_drivers_cli_train_play_interpolate(tmp_path):
     assert D.main(["interpolate", "--config", path, "--first", "0", "--second", "1", "--steps", "2", "--frames", "3"]) == 0
     seqs = cfg["logging"]["interpolated_sequences"]
     assert sorted(os.listdir(seqs)) == ["0", "1", "2"] and len(os.listdir(os.path.join(seqs, "0"))) == 4
+
+
+def test_train_epoch_deferred_loss_readback_matches_step_by_step(tmp_path):
+    """train_epoch reads the loss values of step i through an asynchronous copy AFTER step i + 1 has been enqueued (caddy_loss_cfg.no_sync + pinned buffers): the
+    logged values and the parameters must be the ones of the plain compute_losses / optimizer_step sequence"""
+    cfg = _config()
+    cfg["logging"] = {"save_root_directory": str(tmp_path)}
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    P = O.make_params(d, seed=7)
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.rand(2, 4, 3, 32, 32, generator=g) * 2 - 1, None, None, None) for _ in range(4)]
+    mk = lambda m, lg: getattr(importlib.import_module(cfg["training"]["trainer"]), "trainer")(cfg, m, dataset=None, logger=lg)
+
+    class Log:
+        def __init__(self): self.lines = []
+        def print(self, *a, **k): self.lines.append(" ".join(str(x) for x in a))
+    ma = _build(cfg); ma.load_state_dict(P); ma.train()
+    la = Log(); ta = mk(ma, la); ta.global_step = 20000
+    torch.manual_seed(11)
+    assert ta.train_epoch(ma, batches) == 4
+    mb = _build(cfg); mb.load_state_dict(P); mb.train()
+    tb = mk(mb, None); tb.global_step = 20000
+    torch.manual_seed(11)
+    want = []
+    for b in batches:
+        tb.global_step += 1
+        loss, info, _ = tb.compute_losses(mb, b, 4)
+        tb.optimizer_step(mb)
+        want.append((tb.global_step, loss, info["avg_observations_rec_loss"]))
+    assert len(la.lines) == 4
+    import re
+    for i, (line, (step, loss, rec)) in enumerate(zip(la.lines, want)):      # every line carries ITS step's values (printed with 3 decimals); later steps differ by Adam's
+        assert line.startswith(f"step: {step} "), (line, step)               # response to the run-to-run round-off of the gradients (sign flips of ~0 gradients: +-2 lr)
+        got_rec = float(re.search(r"avg_observations_rec_loss:([-0-9.]+)", line).group(1)); got_loss = float(re.search(r" loss:([-0-9.]+) lr:", line).group(1))
+        tol = 6e-4 if i == 0 else 5e-3
+        assert abs(got_rec - rec) < tol and abs(got_loss - loss) < tol, (i, line, loss, rec)
+    assert abs(ta.last_loss_info["loss"] - want[-1][1]) < 5e-3
+    # one step through train_epoch == one step by hand (parameters; later steps amplify the run-to-run round-off of the gradients through Adam's normalisation)
+    mc = _build(cfg); mc.load_state_dict(P); mc.train()
+    tc = mk(mc, None); tc.global_step = 20000
+    torch.manual_seed(11)
+    assert tc.train_epoch(mc, batches[:1]) == 1
+    md = _build(cfg); md.load_state_dict(P); md.train()
+    td = mk(md, None); td.global_step = 20001
+    torch.manual_seed(11)
+    td.compute_losses(md, batches[0], 4); td.optimizer_step(md)
+    diff = (mc._flat - md._flat).abs()
+    assert (diff > 1e-5).float().mean().item() < 0.02 and diff.max().item() < 2.5 * cfg["training"]["learning_rate"], ((diff > 1e-5).float().mean().item(), diff.max().item())
