@@ -41,6 +41,9 @@ VGG_CONVS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2)
              (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]      # (Cin, Cout, number of 2x2 max-pools before): conv1_1 .. conv5_1
 
 
+DEFER_LOSSES = os.environ.get("CADDY_BENCH_SYNC_LOSSES", "0") != "1"
+
+
 def vgg_work(n_images, H, W):
     """Algorithmic work of the perceptual loss per step (SURVEY 8d definitions): two forward passes (ground truth + reconstruction) and
     one dgrad pass of the 13 VGG19 convolutions at the three resolutions.  -> (FLOPs, bytes)"""
@@ -298,7 +301,9 @@ def run(a, dev, lib=None, backend="nccl"):
     def step(weights=None):
         step_no[0] += 1
         eng.forward_full(obs, wl["gt_init"], wl["tau"], make_noise(B, T, K, Da, dev, gen), training=True, fetch_outputs=False)
-        losses = eng.loss_backward(loss_w if weights is None else weights, smooth_mi=True)
+        # the loss values leave the GPU through an asynchronous copy (caddy_loss_cfg.no_sync), as in the trainer's train_epoch: the host does not wait for the
+        # backward pass before it enqueues the optimiser step and the next forward (CADDY_BENCH_SYNC_LOSSES=1: the synchronous read-back)
+        losses = eng.loss_backward(loss_w if weights is None else weights, smooth_mi=True, deferred=DEFER_LOSSES)
         if world > 1:
             eng.allreduce_gradients()                       # R / D buckets (91 % of 39.4 MB) were started behind the side stream during the backward; the rest here
         eng.adam_step(step_no[0], lr=4e-4, weight_decay=1e-6, grad_scale=1.0 / world)
@@ -317,6 +322,8 @@ def run(a, dev, lib=None, backend="nccl"):
             out = step(weights)
         fence()
         dt = time.perf_counter() - t0
+        if hasattr(out, "result"):
+            out = out.result()
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,6 +333,8 @@ def run(a, dev, lib=None, backend="nccl"):
     for i in range(a.warmup):
         losses = step()
         sync()
+        if hasattr(losses, "result"):
+            losses = losses.result()
         log(f"warm-up step {i} done, loss {losses['total']:.5f}")
     ms_step, losses = timed(a.steps)                        # ---- the contract's timed region: EXACTLY K steps of the full step ----
     log(f"timed region done: {ms_step:.1f} ms/step")
