@@ -598,7 +598,8 @@ def split_vs_exact_case(lib, dev, c, seed=3):
     o_b, l_b, g_b = run(16, 0)           # same forward, exact-fp32 gradients
     o_e, l_e, g_e = run(0, 0)            # exact fp32 everywhere
     eng.set_precision(16, 17)
-    assert torch.equal(o_s[0], o_b[0]) and l_s["total"] == l_b["total"]          # (a) really shares the forward
+    assert torch.equal(o_s[0], o_b[0]), ("same forward arithmetic, different frames", (o_s[0] - o_b[0]).abs().max().item())          # (a) really shares the forward
+    assert abs(l_s["total"] - l_b["total"]) <= 1e-12 * abs(l_b["total"]), (l_s["total"], l_b["total"])      # (fp64 atomics of the loss sums: equal up to their order)
     assert torch.equal(o_s[5], o_e[5]), "action indices: split-f16 forward vs exact fp32"
     fmse = ((o_s[0] - o_e[0]) ** 2).mean(dim=(2, 3, 4)).max().item()
     res = {"frame_mse_split_vs_exact": fmse, "loss_split": l_s["total"], "loss_exact": l_e["total"]}
