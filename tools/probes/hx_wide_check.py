@@ -1,4 +1,5 @@
-"""256-channel-block variant of the 8-wave conv_hx tile (CADDY_HX_WIDE=1): result vs the exact-fp32 kernel, and time, at VGG19 shapes."""
+"""Result vs the exact-fp32 kernel, and time, of k_conv_hx at VGG19 shapes with >= 256 output channels.  Written for the 256-channel-block variant of the 8-wave tile
+(CADDY_HX_WIDE=1 in the experiment build; the variant was not kept -- profiles/r03_experiments.md -- and the switch no longer exists: the script now times the product kernel)."""
 import ctypes as C
 import os
 import sys
