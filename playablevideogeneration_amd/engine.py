@@ -6,6 +6,7 @@ loss + backward, optimiser step, start_inference / generate_next.  `lib` may be 
 build of the same kernel sources); the default is the gfx950 library and there is no CPU fallback.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -194,20 +195,33 @@ class Engine:
         self._early = []                     # (offset, count, work) of the buckets already in flight
         if world == 1 and not force:
             return
-        if native is None:
-            native = self.device.type == "cuda" and hasattr(self.lib, "caddy_dp_available") and self.lib.caddy_dp_available() == 1
+        if native is None:      # (CADDY_DP_NATIVE=0: the torch.distributed hooks even where RCCL is loadable)
+            native = (self.device.type == "cuda" and os.environ.get("CADDY_DP_NATIVE", "1") != "0"
+                      and hasattr(self.lib, "caddy_dp_available") and self.lib.caddy_dp_available() == 1)
         if native:
             rank = dist.get_rank(process_group)
             buf = C.create_string_buffer(128)
+            ok = 1
             if rank == 0:
-                self._check(self.lib.caddy_dp_unique_id(buf))
-            box = [buf.raw if rank == 0 else None]
+                ok = int(self.lib.caddy_dp_unique_id(buf) == 0)
+            box = [(buf.raw, ok) if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
-            self._stream()
-            self._check(self.lib.caddy_dp_init(self.ctx, box[0], world, rank, int(bool(overlap))))
-            self._dp_native = True
-            return
+            uid, ok = box[0]
+            if ok:
+                self._stream()
+                ok = int(self.lib.caddy_dp_init(self.ctx, uid, world, rank, int(bool(overlap))) == 0)
+            if world > 1:      # every rank must take the same path: one failed communicator sends all of them to the hook path
+                flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+                ok = int(flag.item())
+            if ok:
+                self._dp_native = True
+                return
+            import sys
+            print(f"[playablevideogeneration_amd] native RCCL data parallelism unavailable ({self._err()}): using the torch.distributed hooks", file=sys.stderr)
+            if hasattr(self.lib, "caddy_dp_shutdown"):
+                self.lib.caddy_dp_shutdown(self.ctx)
         base = self._ws_raw.data_ptr()
 
         def _hook(ptr, count, _user):
