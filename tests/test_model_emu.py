@@ -98,3 +98,33 @@ def test_full_reduced_s1_fused_batchnorm_paths():
         assert fc["never_materialised"] >= 10 and fc["stats_from_conv_epilogue"] >= 10, fc
     finally:
         M.SIM_SPLIT = False
+
+
+def test_merged_weight_packing_equals_per_layer_launches(monkeypatch):
+    """k_pack_jobs (every layer's packed / split weight forms and the un-packing of the weight gradients as ONE launch over a job table) against the per-layer
+    kernels: same forward bits, same gradients, on the split-operand arithmetic"""
+    import torch
+    from tests import helpers as H
+    lib = load_emu()
+    M.SIM_SPLIT = True
+    try:
+        res = []
+        for merged in ("1", "0"):
+            monkeypatch.setenv("CADDY_PACK_MERGED", merged)      # read when the context is created
+            c, z = H.load_case("full_reduced_s1")
+            d, P, obs = H.inputs_of(c)
+            eng = M.make_engine(c, lib, "cpu")
+            eng.load_state_dict(P)
+            torch.manual_seed(H.NOISE_SEED)
+            nz = M.O.Noise()
+            with torch.no_grad():
+                M.O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+            out = eng.forward_full(obs, c["gt"], c["tau"], M.noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+            eng.loss_backward(H.LOSS_W, smooth_mi=True, mi_alpha=0.2)
+            res.append((out[0].clone(), eng.grads.clone()))
+        assert torch.equal(res[0][0], res[1][0]), ("forward", (res[0][0] - res[1][0]).abs().max().item())
+        # gradients: equal up to the arrival order of the fp32 atomics (the simulator runs workgroups on several host threads): measured 2e-5 relative
+        rel = ((res[0][1] - res[1][1]).double().norm() / res[1][1].double().norm()).item()
+        assert rel < 2e-4, ("gradients", rel)
+    finally:
+        M.SIM_SPLIT = False
