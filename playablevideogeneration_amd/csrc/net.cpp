@@ -337,9 +337,10 @@ void caddy_ctx::ensure_dstream() {
     if (hipStreamCreateWithFlags(&dstream, hipStreamNonBlocking) != hipSuccess) dstream = nullptr;
     hipEventCreateWithFlags(&d_done, hipEventDisableTiming);
 }
+static bool aux_stream_off() { static const bool off = getenv("CADDY_AUX_STREAM") && atoi(getenv("CADDY_AUX_STREAM")) == 0; return off; }      // A/B aid
+bool caddy_ctx::aux_enabled() { if (dry || aux_stream_off()) return false; ensure_dstream(); return dstream != nullptr; }
 hipStream_t caddy_ctx::aux_grad_stream() {
-    static const bool off = getenv("CADDY_AUX_STREAM") && atoi(getenv("CADDY_AUX_STREAM")) == 0;      // A/B aid
-    if (dry || off) return stream;
+    if (dry || aux_stream_off()) return stream;
     ensure_dstream();
     if (!dstream || in_d) return stream;       // (already on the decoder stream: its own ops are off the chain anyway)
     hipEvent_t e = sev();
@@ -348,7 +349,25 @@ hipStream_t caddy_ctx::aux_grad_stream() {
     a_dirty = true;
     return dstream;
 }
+void caddy_ctx::defer_aux(std::function<void()> job) {
+    if (dry || in_d) { job(); return; }      // (in_d: already off the chain, on the decoder stream)
+    aux_jobs.push_back(std::move(job));
+    if (fork_batch <= 1 || (int)aux_jobs.size() >= fork_batch) flush_aux();
+}
+void caddy_ctx::flush_aux() {
+    if (aux_jobs.empty()) return;
+    std::vector<std::function<void()>> jobs;
+    jobs.swap(aux_jobs);
+    hipStream_t as = aux_grad_stream();      // ONE fork
+    if (as == stream) { for (auto& j : jobs) j(); return; }
+    StreamRes keep{stream, conv_aux, conv_split, red_scratch};
+    stream = as; conv_aux = dsr.aux; conv_split = dsr.split;
+    for (auto& j : jobs) j();
+    stream = keep.st; conv_aux = keep.aux; conv_split = keep.split;
+}
+void caddy_ctx::step_boundary() { flush_aux(); launch_wgrad_jobs(); }
 void caddy_ctx::join_aux(hipStream_t onto) {
+    flush_aux();
     if (!dstream || !a_dirty || dry || onto == dstream) return;
     hipEvent_t e = sev();
     hipEventRecord(e, dstream);
@@ -395,7 +414,7 @@ void caddy_ctx::flush_wgrad(PendingW& p) {
     p.count = 0; p.flops = 0;
     RUN(timed_conv_wgrad(w, fl));
 }
-void caddy_ctx::flush_all_wgrad() { for (auto& kv : pending) flush_wgrad(kv.second); }
+void caddy_ctx::flush_all_wgrad() { for (auto& kv : pending) flush_wgrad(kv.second); launch_wgrad_jobs(); }
 void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
     static const int chunk = getenv("CADDY_WGRAD_BATCH") ? atoi(getenv("CADDY_WGRAD_BATCH")) : 5;      // time steps per launch (1 = off)
     // only the per-time-step calls (N == batch) repeat; the B*T-frame passes of E / A run once or twice: launch those immediately so that
@@ -432,8 +451,22 @@ void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
     p->last_dy = w.dy;
     if (p->count >= chunk) flush_wgrad(*p);
 }
+// Weight-gradient launches and auxiliary-gradient jobs are handed to the other streams in batches of fork_batch (and at every time-step boundary of the backward): a fork --
+// hipEventRecord on the compute stream + hipStreamWaitEvent on the other one -- costs the RECORDING stream 5.3 us (tools/probes/event_cost.hip) and the BPTT chain forked
+// ~460 times per step.  Measured, E/R/A/D step: 1 / 4 / 8 / 16 per fork -> 73.6 / 73.1 / 73.1-73.3 / 73.5 ms (larger batches start the deferred work too late).
 int caddy_ctx::timed_conv_wgrad(const WgradArgs& a, double flops) {
-    hipStream_t stream = wgrad_stream();
+    if (dry || fork_batch <= 1 || !use_side || !side) return launch_conv_wgrad(a, flops, wgrad_stream());
+    wgrad_jobs.emplace_back(a, flops);
+    if ((int)wgrad_jobs.size() >= fork_batch) launch_wgrad_jobs();
+    return 0;
+}
+void caddy_ctx::launch_wgrad_jobs() {
+    if (wgrad_jobs.empty()) return;
+    hipStream_t s2 = wgrad_stream();      // ONE fork for all of them
+    for (auto& j : wgrad_jobs) RUN(launch_conv_wgrad(j.first, j.second, s2));
+    wgrad_jobs.clear();
+}
+int caddy_ctx::launch_conv_wgrad(const WgradArgs& a, double flops, hipStream_t stream) {
     if (!prof) return conv_wgrad_launch(a, stream);
     int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
     const double px = (double)a.N * a.H * a.W;
@@ -493,13 +526,20 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             bool bias_done = !Lp->dbias;
             bool any_aux = !bias_done;
             for (int s = 0; s < nseg; s++) any_aux = any_aux || (sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3);
-            hipStream_t as = any_aux ? aux_grad_stream() : stream;      // off the BPTT chain: nothing before the action network's backward / the optimiser reads these
-            for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
-                if (!(sg[s].need_grad && sg[s].bcast && Lp->pd.KS == 3)) continue;
-                RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmp[s].d, sg[s].t.g, sg[s].t.sn, bias_done ? nullptr : Lp->dbias, as));
-                bias_done = true;
+            if (any_aux) {      // off the BPTT chain: nothing before the action network's backward / the optimiser reads these (dz and the per-call scratch stay valid)
+                const bool bias_first = bias_done;
+                std::array<T4, CONV_MAX_SRC> tmpv{tmp[0], tmp[1], tmp[2]};
+                std::array<Seg, CONV_MAX_SRC> sgv{sg[0], sg[1], sg[2]};
+                defer_aux([=]() {
+                    bool bd = bias_first;
+                    for (int s = 0; s < nseg; s++) {      // broadcast inputs first: their border-aware sums of dY contain the bias gradient
+                        if (!(sgv[s].need_grad && sgv[s].bcast && Lp->pd.KS == 3)) continue;
+                        RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmpv[s].d, sgv[s].t.g, sgv[s].t.sn, bd ? nullptr : Lp->dbias, stream));
+                        bd = true;
+                    }
+                    if (!bd) RUN(pw_colsum(dzv, Lp->dbias, stream));
+                });
             }
-            if (!bias_done) RUN(pw_colsum(dzv, Lp->dbias, as));
             for (int s = 0; s < nseg; s++) {
                 if (!sg[s].need_grad) continue;
                 if (sg[s].bcast && Lp->pd.KS == 3) continue;
@@ -518,13 +558,17 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                     d.out = sg[s].t.g; d.out_sn = sg[s].t.sn; d.out_ld = sg[s].t.ld; d.accumulate = assign ? 0 : 1;
                     // d(h_{t-1}) of a ConvLSTM's gate convolution: first read by the previous time step's cell backward, a whole R -> E -> D backward later.  The launch
                     // (under-filled: 16x16 / 32x32 maps) goes to the decoder stream, beside the chain; lstm_step's BatchNorm backward joins it.
-                    hipStream_t as = (sg[s].off_chain && !assign) ? aux_grad_stream() : stream;
-                    if (as != stream) {
-                        StreamRes keep{stream, conv_aux, conv_split, red_scratch};
-                        stream = as; conv_aux = dsr.aux; conv_split = dsr.split; d.aux = conv_aux;
-                        RUN(timed_conv_fwd(d, dfl));
-                        if (!dry) { if (!Lp->off_ev) hipEventCreateWithFlags(&Lp->off_ev, hipEventDisableTiming); hipEventRecord(Lp->off_ev, as); Lp->off_pending = true; }
-                        stream = keep.st; conv_aux = keep.aux; conv_split = keep.split;
+                    if (sg[s].off_chain && !assign && !dry && !in_d && aux_enabled()) {
+                        const int pk = prof_kind_override;
+                        Lp->off_pending = true;      // (the consumer flushes the queued jobs before it waits for the event)
+                        defer_aux([=]() mutable {      // (runs with stream / scratch of the auxiliary stream)
+                            d.aux = conv_aux;
+                            const int keepk = prof_kind_override; prof_kind_override = pk;
+                            RUN(timed_conv_fwd(d, dfl));
+                            prof_kind_override = keepk;
+                            if (!Lp->off_ev) hipEventCreateWithFlags(&Lp->off_ev, hipEventDisableTiming);
+                            hipEventRecord(Lp->off_ev, stream);
+                        });
                     } else {
                         if (assign) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
                         RUN(timed_conv_fwd(d, dfl));
@@ -716,7 +760,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
             T4 ihg = L.ih, icg = L.ic;
             ConvL* Lg = &L.gates;
             tp->push_back([=]() {
-                if (Lg->off_pending && !dry) { hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; }      // d(initial h) comes from the first step's gate-convolution dgrad on the decoder stream
+                if (Lg->off_pending && !dry) { flush_aux(); hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; }      // d(initial h) comes from the first step's gate-convolution dgrad on the decoder stream
                 RUN(pw_batch_sum(hprev.g, hprev.sn, hprev.sn, B, ihg.g, stream));
                 RUN(pw_batch_sum(cprev.g, cprev.sn, cprev.sn, B, icg.g, stream));
             });
@@ -740,7 +784,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     L.h = hn; L.c = cn;
     T4 hb = bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
     if (recording) { ConvL* Lg = &L.gates;      // (reverse replay: first thing of this step's cell) d(h_t) also receives the NEXT step's gate-convolution dgrad, from the decoder stream
-        tp->push_back([=]() { if (Lg->off_pending && !dry) { hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; } }); }
+        tp->push_back([=]() { if (Lg->off_pending && !dry) { flush_aux(); hipStreamWaitEvent(stream, Lg->off_ev, 0); Lg->off_pending = false; } }); }
     return hb;
 }
 
@@ -913,6 +957,7 @@ void caddy_ctx::unpack_all() {
 // ranges to the caller, who starts their all-reduce while A and E-on-ground-truth-frames are still in their backward.
 void caddy_ctx::early_gradient_buckets() {
     if (!grads_hook || dry) return;
+    launch_wgrad_jobs();
     hipStream_t s2 = wgrad_stream();
     join_aux(s2);      // the conv bias gradients of R / D are part of the bucket ranges
     unpack_layers(this, 1, s2);
@@ -959,6 +1004,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     T4 aux_all{c->head1.b.aux, c->head1.b.d_aux, B * (T - 1), 1, 1, g.actions + g.action_dim, AUX_LD, AUX_LD};
     if (c->recording) c->tape.push_back([c]() { c->mark("bwd:time loop"); c->flush_all_wgrad(); c->early_gradient_buckets(); });      // runs AFTER the time loop's backward: the queued chunks (and the R / D gradient buckets) overlap with the A / E tail
     for (int t = 0; t < T - 1; t++) {
+        if (c->recording) c->tape.push_back([c]() { c->step_boundary(); });      // (reverse replay: after this time step's backward)
         if (t == gt_init - 1) { c->mark("fwd:teacher-forced steps"); if (c->recording) c->tape.push_back([c]() { c->mark("bwd:closed-loop steps"); }); }
         T4 state = chan(tslice(c->rec_x65, B, T, t), 0, 64);
         T4 aux = tslice(aux_all, B, T - 1, t);
@@ -1389,6 +1435,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
+    if (const char* e = getenv("CADDY_FORK_BATCH")) c->fork_batch = atoi(e);            // A/B aid: weight-gradient launches / auxiliary jobs per fork (<= 1: one fork each)
     if (const char* e = getenv("CADDY_PACK_MERGED")) c->merged_pack = atoi(e) != 0;     // A/B aid: 0 = one (un)packing launch per layer and form
     if (const char* e = getenv("CADDY_D_STREAM")) c->use_dstream = atoi(e) != 0;        // A/B aid: 0 = teacher-forced decoder calls on the main stream
     if (const char* e = getenv("CADDY_BN_SMALL")) c->bn_small = atoi(e) != 0;           // A/B aid: 0 = no one-launch BatchNorm for tiny maps

@@ -2,6 +2,7 @@
 // caller's workspace, and a tape that replays the forward graph in reverse for BPTT.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <functional>
 #include <string>
 #include <vector>
@@ -239,6 +240,11 @@ struct caddy_ctx {
     void add_job(JobList& jl, const PackDesc& d, void* buf, int kind, int seg, int p0, int p1, long total);
     void upload_jobs(JobList& jl, hipStream_t st);
     bool merged_pack = true;
+    int fork_batch = 4;      // weight-gradient launches / auxiliary-gradient jobs handed to the other stream per fork (CADDY_FORK_BATCH; <= 1: one fork each)
+    std::vector<std::pair<WgradArgs, double>> wgrad_jobs; std::vector<std::function<void()>> aux_jobs;
+    void launch_wgrad_jobs(); int launch_conv_wgrad(const WgradArgs& a, double flops, hipStream_t st);
+    void defer_aux(std::function<void()> job); void flush_aux(); void step_boundary();
+    bool aux_enabled();
     void ck(int rc, const char* what);
 };
 
