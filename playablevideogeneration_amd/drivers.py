@@ -4,6 +4,7 @@ display / wandb / ffmpeg plumbing, on the plugin seam the reference itself uses 
     python -m playablevideogeneration_amd.drivers train       --config cfg.yaml [--max-steps N]
     python -m playablevideogeneration_amd.drivers play        --config cfg.yaml --actions 1,3,3,2 [--out play_results] [--sample 0:0]
     python -m playablevideogeneration_amd.drivers interpolate --config cfg.yaml --first 1 --second 2 [--steps 6] [--frames 8]
+    python -m playablevideogeneration_amd.drivers build-dataset --config cfg.yaml
 
     train        train.py:76-108      epochs of trainer.train_epoch, `latest` checkpoint after each, `checkpoint_<step>` every save_freq steps, evaluation with the inferred
                                       actions every eval_freq steps and -- when the data carries annotations -- with the ground-truth actions mapped through the Hungarian
@@ -11,6 +12,8 @@ display / wandb / ffmpeg plumbing, on the plugin seam the reference itself uses 
     play         play.py:115-207      start_inference + generate_next per action; the action list replaces the key presses (1-based as typed there, 0 ends the sequence);
                                       frames as <out>/<sequence>/<i>.png and play_metadata.pkl {"actions", "timestamps"} as the reference writes them
     interpolate  interpolate.py:102-158  one sequence per interpolation value in linspace(0, 1, steps + 1) through generate_next_interpolation
+    build-dataset  build_evaluation_dataset.py:17-77  the `builder(config, dataset, logger)` factory of config["evaluation_dataset"]["builder"] on the TEST split: roll-outs with
+                                      one-hot actions and zero variations, written in the on-disk video format under logging.evaluation_dataset_directory
 
 The configuration defaults and directory layout are those of utils/configuration.py:31-110.  The model runs on the GPU through libcaddy_hip.so; there is no CPU path
 (the `*_loop` functions take the model object so that the tests can drive them with the emulator build of the same kernels).
@@ -228,7 +231,15 @@ def interpolate_loop(model, start_observation: torch.Tensor, first_action: int, 
     return sequences
 
 
-def _load_for_inference(config, logger):
+def build_dataset_loop(config, model, datasets, logger) -> int:
+    """build_evaluation_dataset.py:56-77 on a built model: -> number of videos written"""
+    path = config.get("evaluation_dataset", {}).get("builder", "playablevideogeneration_amd.evaluation_dataset_builder")
+    b = _factory(path, "builder")(config, datasets["test"], logger)
+    model.eval()
+    return len(b.build(model))
+
+
+def _load_for_inference(config, logger, required=True):
     """play.py:44-70: model, datasets, checkpoint (mandatory there: "Cannot play without loading checkpoint")"""
     model = build_model(config)
     datasets = build_datasets(config)
@@ -237,8 +248,9 @@ def _load_for_inference(config, logger):
         trainer.load_checkpoint(model)
     except Exception as e:
         logger.print(e)
-        logger.print("Cannot play without loading checkpoint")
-        raise SystemExit(1)
+        if required:
+            logger.print("Cannot play without loading checkpoint")
+            raise SystemExit(1)
     return model, datasets
 
 
@@ -250,6 +262,7 @@ def main(argv=None) -> int:
     p.add_argument("--out", default="play_results"); p.add_argument("--sample", default="0:0", help="batch_index:observation_index of the first validation batch")
     p = sub.add_parser("interpolate"); p.add_argument("--config", required=True); p.add_argument("--first", type=int, required=True); p.add_argument("--second", type=int, required=True)
     p.add_argument("--steps", type=int, default=6); p.add_argument("--frames", type=int, default=8); p.add_argument("--out", default=None)
+    p = sub.add_parser("build-dataset"); p.add_argument("--config", required=True)
     args = ap.parse_args(argv)
     config = load_configuration(args.config)
     logger = HeadlessLogger(config)
@@ -257,6 +270,11 @@ def main(argv=None) -> int:
         model = build_model(config)
         res = train_loop(config, model, build_datasets(config), logger, args.max_steps)
         logger.print(f"- finished at step {res['steps']} after {res['epochs']} epoch(s)")
+        return 0
+    if args.cmd == "build-dataset":      # (build_evaluation_dataset.py goes on without a checkpoint: its `raise` is commented out)
+        model, datasets = _load_for_inference(config, logger, required=False)
+        n = build_dataset_loop(config, model, datasets, logger)
+        logger.print(f"- {n} videos written to {config['logging']['evaluation_dataset_directory']}")
         return 0
     model, datasets = _load_for_inference(config, logger)
     obs = _first_observations(datasets["validation"], config["evaluation"]["batching"]["batch_size"])

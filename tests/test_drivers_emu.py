@@ -28,7 +28,8 @@ def _yaml_config(tmp_path):
     os.makedirs(root)
     _dataset(root)
     cfg = _config()
-    cfg["data"].update({"data_root": root, "dataset_splits": [0.5, 0.5, 0.0]})
+    cfg["data"].update({"data_root": root, "dataset_splits": [0.5, 0.25, 0.25]})
+    cfg["evaluation_dataset"] = {"builder": "playablevideogeneration_amd.evaluation_dataset_builder", "ground_truth_observations_init": 2}
     cfg["model"]["representation_network"]["target_input_size"] = [W, H]
     cfg["logging"] = {"output_root": str(tmp_path / "out"), "save_root": str(tmp_path / "ckpt"), "run_name": "run0"}
     cfg["training"]["batching"].update({"batch_size": 2, "skip_frames": 0, "num_workers": 0, "observations_count": 4, "observations_count_start": 4})
@@ -105,3 +106,19 @@ def test_train_then_play_then_interpolate(tmp_path):
     with torch.no_grad():
         f, _ = m2.generate_next(start, 0)
     assert np.array_equal(seqs[0][1], D.frame_to_uint8(f))
+
+
+def test_build_evaluation_dataset_loop(tmp_path):
+    """build_evaluation_dataset.py:56-77: roll-outs of the TEST split (one-hot actions, zero variations, gt_init from the config) written in the on-disk video format
+    that VideoDataset reads back"""
+    cfg = D.load_configuration(_yaml_config(tmp_path))
+    logger = D.HeadlessLogger(cfg, echo=False)
+    datasets = VD.build_datasets(cfg)
+    m = _make_model(cfg)
+    n = D.build_dataset_loop(cfg, m, datasets, logger)
+    assert n == len(datasets["test"]) and n > 0
+    out = cfg["logging"]["evaluation_dataset_directory"]
+    assert sorted(os.listdir(out)) == [f"{i:05d}" for i in range(n)]
+    back = VD.VideoDataset(out, cfg["evaluation"]["batching"], VD.final_transform(cfg))
+    assert len(back) == n and back.all_videos[0].get_frames_count() == cfg["evaluation"]["batching"]["observations_count"]
+    assert back.all_videos[0].metadata[0]["model"] == "ours" and "inferred_action" in back.all_videos[0].metadata[0]
