@@ -114,6 +114,9 @@ def test_headless_drivers_cli_train_play_interpolate(tmp_path):
     assert D.main(["interpolate", "--config", path, "--first", "0", "--second", "1", "--steps", "2", "--frames", "3"]) == 0
     seqs = cfg["logging"]["interpolated_sequences"]
     assert sorted(os.listdir(seqs)) == ["0", "1", "2"] and len(os.listdir(os.path.join(seqs, "0"))) == 4
+    assert D.main(["build-dataset", "--config", path]) == 0                                   # build_evaluation_dataset.py:17-77
+    out_ds = cfg["logging"]["evaluation_dataset_directory"]
+    assert len(os.listdir(out_ds)) > 0 and os.path.isfile(os.path.join(out_ds, "00000", "00000.png")) and os.path.isfile(os.path.join(out_ds, "00000", "actions.pkl"))
 
 
 def test_train_epoch_deferred_loss_readback_matches_step_by_step(tmp_path):
