@@ -185,7 +185,9 @@ int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, f
                     int step, float grad_scale);
 
 /* --- play.py roll-out: Model.start_inference (model.py:561-568) / Model.generate_next (model.py:570-607), eval mode.
- *     observation: (3S,H,W); variation: (Da) or NULL (= zeros, noise=False); frame_out: (3,H,W); obs_out: (3S,H,W). --- */
+ *     observation: (3S,H,W); variation: (Da) or NULL (= zeros, noise=False); frame_out: (3,H,W); obs_out: (3S,H,W) or NULL.
+ *     observation, frame_out and obs_out must NOT overlap (obs_out = cat[frame, observation[:-3]] is written while observation is read):
+ *     an overlapping call is rejected with -2. --- */
 int caddy_start_inference(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
@@ -216,6 +218,7 @@ int caddy_debug_count(caddy_ctx* ctx);
 int caddy_debug_fusion_counts(caddy_ctx* ctx, long* out3);
 /* tests / A-B: which BatchNorm paths the driver may pick (all default to 1): the one-launch kernel for tiny maps, the lazily applied form, statistics from the conv epilogue */
 int caddy_debug_set_bn_paths(caddy_ctx* ctx, int small, int lazy, int epilogue_stats);
+int caddy_debug_set_pack_merged(caddy_ctx* ctx, int on);      /* tests: 0 = one (un)packing launch per layer and form instead of the job-table launch */
 int caddy_debug_dims(caddy_ctx* ctx, int i, int* nhwc4);
 int caddy_debug_get(caddy_ctx* ctx, int i, int grad, float* dst_nchw);
 

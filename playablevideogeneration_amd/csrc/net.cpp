@@ -228,6 +228,8 @@ void build_layers(caddy_ctx* c) {
     }
     c->inf_aux = (float*)c->persist.alloc(AUX_LD * 4);      // roll-out: one-hot action + variation row read by the captured per-frame kernel sequence
     if (g.perceptual) vgg_build(c);
+    for (int i = 0; i < 3; i++) c->d_norm[i].deferred = true;      // D's BatchNorms: their calls execute on two streams (see BNL)
+    for (int i = 0; i < 2; i++) { c->d_res[i].bn1.deferred = c->d_res[i].bn2.deferred = true; if (c->d_res[i].has_down) c->d_res[i].bnd.deferred = true; }
     {   // zero pool: packed weight gradients of every layer + the (1,h,w,C) gradients of the learned ConvLSTM initial states + the loss accumulators,
         // contiguous so that loss_backward clears them with a single memset
         size_t bytes = 0;
@@ -236,12 +238,15 @@ void build_layers(caddy_ctx* c) {
         for (ConvL* L : c->convs) offs.push_back(take(L->wp_floats * 4));
         size_t lo[3][2];
         for (int i = 0; i < 3; i++) { lo[i][0] = take(c->lstm[i].ih.sn * 4); lo[i][1] = take(c->lstm[i].ic.sn * 4); }
+        std::vector<std::pair<BNL*, size_t>> bnd;      // private parameter-gradient accumulators of the decoder stream: [dgamma | dbeta]
+        for (BNL* b : c->bns) if (b->deferred) bnd.emplace_back(b, take(sizeof(float) * 2 * (size_t)round_up(b->C, 4)));
         const size_t acc_off = take(sizeof(double) * LOSS_SLOTS);
         char* pool = (char*)c->persist.alloc(bytes);
         c->zero_pool = pool; c->zero_pool_bytes = bytes;
         for (size_t i = 0; i < c->convs.size(); i++) c->convs[i]->dwp = (float*)(pool + offs[i]);
         for (int i = 0; i < 3; i++) { c->lstm[i].ih.g = (float*)(pool + lo[i][0]); c->lstm[i].ic.g = (float*)(pool + lo[i][1]); }
         c->loss_acc = (double*)(pool + acc_off);
+        for (auto& kv : bnd) { kv.first->dgamma_d = (float*)(pool + kv.second); kv.first->dbeta_d = kv.first->dgamma_d + round_up(kv.first->C, 4); }
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
@@ -255,8 +260,6 @@ void build_layers(caddy_ctx* c) {
     c->dsr.aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->dsr.split = (float*)c->persist.alloc(sizeof(float) * c->conv_split_cap);
     c->dsr.red = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
-    for (int i = 0; i < 3; i++) c->d_norm[i].deferred = true;
-    for (int i = 0; i < 2; i++) { c->d_res[i].bn1.deferred = c->d_res[i].bn2.deferred = true; if (c->d_res[i].has_down) c->d_res[i].bnd.deferred = true; }
 }
 }  // namespace
 
@@ -304,10 +307,13 @@ int caddy_ctx::timed_conv_fwd(const ConvArgs& a, double flops) {
     prof_recs.push_back(r);
     return rc;
 }
+// CADDY_STREAMS=0: every kernel of the step on the caller's stream, in program order (serialised kernel breakdowns: tools/gpu_final_b.sh; also the reference point of the
+// determinism tests).  One switch for the whole topology -- weight-gradient stream, decoder stream, auxiliary gradients, VGG19 levels: a partial combination (e.g. the decoder
+// stream without the side stream) would put two accumulating writers of one buffer on different streams.
+bool caddy_serial_streams() { static const bool serial = getenv("CADDY_STREAMS") && atoi(getenv("CADDY_STREAMS")) == 0; return serial; }
 void caddy_ctx::ensure_side() {
     if (!use_side || side) return;
-    static const bool off = getenv("CADDY_SIDE_STREAM") && atoi(getenv("CADDY_SIDE_STREAM")) == 0;
-    if (off) { use_side = false; return; }
+    if (caddy_serial_streams()) { use_side = false; return; }
     // lowest priority: weight-gradient workgroups fill the compute units the BPTT chain leaves idle (R's small feature maps,
     // point-wise kernels) instead of competing with it
     int least = 0, greatest = 0;
@@ -337,7 +343,7 @@ void caddy_ctx::ensure_dstream() {
     if (hipStreamCreateWithFlags(&dstream, hipStreamNonBlocking) != hipSuccess) dstream = nullptr;
     hipEventCreateWithFlags(&d_done, hipEventDisableTiming);
 }
-static bool aux_stream_off() { static const bool off = getenv("CADDY_AUX_STREAM") && atoi(getenv("CADDY_AUX_STREAM")) == 0; return off; }      // A/B aid
+static bool aux_stream_off() { return caddy_serial_streams(); }
 bool caddy_ctx::aux_enabled() { if (dry || aux_stream_off()) return false; ensure_dstream(); return dstream != nullptr; }
 hipStream_t caddy_ctx::aux_grad_stream() {
     if (dry || aux_stream_off()) return stream;
@@ -402,6 +408,16 @@ void caddy_ctx::replay_tape2(bool concurrent) {
         leave_d();
     }
 }
+void caddy_ctx::fold_d_bn_grads() {
+    VecAddJobs j{};
+    for (BNL* b : bns) {
+        if (!b->dgamma_d) continue;
+        if (j.count + 2 > VEC_ADD_MAX) { RUN(pw_vec_add(j, stream)); j.count = 0; }
+        j.dst[j.count] = b->dgamma; j.src[j.count] = b->dgamma_d; j.n[j.count++] = b->C;
+        j.dst[j.count] = b->dbeta; j.src[j.count] = b->dbeta_d; j.n[j.count++] = b->C;
+    }
+    if (j.count) RUN(pw_vec_add(j, stream));
+}
 void caddy_ctx::flush_wgrad(PendingW& p) {
     if (p.count == 0) return;
     WgradArgs w = p.first;
@@ -416,7 +432,7 @@ void caddy_ctx::flush_wgrad(PendingW& p) {
 }
 void caddy_ctx::flush_all_wgrad() { for (auto& kv : pending) flush_wgrad(kv.second); launch_wgrad_jobs(); }
 void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
-    static const int chunk = getenv("CADDY_WGRAD_BATCH") ? atoi(getenv("CADDY_WGRAD_BATCH")) : 5;      // time steps per launch (1 = off)
+    const int chunk = 5;      // time steps per launch
     // only the per-time-step calls (N == batch) repeat; the B*T-frame passes of E / A run once or twice: launch those immediately so that
     // they overlap with the rest of the backward instead of piling up behind flush_all_wgrad()
     if (chunk <= 1 || dry || w.N != cfg.batch) { RUN(timed_conv_wgrad(w, flops)); return; }
@@ -637,8 +653,7 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
 bool caddy_ctx::lazy_ok(const ConvL& consumer, const T4& x) const {
     if (!lazy_bn || !consumer.wq || prec_fwd == PREC_FP32 || consumer.pd.KS != 3) return false;
     if (recording) {      // its weight gradient must run on k_wgrad_hx (conv_hx_wgrad_try's conditions)
-        static const bool wg_off = getenv("CADDY_WGRAD_HX") && atoi(getenv("CADDY_WGRAD_HX")) == 0;
-        if (wg_off || prec_bwd == PREC_FP32 || consumer.pd.Cout < 32 || consumer.pd.Ktot < 32 || x.W < 8 || x.H < 2) return false;
+        if (prec_bwd == PREC_FP32 || consumer.pd.Cout < 32 || consumer.pd.Ktot < 32 || x.W < 8 || x.H < 2) return false;
     }
     return (x.ld & 3) == 0 && (x.sn & 3) == 0;
 }
@@ -658,7 +673,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             BNL* b1 = &bn;
             tp->push_back([=]() {
                 const float* ls = actf ? s1.scale : nullptr;
-                RUN(pw_bn_bwd_reduce(gv(out), nullptr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream, ls, s1.shift));
+                RUN(pw_bn_bwd_reduce(gv(out), nullptr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream, ls, s1.shift));
                 RUN(pw_bn_bwd_apply(gv(out), nullptr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream, ls, s1.shift));
             });
         }
@@ -684,13 +699,13 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             const TV* omp = actf ? &om : nullptr;
             if (small) {
                 TV dres{}; if (has2) dres = gv(x2c);
-                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), b1->dgamma, b1->dbeta, has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
+                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), bn_dgamma(b1), bn_dbeta(b1), has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
                 return;
             }
-            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, b1->dgamma, b1->dbeta, stream));   // sums assigned; param grads fused
+            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream));   // sums assigned; param grads fused
             RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream));
             if (has2 && b2) {
-                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, b2->dgamma, b2->dbeta, stream));
+                RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, bn_dgamma(b2), bn_dbeta(b2), stream));
                 RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
             } else if (has2) {
                 if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream, x2c.nz2 ? 1 : 0));      // identity path: first writer of d(x) when x is nz2
@@ -1016,7 +1031,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
             c->render(hdn, t, T - 1);
             c->leave_d();
             if (t + 2 >= gt_init || t + 2 >= T) c->tape.push_back([c]() {      // (reverse replay: runs right before R-bwd of the last teacher-forced step)
-                if (c->d_forked && !c->dry) { hipStreamWaitEvent(c->stream, c->d_done, 0); c->d_forked = false; }
+                if (c->d_forked && !c->dry) { hipStreamWaitEvent(c->stream, c->d_done, 0); c->d_forked = false; c->fold_d_bn_grads(); }
                 else if (!c->tape2_done) c->replay_tape2(false);
             });
         } else c->render(hdn, t, T - 1);
@@ -1434,13 +1449,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { set_error("buffers must be 256-byte (workspace) / 16-byte (params, grads) aligned"); return nullptr; }
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
-    if (const char* e = getenv("CADDY_ROLLOUT_FOLD")) c->use_fold = atoi(e) != 0;      // A/B aid: 0 = roll-out with separate BatchNorm launches
-    if (const char* e = getenv("CADDY_FORK_BATCH")) c->fork_batch = atoi(e);            // A/B aid: weight-gradient launches / auxiliary jobs per fork (<= 1: one fork each)
-    if (const char* e = getenv("CADDY_PACK_MERGED")) c->merged_pack = atoi(e) != 0;     // A/B aid: 0 = one (un)packing launch per layer and form
-    if (const char* e = getenv("CADDY_D_STREAM")) c->use_dstream = atoi(e) != 0;        // A/B aid: 0 = teacher-forced decoder calls on the main stream
-    if (const char* e = getenv("CADDY_BN_SMALL")) c->bn_small = atoi(e) != 0;           // A/B aid: 0 = no one-launch BatchNorm for tiny maps
-    if (const char* e = getenv("CADDY_BN_LAZY")) c->lazy_bn = atoi(e) != 0;             // A/B aid: 0 = every BatchNorm output is materialised
-    if (const char* e = getenv("CADDY_BN_EPI_STATS")) c->epi_stats = atoi(e) != 0;      // A/B aid: 0 = BatchNorm statistics by a separate pass over the conv output
+    if (caddy_serial_streams()) c->use_dstream = false;
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
         else if (!strcmp(e, "fwd")) { c->prec_bwd = PREC_FP32; c->vgg_precision_bwd = PREC_FP32; }
@@ -1459,6 +1468,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
 int caddy_debug_set_bn_paths(caddy_ctx* c, int small, int lazy, int epilogue_stats) { c->bn_small = small != 0; c->lazy_bn = lazy != 0; c->epi_stats = epilogue_stats != 0; return 0; }
+int caddy_debug_set_pack_merged(caddy_ctx* c, int on) { c->merged_pack = on != 0; c->pack_jobs.key = -1; for (auto& j : c->unpack_jobs) j.key = -1; return 0; }
 int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }
 int caddy_set_sampler_hook(caddy_ctx* c, caddy_sampler_hook hook, void* user, int provides_samples, int provides_variations) {
@@ -1502,7 +1512,10 @@ int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
     return vgg_load(c, vgg_flat);
 }
 int caddy_set_perceptual_prefetch(caddy_ctx* c, int on) { c->perc_prefetch = on != 0; return 0; }
-int caddy_set_rollout_fold(caddy_ctx* c, int on) { c->use_fold = on != 0; c->drop_graph(); c->packed_fold = false; return 0; }
+int caddy_set_rollout_fold(caddy_ctx* c, int on) {
+    if (c->graph_exec && !c->dry) { hipStreamSynchronize(c->stream); if (c->gstream) hipStreamSynchronize(c->gstream); }      // a launch of the graph may still be executing: never destroy its exec object under it
+    c->use_fold = on != 0; c->drop_graph(); c->packed_fold = false; return 0;
+}
 int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
 int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }
@@ -1512,6 +1525,12 @@ int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inferenc
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     c->fail = false;
     if (!observation || !frame_out) { set_error("null input"); return -2; }
+    {   // the boundary kernel behind the frame reads `observation` while it writes obs_out = cat[frame, observation[:-3]] and frame_out: the buffers must not overlap
+        const size_t ob = sizeof(float) * 3 * (size_t)c->cfg.stacking * c->cfg.height * c->cfg.width, fb = sizeof(float) * 3 * (size_t)c->cfg.height * c->cfg.width;
+        auto overlap = [](const void* a, size_t na, const void* b, size_t nb) { return (const char*)a < (const char*)b + nb && (const char*)b < (const char*)a + na; };
+        if ((obs_out && overlap(observation, ob, obs_out, ob)) || overlap(observation, ob, frame_out, fb) || (obs_out && overlap(obs_out, ob, frame_out, fb))) {
+            set_error("caddy_generate_next: observation, frame_out and obs_out must not overlap (in-place update of the stacked observation is not supported)"); return -2; }
+    }
     if (c->lstm[0].h.d != c->lstm[0].ph.d || c->lstm[0].h.d == nullptr) { set_error("call caddy_start_inference first"); return -2; }
     return generate_next(c, observation, action, variation, frame_out, obs_out);
 }

@@ -69,6 +69,9 @@ struct ConvL {
     hipEvent_t off_ev = nullptr; bool off_pending = false;
 };
 struct BNL { std::string name; float *gamma, *beta, *dgamma, *dbeta, *rmean, *rvar; int C; long calls = 0;
+             // D's BatchNorms are replayed on TWO streams in the backward (teacher-forced steps on the decoder stream beside the closed-loop steps on the main stream): the
+             // decoder stream accumulates into private (dgamma_d, dbeta_d), folded into the flat gradient buffer after the join -- no read-modify-write race, fixed order
+             float *dgamma_d = nullptr, *dbeta_d = nullptr;
              float* eval_stash = nullptr; bool eval_valid = false;
              // deferred running-statistics update (D's BatchNorms: their calls execute on two streams): every train-mode call leaves (mean, unbiased variance) in its
              // stash and the momentum updates are applied in CALL order by one kernel at the end of the forward
@@ -110,6 +113,9 @@ struct caddy_ctx {
     void enter_d(bool fork);
     void leave_d();
     void replay_tape2(bool concurrent);
+    void fold_d_bn_grads();      // after the join of the decoder stream's backward: G += the private BatchNorm parameter gradients (BNL::dgamma_d)
+    float* bn_dgamma(BNL* b) const { return in_d && b->dgamma_d ? b->dgamma_d : b->dgamma; }
+    float* bn_dbeta(BNL* b) const { return in_d && b->dbeta_d ? b->dbeta_d : b->dbeta; }
     void end_forward();
     bool tape2_done = false;
     std::vector<T4> dbg;             // every alloc() of the current forward (debug introspection, caddy_debug_*)
@@ -216,7 +222,7 @@ struct caddy_ctx {
     struct TileStats { const float* x = nullptr; float* part = nullptr; int tiles = 0, ldp = 0; };
     TileStats stats_ring[2]; int stats_next = 0;      // the two most recent producers (a residual block's conv2 and its 1x1 down-sampling conv feed one bn_act call)
     const TileStats* find_stats(const float* x) const { for (const TileStats& t : stats_ring) if (t.x == x && t.tiles > 0) return &t; return nullptr; }
-    bool lazy_bn = true, epi_stats = true, bn_small = true;      // A/B switches (CADDY_BN_LAZY=0, CADDY_BN_EPI_STATS=0, CADDY_BN_SMALL=0; tests: caddy_debug_set_bn_paths)
+    bool lazy_bn = true, epi_stats = true, bn_small = true;      // test switches (caddy_debug_set_bn_paths)
     long n_bn_lazy = 0, n_bn_tile_stats = 0, n_bn_calls = 0;      // since creation: BatchNorm calls applied lazily / finalised from conv-epilogue partial sums / all train-mode calls (caddy_debug_fusion_counts)
     bool lazy_ok(const ConvL& consumer, const T4& x) const;
     T4 pool2(const T4& x, bool act = false);
@@ -240,7 +246,7 @@ struct caddy_ctx {
     void add_job(JobList& jl, const PackDesc& d, void* buf, int kind, int seg, int p0, int p1, long total);
     void upload_jobs(JobList& jl, hipStream_t st);
     bool merged_pack = true;
-    int fork_batch = 4;      // weight-gradient launches / auxiliary-gradient jobs handed to the other stream per fork (CADDY_FORK_BATCH; <= 1: one fork each)
+    int fork_batch = 4;      // weight-gradient launches / auxiliary-gradient jobs handed to the other stream per fork (measured 1 / 4 / 8 / 16: profiles/r03_experiments.md)
     std::vector<std::pair<WgradArgs, double>> wgrad_jobs; std::vector<std::function<void()>> aux_jobs;
     void launch_wgrad_jobs(); int launch_conv_wgrad(const WgradArgs& a, double flops, hipStream_t st);
     void defer_aux(std::function<void()> job); void flush_aux(); void step_boundary();
@@ -250,3 +256,4 @@ struct caddy_ctx {
 
 void build_param_table(const caddy_config& c, std::vector<ParamEntry>& t, long* n_floats, long* n_train);
 void set_error(const std::string& s);
+bool caddy_serial_streams();      // CADDY_STREAMS=0 (net.cpp)

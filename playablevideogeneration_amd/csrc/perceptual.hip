@@ -315,7 +315,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
     // The half- and quarter-resolution levels (24 % of the work, most of it in under-filled launches on 8x8 ... 64x64 maps) run on the driver's side
     // stream BESIDE the full-resolution level: separate memory (they are allocated first and stay live until the join), their own thin-kernel
     // scratch, the three levels only meet in the loss accumulators (atomics) and write disjoint gradient tensors (d rec_r).
-    static const bool no_par = getenv("CADDY_VGG_LEVELS_PARALLEL") && atoi(getenv("CADDY_VGG_LEVELS_PARALLEL")) == 0;      // A/B aid
+    const bool no_par = caddy_serial_streams();
     const bool par = !no_par && !dry && c->use_side && c->side != nullptr && !c->prof;
     hipStream_t side = par ? c->wgrad_stream() : st;      // (ordered after the L1 kernels that wrote the seeds / resized ground truth)
     const size_t mark_all = c->act.off;

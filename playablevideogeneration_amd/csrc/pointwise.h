@@ -50,3 +50,7 @@ int pw_bcast_input_grad(const TV& dz, const PackDesc& d, int seg, float* S /* N*
                         float* dbias /* nullable: the conv's bias gradient falls out of the same sums */, hipStream_t st);
 int pw_fold_bias(const float* bias /* nullable */, const float* scale, const float* shift, float* out, int C, hipStream_t st);
 int pw_batch_sum(const float* src, long sn, long n_el, int N, float* dst, hipStream_t st);
+// dst[i][k] += src[i][k] for up to VEC_ADD_MAX short vectors in ONE launch (private per-stream parameter-gradient accumulators -> the flat gradient buffer)
+#define VEC_ADD_MAX 24
+struct VecAddJobs { float* dst[VEC_ADD_MAX]; const float* src[VEC_ADD_MAX]; int n[VEC_ADD_MAX]; int count; };
+int pw_vec_add(const VecAddJobs& j, hipStream_t st);

@@ -100,20 +100,21 @@ def test_full_reduced_s1_fused_batchnorm_paths():
         M.SIM_SPLIT = False
 
 
-def test_merged_weight_packing_equals_per_layer_launches(monkeypatch):
+def test_merged_weight_packing_equals_per_layer_launches():
     """k_pack_jobs (every layer's packed / split weight forms and the un-packing of the weight gradients as ONE launch over a job table) against the per-layer
     kernels: same forward bits, same gradients, on the split-operand arithmetic"""
+    import ctypes as C
     import torch
     from tests import helpers as H
     lib = load_emu()
     M.SIM_SPLIT = True
     try:
         res = []
-        for merged in ("1", "0"):
-            monkeypatch.setenv("CADDY_PACK_MERGED", merged)      # read when the context is created
+        for merged in (1, 0):
             c, z = H.load_case("full_reduced_s1")
             d, P, obs = H.inputs_of(c)
             eng = M.make_engine(c, lib, "cpu")
+            lib.caddy_debug_set_pack_merged(C.c_void_p(eng.ctx), merged)
             eng.load_state_dict(P)
             torch.manual_seed(H.NOISE_SEED)
             nz = M.O.Noise()

@@ -8,10 +8,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o bair --
 python tools/rocprof_summary.py gpurun_out/prof_stats/bair_results.db "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plugin (BAIR 256x256, T=16, B=8 incl. VGG19 perceptual loss; timed steps + erad-only leg + profiled steps + exact-fp32 step + 4 x 36-frame roll-outs)" > gpurun_out/kernel_stats.txt
 head -12 gpurun_out/kernel_stats.txt | cut -c1-90,105-160
 rm -rf gpurun_out/prof_stats gpurun_out/prof_serial
-CADDY_SIDE_STREAM=0 CADDY_D_STREAM=0 CADDY_AUX_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout --no-extra-legs --no-plugin > /dev/null 2> gpurun_out/bench_serial.err
+CADDY_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout --no-extra-legs --no-plugin > /dev/null 2> gpurun_out/bench_serial.err
 python tools/step_breakdown.py gpurun_out/prof_serial/bair_results.db 60 > gpurun_out/step_breakdown_serial.txt; head -3 gpurun_out/step_breakdown_serial.txt
 rm -rf gpurun_out/prof_serial
-CADDY_SIDE_STREAM=0 CADDY_D_STREAM=0 CADDY_AUX_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout --no-perceptual --no-extra-legs --no-plugin > /dev/null 2> gpurun_out/bench_serial_erad.err
+CADDY_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_serial -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout --no-perceptual --no-extra-legs --no-plugin > /dev/null 2> gpurun_out/bench_serial_erad.err
 python tools/step_breakdown.py gpurun_out/prof_serial/bair_results.db 60 > gpurun_out/step_breakdown_serial_erad.txt; head -3 gpurun_out/step_breakdown_serial_erad.txt
 rm -rf gpurun_out/prof_serial gpurun_out/prof_tl
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tl -o bair -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-rollout --no-perceptual --no-extra-legs --no-plugin > /dev/null 2> gpurun_out/bench_tl.err

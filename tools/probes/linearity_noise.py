@@ -26,4 +26,4 @@ for it in range(4):
     eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False); g1 = eng.grads.clone()
     eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False); g1b = eng.grads.clone()
     eng.loss_backward(w2, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False); g2 = eng.grads.clone()
-    print(f"merged={os.environ.get('CADDY_PACK_MERGED', '1')} repeat {rel(g1b, g1):.2e}  linear {rel(g2, 2 * g1):.2e}", flush=True)
+    print(f"repeat {rel(g1b, g1):.2e}  linear {rel(g2, 2 * g1):.2e}", flush=True)
