@@ -65,6 +65,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     constexpr int BM = TH * TW;
     constexpr int HW_ = TW + 2, HH_ = TH + 2, HPX = HW_ * HH_;
     constexpr int PITCH = NPL * KC + 8;                      // LDS row pitch in 16-bit elements: 72 (144 B) or 40 (80 B)
+    // Halo image: pixel (hy, hx) at hy * AROW + hx * PITCH with the ROW pitch a multiple of 256 B.  A 32x32x16 A-fragment read (ds_read_b128) covers two tile rows of 16
+    // pixels; the instruction is serviced in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32), i.e. 8 pixels of one tile row and 8 of the next.  With the odd
+    // 16-byte-slot pitch (9 or 5) pixels i and j of one row never share a slot unless i = j (mod 16); a row pitch of k * 256 B makes the second row's pixels fall on the
+    // slots of the SAME pixel numbers, i.e. on the eight slots the first row's eight pixels leave free: conflict-free.  (Dense rows -- HW_ * PITCH -- put two of the 16 pixels
+    // of every group on a busy slot: SQ_LDS_BANK_CONFLICT was 35 % of SQ_LDS_IDX_ACTIVE on the 8 x 16 x 64 tile, profiles/r04_conv_pmc.md.)
+    constexpr int AROW = (HW_ * PITCH + 127) / 128 * 128;
     constexpr int APP = NT / 8;                              // halo pixels staged per pass (8 threads x float4 cover one pixel's 32-channel chunk)
     constexpr int NA = (HPX + APP - 1) / APP;
     constexpr int BROW16 = NPL * KC * 2 / 16;                // 16-byte pieces per weight row
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     static_assert((WM * WN == 4 || WM * WN == 8) && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave layout");
     static_assert(TW == 16, "row <-> pixel map assumes 16-pixel tile rows");
     static_assert(D == 1 || D == 3, "9 taps per chunk: the ring depth must divide 9");
-    __shared__ __attribute__((aligned(16))) T As[HPX * PITCH];
+    __shared__ __attribute__((aligned(16))) T As[HH_ * AROW];
     __shared__ __attribute__((aligned(16))) T Bs[2][BN * PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,14 +102,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     const int nchunks = a.Kq / KC;
 
     // ---- A staging roles: float4 column q of halo pixels (tid >> 3) + 32 i ----
+    // (pixel order inside every block of eight: 0 4 1 5 2 6 3 7 -- the 16 contiguous lanes that one ds_write_b64 group serves then hold pixels p and p + 4, whose 64-byte
+    //  halves fall on disjoint bank halves (pixel pitch 36 dwords = 4 mod 32); neighbouring pixels p, p + 1 overlapped on 12 of their 16 banks)
     const int q = tid & 7;
+    const int tp = ((tid >> 3) & ~7) | (((tid >> 3) & 1) << 2) | (((tid >> 3) >> 1) & 3);
     int pixoff[NA];                                           // (y * W + x) of the halo pixel, -1: outside the image / beyond the halo
+    int aoff[NA];                                             // element offset of that pixel's row in the LDS image
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-        const int p = (tid >> 3) + APP * i;
+        const int p = tp + APP * i;
         const int hy = p / HW_, hx = p - hy * HW_;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         pixoff[i] = (p < HPX && y >= 0 && y < a.H && x >= 0 && x < a.W) ? y * a.W + x : -1;
+        aoff[i] = hy * AROW + hx * PITCH + 4 * q;
     }
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         const bool bn_ = sg_.bn_scale != nullptr;               /* wave-uniform */                                                \
         const float sl_ = sg_.bn_act ? 0.2f : 1.f;                                                                                \
         _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                                          \
-            const int p_ = (tid >> 3) + APP * i;                                                                                  \
+            const int p_ = tp + APP * i;                                                                                          \
             if (HPX % APP == 0 || p_ < HPX) {                                                                                      \
                 const bool ok_ = cok_ && pixoff[i] >= 0;                                                                           \
                 float4 v_ = ra[i];                                                                                                 \
@@ -151,8 +162,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
                 lo_[0] = (T)(x0_ - (float)hi_[0]); lo_[1] = (T)(x1_ - (float)hi_[1]);                                             \
                 lo_[2] = (T)(x2_ - (float)hi_[2]); lo_[3] = (T)(x3_ - (float)hi_[3]);                                             \
-                *reinterpret_cast<v4*>(&As[p_ * PITCH + 4 * q]) = hi_;                                                            \
-                if (NPL == 2) *reinterpret_cast<v4*>(&As[p_ * PITCH + KC + 4 * q]) = lo_;                                         \
+                *reinterpret_cast<v4*>(&As[aoff[i]]) = hi_;                                                                       \
+                if (NPL == 2) *reinterpret_cast<v4*>(&As[aoff[i] + KC]) = lo_;                                                    \
             }                                                                                                                      \
         }                                                                                                                          \
     } while (0)
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
 #pragma unroll
     for (int i = 0; i < TMt; i++) {
         const int m = wm * (BM / WM) + i * 32 + (lane & 31);
-        abase[i] = ((m / TW) * HW_ + (m % TW)) * PITCH + (lane >> 5) * 8;
+        abase[i] = (m / TW) * AROW + (m % TW) * PITCH + (lane >> 5) * 8;
     }
 #pragma unroll
     for (int j = 0; j < TNt; j++) bbase[j] = (wn * (BN / WN) + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 8;
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
 #if !(HX_EXPERIMENT & 2)
                 if (tap == (D == 1 ? 0 : 3)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile: consumed >= 6 steps later (last chunk: re-requested, unused)
 #endif
-                const int toff = ((tap / 3) * HW_ + tap % 3) * PITCH;
+                const int toff = (tap / 3) * AROW + (tap % 3) * PITCH;
                 const T* Bt = Bs[bbuf];
 #pragma unroll
                 for (int s = 0; s < KC / 16; s++) {

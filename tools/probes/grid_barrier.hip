@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_barrier_loop(u64* rec, unsigned* ctr /*
             else __hip_atomic_store(rs + (long)wg * 64 + tid, tag + tid, RLX, AGENT);
         }
         if (mode == 1) __threadfence();
-        else __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's write-through stores have left
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left (inline asm: invisible to the compiler's wait-count pass)
         __syncthreads();
         if (tid == 0) {
             bool ok;
