@@ -75,7 +75,10 @@ typedef struct caddy_loss_cfg {
  * reference logs it (in-place aliasing at training/losses.py:483-487, which also makes levels 1..4 count twice in the term). */
 enum { CADDY_LOSS_TOTAL = 0, CADDY_LOSS_REC, CADDY_LOSS_STATES, CADDY_LOSS_ENTROPY, CADDY_LOSS_DIRKL, CADDY_LOSS_MI,
        CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2,
-       CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12, CADDY_LOSS_PERC_R0 = 16,
+       CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12,
+       CADDY_LOSS_F16_SATURATED = 13,      /* 1.0: a split-f16 forward convolution (model or VGG19) staged |x| > 65504 since the forward began; it was clamped to the f16 range -- switch
+                                              the context to the exact-fp32 forward: caddy_set_precision(ctx, 0, 17) / caddy_set_vgg_precision(ctx, 0, 17) */
+       CADDY_LOSS_PERC_R0 = 16,
        /* caddy_loss_cfg.diagnostics: samples_entropy, action_distribution_entropy, states_magnitude, hidden_states_magnitude, action_directions_{mean,variance}_magnitude,
         * reconstructed_action_directions_{mean,variance}_magnitude, action_directions_reconstruction_error, reconstructed_action_directions_kl_loss,
         * centroids_mean_magnitude, average_centroids_distance, average_action_variations_norm_l2, action_variations_mean -- in this order */
@@ -189,6 +192,8 @@ int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, f
  *     observation, frame_out and obs_out must NOT overlap (obs_out = cat[frame, observation[:-3]] is written while observation is read):
  *     an overlapping call is rejected with -2. --- */
 int caddy_start_inference(caddy_ctx* ctx);
+/* 1 if a split-f16 forward convolution met an input beyond the f16 range (|x| > 65504, clamped) since the last forward / caddy_start_inference began; waits for the stream */
+int caddy_f16_saturated(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.

@@ -41,6 +41,7 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return 
 #define HX_EXPERIMENT 0      // timing experiments only (tools/gpu_hx_experiments.sh): 1 = no weight-tile traffic in the K loop, 2 = no activation staging, 4 = no per-tap barrier
 #endif
 constexpr int KC = HX_KC;      // channels per chunk
+#define HX_F16_MAX 65504.f
 struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; const float* bn_scale; const float* bn_shift; int bn_act; int bn_gn; long bn_gs; };
 template <typename T> struct is_bf16 { static constexpr bool value = false; };
 template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
     float4 ra[NA];
+    float amax = 0.f;                                         // split-f16 only: largest |x| this thread staged (saturation guard, ConvArgs.sat_flag)
     float4 rsc, rsh;                                          // lazily applied BatchNorm of the producer (ConvSrc.bn_*): scale / shift of this thread's four channels, chunk in flight
 #define HX_SEG_OF(chunk_)                                                                                                          \
         int s_ = 0, c0_ = (chunk_) * KC;                                                                                          \
@@ -156,8 +158,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     v_.x = v_.x > 0.f ? v_.x : sl_ * v_.x; v_.y = v_.y > 0.f ? v_.y : sl_ * v_.y;                                  \
                     v_.z = v_.z > 0.f ? v_.z : sl_ * v_.z; v_.w = v_.w > 0.f ? v_.w : sl_ * v_.w;                                  \
                 }                                                                                                                  \
-                const float x0_ = ok_ ? v_.x : 0.f, x1_ = (ok_ && m1_) ? v_.y : 0.f;                                               \
-                const float x2_ = (ok_ && m2_) ? v_.z : 0.f, x3_ = (ok_ && m3_) ? v_.w : 0.f;                                      \
+                float x0_ = ok_ ? v_.x : 0.f, x1_ = (ok_ && m1_) ? v_.y : 0.f;                                                     \
+                float x2_ = (ok_ && m2_) ? v_.z : 0.f, x3_ = (ok_ && m3_) ? v_.w : 0.f;                                            \
+                if (!is_bf16<T>::value) {      /* f16 range guard: clamp (a NaN stays a NaN), remember the largest magnitude */    \
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x0_), fabsf(x1_))), fmaxf(fabsf(x2_), fabsf(x3_)));                       \
+                    x0_ = fabsf(x0_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x0_) : x0_; x1_ = fabsf(x1_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x1_) : x1_; \
+                    x2_ = fabsf(x2_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x2_) : x2_; x3_ = fabsf(x3_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x3_) : x3_; \
+                }                                                                                                                  \
                 v4 hi_, lo_;                                                                                                       \
                 hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
                 lo_[0] = (T)(x0_ - (float)hi_[0]); lo_[1] = (T)(x1_ - (float)hi_[1]);                                             \
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         }
     }
 
+    if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > HX_F16_MAX) atomicOr(a.sat_flag, 1u);      // (rare: one atomic per saturating thread)
     // ---- epilogue: D fragment map col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile) ----
     float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
 #pragma unroll

@@ -385,6 +385,7 @@ __global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1
         acc[LOSS_TOTAL] += term / 3.0;
     }
 }
+__global__ void k_report_flag(const unsigned* flag, double* slot) { *slot = *flag != 0 ? 1.0 : 0.0; }
 __global__ void k_softmax_rows(const float* logits, float* prob, float* logp, int NS, int K) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= NS) return;
@@ -555,5 +556,9 @@ int loss_small(const SmallLossArgs& a, allreduce_hook_t hook, void* user, hipStr
 int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, double n2, double nstates, double nhidden, const VggLevels* lv, hipStream_t st) {
     VggLevels l{}; if (lv) l = *lv;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden, l, lv ? 1 : 0);
+    return 0;
+}
+int loss_report_flag(const unsigned* flag, double* slot, hipStream_t st) {
+    hipLaunchKernelGGL(k_report_flag, dim3(1), dim3(1), 0, st, flag, slot);
     return 0;
 }

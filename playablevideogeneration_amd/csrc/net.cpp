@@ -249,6 +249,7 @@ void build_layers(caddy_ctx* c) {
         for (auto& kv : bnd) { kv.first->dgamma_d = (float*)(pool + kv.second); kv.first->dbeta_d = kv.first->dgamma_d + round_up(kv.first->C, 4); }
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
+    c->sat_flag = (unsigned*)c->persist.alloc(256);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_aux2 = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
@@ -505,7 +506,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf; a.out = out.d;
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
-    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; }
+    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag; }
     for (int s = 0; s < nseg; s++)
         if (segs[s].t.bn_scale && !conv_src_lazy_ok(a)) { fail = true; set_error("internal: lazily normalised input handed to a convolution that cannot apply it"); }
     TileStats* ts_slot = nullptr;
@@ -1000,6 +1001,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
     c->mark("fwd:begin");
+    if (!dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream);
     c->pack_all();
     c->mark("fwd:packed");
     caddy_noise z{}; if (nz) z = *nz;
@@ -1079,6 +1081,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
+    if (!dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream);
     c->pack_all();
     caddy_noise z{}; if (nz) z = *nz;
     c->obs = c->alloc(B * T, H, W, 3 * S);
@@ -1239,6 +1242,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     c->mark("bwd:A1 + E(gt)");
     c->unpack_all();
     c->mark("bwd:join + unpack");
+    if (!dry) c->ck(loss_report_flag(c->sat_flag, c->loss_acc + LOSS_F16_SATURATED, st), "saturation flag");      // after the VGG19 forward passes of this call, on whatever stream they ran
     if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); if (!lc->no_sync) hipStreamSynchronize(st); }
     return finish(c);
 }
@@ -1521,7 +1525,14 @@ int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }
     c->prec_fwd = forward; c->prec_bwd = backward; return 0;
 }
-int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
+int caddy_start_inference(caddy_ctx* c) { c->fail = false; if (!c->dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream); return start_inference(c); }
+int caddy_f16_saturated(caddy_ctx* c) {      // waits for the stream: 1 if a split-f16 forward convolution met |x| > 65504 since the last forward / start_inference began
+    unsigned v = 0;
+    if (c->dry) return 0;
+    hipMemcpyAsync(&v, c->sat_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    hipStreamSynchronize(c->stream);
+    return v != 0;
+}
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     c->fail = false;
     if (!observation || !frame_out) { set_error("null input"); return -2; }

@@ -146,6 +146,7 @@ struct caddy_ctx {
     // native data parallelism (dp_rccl.cpp): a communicator owned by the context; the hooks above then point at ncclAllReduce wrappers
     void* comm = nullptr; int comm_world = 1; std::vector<std::pair<long, long>> comm_buckets; hipStream_t comm_bucket_stream = nullptr;
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
+    unsigned* sat_flag = nullptr;    // f16 range guard of the split-f16 forward (ConvArgs.sat_flag): ORed by any staging thread that met |x| > 65504 since the last forward began
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     float* conv_aux2 = nullptr;      // ... of the VGG19 levels that run on the side stream (perceptual.hip)

@@ -240,6 +240,7 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
         a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld;
         a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : (c->vgg_precision == PREC_BF16X3 ? PREC_BF16X3 : PREC_F16X3));
         if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : (a.precision == PREC_BF16X3 ? 2 : 0)];
+        a.sat_flag = c->sat_flag;      // f16 range guard: real VGG19 weights on un-normalised inputs are where a forward activation could leave the f16 range
         // MaxPool2d(2, 2) in front of the next conv: written by THIS conv's epilogue on the split-operand kernel (the window's four pixels sit in
         // one lane) -- no separate pass over the full-resolution map; a branch that is never back-propagated (keep_all = false: the ground truth)
         // does not even store the full-resolution map of such a layer (it is no tap: the taps are the first convs AFTER a pool)

@@ -47,6 +47,7 @@ class LossCfg(C.Structure):
 def _losses_dict(host, diagnostics: bool, with_perceptual: bool) -> Dict[str, float]:
     """losses_host slots of caddy_loss_backward -> the names the trainer mirror uses"""
     res = {n: float(host[i]) for i, n in enumerate(LOSS_NAMES)}
+    res["f16_saturated"] = bool(host[13])      # CADDY_LOSS_F16_SATURATED: a split-f16 forward convolution clamped an input beyond the f16 range (see Engine.f16_saturated)
     if diagnostics:      # evaluated on the device inside the same call: no tensor fetch, no extra synchronisation
         res["diagnostics"] = {n: float(host[DIAG_0 + i]) for i, n in enumerate(DIAG_NAMES)}
     if with_perceptual:      # loss_info keys of trainer.py:459-462
@@ -105,6 +106,7 @@ def _bind(lib):
     lib.caddy_set_rollout_fold.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_set_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
+    lib.caddy_f16_saturated.argtypes = [C.c_void_p]
     lib.caddy_generate_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_bn_layer_count.argtypes = [C.c_void_p]
     lib.caddy_bn_calls.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
@@ -482,6 +484,11 @@ class Engine:
                                              weight_decay, step, grad_scale))
 
     # ---- roll-out (Model.start_inference / generate_next) ----
+    def f16_saturated(self) -> bool:
+        """True if a split-f16 forward convolution (model or VGG19) met |x| > 65504 since the last forward / start_inference began: the value was clamped to the f16 range.
+        Remedy: `set_precision(0, 17)` / `set_vgg_precision(0, 17)` (exact-fp32 forward).  Waits for the stream."""
+        return bool(self.lib.caddy_f16_saturated(self.ctx))
+
     def start_inference(self):
         self._stream()
         self._check(self.lib.caddy_start_inference(self.ctx))

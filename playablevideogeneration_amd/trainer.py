@@ -167,7 +167,19 @@ class Trainer:
         w = self.loss_weights()
         return lambda: self._loss_info(model, eng, pending.result() if hasattr(pending, "result") else pending, w, gt, tau, observations_count)
 
+    def _check_saturation(self, eng, li):
+        """f16 range guard of the split-f16 forward (CADDY_LOSS_F16_SATURATED): a forward activation beyond +-65504 was clamped in that step.  The engine keeps training on the
+        exact-fp32 forward from here on (slower, no range limit); the reference has no such limit (fp32 throughout)."""
+        if li.get("f16_saturated") and not getattr(self, "_saturation_handled", False):
+            self._saturation_handled = True
+            eng.set_precision(0, 17)
+            if self.vgg_state is not None:
+                eng.set_vgg_precision(0, 17)
+            if self.logger is not None:
+                self.logger.print("warning: a forward activation exceeded the f16 range (|x| > 65504) and was clamped; switching the engine to the exact-fp32 forward")
+
     def _loss_info(self, model, eng, li, w, gt, tau, observations_count):
+        self._check_saturation(eng, li)
         loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
                      "loss_component_perceptual_loss": li.get("perceptual_term", 0.0), "avg_perceptual_loss": li.get("perceptual", 0.0),
                      "loss_component_entropy": w["entropy"] * li["entropy"], "loss_component_action_directions_kl_divergence": w["dir_kl"] * li["dir_kl"],
@@ -200,6 +212,7 @@ class Trainer:
         return lambda: self._loss_info_pretraining(model, eng, pending.result() if hasattr(pending, "result") else pending, w, tau, observations_count)
 
     def _loss_info_pretraining(self, model, eng, li, w, tau, observations_count):
+        self._check_saturation(eng, li)
         loss_info = {"loss_component_observations_rec": w["rec"] * li["rec"], "loss_component_states_rec": w["states"] * li["states"],
                      "loss_component_perceptual_loss": li.get("perceptual_term", 0.0), "avg_perceptual_loss": li.get("perceptual", 0.0),
                      "loss_component_hidden_states_rec": w["hidden"] * li["hidden"], "loss_component_entropy": w["entropy"] * li["entropy"],

@@ -603,6 +603,45 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     return err
 
 
+def hx_saturation_case(lib, dev, N=1, H=10, W=20, Cin=40, Cout=48, seed=0):
+    """f16 range guard of the split-f16 forward (ConvArgs.sat_flag): inputs beyond +-65504 are clamped to the f16 range while they are staged (no inf - inf = NaN in the low
+    half) and the launch sets the flag; in-range inputs leave the flag alone.  Reference: fp64 conv2d of the CLAMPED input."""
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    st = stream(dev)
+    w_d = w.contiguous().to(dev)
+    d = make_pack([w], [(0, Cin)], 3, lib)
+    d.w[0] = w_d.data_ptr()
+    rows_pad = round_up(Cout, lib.caddy_k_hx_pick_bn(Cout))
+    wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), -1, rows_pad, 2), dtype=torch.uint8, device=dev)
+    assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, -1, PREC_F16X3, st) == 0
+    res = []
+    for big_values in (False, True):
+        x = torch.randn(N, Cin, H, W, generator=g)
+        if big_values:
+            x[0, 3, 2, 5], x[0, 7, 9, 19], x[0, 39, 0, 0] = 1.0e5, -2.5e5, 7.0e4
+        flag = torch.zeros(4, dtype=torch.int32, device=dev)
+        bb = nhwc(x, dev=dev)
+        a = ConvArgs()
+        a.src[0] = ConvSrc(bb.data_ptr(), H * W * bb.shape[3], bb.shape[3], Cin, round_up(Cin, CONV_BK), 0)
+        a.nsrc, a.N, a.H, a.W, a.KS = 1, N, H, W, 3
+        a.wp, a.Ktot, a.Cout, a.Cout_pad = None, round_up(Cin, CONV_BK), Cout, round_up(Cout, lib.caddy_k_conv_pick_bn(Cout))
+        a.wq, a.precision, a.sat_flag = wq.data_ptr(), PREC_F16X3, flag.data_ptr()
+        out = torch.zeros(N, H, W, round_up(Cout, 4), device=dev)
+        a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out.shape[3], out.shape[3]
+        assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+        sync(dev)
+        ref = F.conv2d(x.clamp(-65504.0, 65504.0).double(), w.double(), None, padding=1)
+        y = to_nchw(out, Cout).double()
+        assert torch.isfinite(y).all()
+        err = (y - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, ("saturating conv", big_values, err)
+        assert int(flag[0].item()) == (1 if big_values else 0), (big_values, flag.tolist())
+        res.append(err)
+    return res
+
+
 def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big=-1, groups=1, split=False):
     """The BatchNorm fusion of round 3 as one chain at kernel level (reference: conv -> BatchNorm2d(train) -> LeakyReLU(0.2) -> conv, e.g. conv1 / bn1 /
     conv2 of model/layers/residual_block.py:51-61), against torch autograd in fp64:

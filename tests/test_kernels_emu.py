@@ -90,6 +90,10 @@ def test_conv_hx_split_f16_forward_small():
     K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=72, bias=True)
 
 
+def test_conv_hx_f16_range_guard_small():
+    K.hx_saturation_case(load_emu(), "cpu")
+
+
 def test_conv_hx_narrow_output_tiles_small():
     """64- and 32-channel output tiles on 8x16-pixel tiles (under-filled launches) and their dgrad forms"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True)

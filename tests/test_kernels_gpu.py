@@ -125,6 +125,12 @@ def test_batchnorm_fused_into_convolutions(lib, kw):
     K.hx_lazy_bn_case(lib, "cuda", **kw)
 
 
+def test_conv_hx_f16_range_guard(lib):
+    """activations beyond the f16 range (1e5-scale) in a split-f16 forward convolution: clamped while staged, finite output, flag word set"""
+    K.hx_saturation_case(lib, "cuda")
+    K.hx_saturation_case(lib, "cuda", N=2, H=40, W=52, Cin=64, Cout=128, seed=1)
+
+
 def test_conv_hx_fused_maxpool_epilogue(lib):
     """MaxPool2d(2, 2) written by the conv epilogue at VGG19 shapes (conv1_2 / conv3_4 / conv4_4), incl. the write-less ground-truth form and an odd map"""
     K.hx_conv_case(lib, "cuda", N=4, H=256, W=256, segs=[(64, False)], Cout=64, bias=True, act=2, pool=True)

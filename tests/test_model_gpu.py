@@ -3,6 +3,7 @@ properties at the BASELINE geometry."""
 import pytest
 import torch
 
+from tests import helpers as H
 from tests import model_cases as M
 
 pytestmark = pytest.mark.gpu
@@ -210,6 +211,55 @@ def test_device_prefetcher_on_gpu(lib):
 def test_breakout160_smooth_mi_geometry_properties(lib):
     """BASELINE.json configs[4] shard: Breakout hyper-parameters (reduced model) at 160x160, T=9, B=8, smooth MI loss"""
     M.property_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=8, T=9, H=160, W=160, gt=6, tau=0.4))
+    torch.cuda.empty_cache()
+
+
+def test_breakout160_t9_smooth_mi_vs_oracle(lib):
+    """BASELINE.json configs[4] geometry (Breakout hyper-parameters, reduced model, 160x160, T=9, gt=6, smooth MI estimator) at batch 2 against the fp32 CPU oracle: every
+    output of the 20-tuple, exact action indices, frame MSE, the loss terms incl. the smooth-MI estimator path, finite gradients (this geometry had
+    property checks only).  160 / 8 = 20-pixel state maps: ragged 8x16 / 16x16 conv tiles, odd pooled sizes in A."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    M.oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=9, H=160, W=160, gt=6, tau=0.4))
+    torch.cuda.empty_cache()
+
+
+def test_breakout160_t9_gradients_vs_fp64_oracle(lib):
+    """backward at the configs[4] geometry (batch 2, three closed-loop steps): per-module relative L2 distance to the fp64 oracle's gradients"""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    res = M.full_geometry_grad_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=9, H=160, W=160, gt=6, tau=0.4))
+    print(res)
+    torch.cuda.empty_cache()
+
+
+def test_breakout160_perceptual_loss_vs_oracle(lib):
+    """the VGG19 perceptual term at 160x160 (quarter resolution 40x40 -> 20 -> 10 -> 5 -> 2 through the four max-pools: the odd, floor-mode sizes) vs the oracle,
+    training/losses.py:441-491 at configs/02_breakout.yaml's resolution class"""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    M.perceptual_oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=160, W=160, gt=2, tau=0.4), lam=1.0)
+    torch.cuda.empty_cache()
+
+
+def test_f16_range_guard_reports_through_the_losses(lib):
+    """1e6-scale observations drive VGG19's first feature maps beyond the f16 range: the split-f16 forward clamps and reports (losses["f16_saturated"], Engine.f16_saturated),
+    the losses stay finite; in-range observations report nothing; the exact-fp32 forward never reports"""
+    from playablevideogeneration_amd.init import init_parameters, random_vgg19_state
+    c = dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=64, gt=1, tau=0.7)
+    eng = M.make_engine(c, lib, "cuda", perceptual=True)
+    init_parameters(eng, 1)
+    eng.load_vgg(random_vgg19_state(0))
+    g = torch.Generator(device="cuda").manual_seed(2)
+    n = c["T"] - 1
+    noise = {"eps_states": torch.randn(c["B"] * c["T"], 1, device="cuda", generator=g), "eps_dirs": torch.randn(c["B"] * n, 1, device="cuda", generator=g),
+             "gumbel_uniform": torch.rand(c["B"] * n, 3, device="cuda", generator=g),
+             "eps_states_rec": torch.randn(c["B"] * c["T"], 1, device="cuda", generator=g), "eps_dirs_rec": torch.randn(c["B"] * n, 1, device="cuda", generator=g)}
+    w = dict(H.LOSS_W, perceptual=1.0)
+    for scale, vgg_prec, expect in ((1.0, (16, 17), False), (1.0e6, (16, 17), True), (1.0e6, (0, 17), False)):
+        eng.set_vgg_precision(*vgg_prec)
+        obs = (torch.rand(c["B"], c["T"], 3, 64, 64, device="cuda", generator=g) * 2 - 1) * scale
+        eng.forward_full(obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
+        li = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+        assert li["f16_saturated"] == expect and eng.f16_saturated() == expect, (scale, vgg_prec, li["f16_saturated"])
+        assert all(v == v and abs(v) != float("inf") for k, v in li.items() if isinstance(v, float)), li
     torch.cuda.empty_cache()
 
 
