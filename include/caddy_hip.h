@@ -113,12 +113,25 @@ int caddy_set_precision(caddy_ctx* ctx, int forward, int backward);
  * perceptual loss (resize + VGG19 features of the observations: independent of the model) on the driver's side stream, concurrently with
  * the model's forward pass; caddy_loss_backward then only runs the reconstruction branch.  off: everything inside caddy_loss_backward. */
 int caddy_set_perceptual_prefetch(caddy_ctx* ctx, int on);
+/* Evaluation (evaluation/evaluator.py:55,62,193-197: SequenceLossEvaluator(ParallelPerceptualLoss())): after a forward pass, the FULL-RESOLUTION perceptual distance per
+ * reconstructed frame and VGG19 level, out_host[l * N + n] = mean |relu{l+1}_1(rec_n) - relu{l+1}_1(gt_n)|, n = b * Trec + t (Trec = T - 1, or T after forward_pretraining),
+ * l = 0..4; 5 * N doubles, host memory; waits for the stream.  Position t of the reference's "perceptual_loss/pos_t" = sum_l mean_b out[l][b * Trec + t - off]. */
+int caddy_perceptual_per_frame(caddy_ctx* ctx, double* out_host);
+/* ... and the per-frame reconstruction / state losses of the same evaluator (evaluator.py:192,194, ObservationsLoss / StatesLoss per sequence position), from the loss-kernel
+ * family: l1_host[b * Trec + t] = mean |frame - ground-truth observation[:3]| at full resolution, mse_host[b * T + t] = mean (reconstructed state - state)^2; host memory,
+ * either may be NULL; waits for the stream. */
+int caddy_sequence_losses_per_frame(caddy_ctx* ctx, double* l1_host, double* mse_host);
 int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
 /* on (default): caddy_start_inference folds every eval-mode BatchNorm of the roll-out path (E, R's non-recurrent blocks, D) into the packed
  * weights / bias of the convolution in front of it, and caddy_generate_next runs the folded graph (LeakyReLU and the residual add in the conv
  * epilogues, the ConvLSTM cells' BatchNorm as a second output of the gate kernel): ~35 fewer launches per frame.  off: one BatchNorm launch per
  * nn.BatchNorm2d as in the training graph.  Only caddy_generate_next is affected (model.py:570-607, eval mode). */
 int caddy_set_rollout_fold(caddy_ctx* ctx, int on);
+/* Bit-reproducible backward pass (default off).  The forward pass is always bit-reproducible (fixed-order split-K, action indices!); the default backward combines the partial
+ * sums of under-filled dgrads and of the weight-gradient pixel splits with fp32 atomics in arrival order (run-to-run: ~1e-5 relative on the flat gradient, amplified by BPTT
+ * through the closed-loop steps -- the reference's CPU path is bit-repeatable).  on: slabs + fixed-order reduces everywhere; two backward passes over the same forward then
+ * give bit-identical gradients.  Cost: profiles/. */
+int caddy_set_deterministic(caddy_ctx* ctx, int on);
 
 /* --- context --- */
 size_t caddy_workspace_bytes(const caddy_config* cfg);
@@ -135,13 +148,16 @@ typedef void (*caddy_grads_ready_hook)(float* grads, long offset, long count, vo
 int caddy_set_grads_ready_hook(caddy_ctx* ctx, caddy_grads_ready_hook hook, void* user);
 /* Native data parallelism: the same three reductions issued from C into RCCL (ncclAllReduce over xGMI) on a communicator owned by the context -- replaces
  * nn.DataParallel's per-step replicate / gather / reduce-add (train.py:67-68).  One process per GPU:
- *   rank 0: caddy_dp_unique_id(id) -> the 128 bytes travel to every rank (any out-of-band channel, e.g. a torch.distributed broadcast) ->
+ *   rank 0: caddy_dp_unique_id(id) -> the 256 bytes (TWO ncclUniqueIds) travel to every rank (any out-of-band channel, e.g. a torch.distributed broadcast) ->
  *   every rank: caddy_dp_init(ctx, id, world_size, rank, overlap) [overlap = 1: R / D gradient buckets behind the side stream during the backward] ->
  *   per step: caddy_forward_full, caddy_loss_backward, caddy_allreduce_grads (the rest + join), caddy_adam_step(..., grad_scale = 1 / world_size).
+ * One communicator per stream: the first id's communicator carries every collective issued on the context's stream, the second one's (created when overlap = 1) the
+ * gradient buckets on the side stream -- each communicator sees one totally ordered sequence of collectives on every rank.  caddy_dp_init blocks until every rank has
+ * called it, at most CADDY_DP_INIT_TIMEOUT_S seconds (default 180): then it returns -3 with a message instead of hanging.
  * RCCL is resolved with dlopen at the first call (CADDY_RCCL_LIB, librccl.so of the process, /opt/rocm/lib): caddy_dp_available() says whether one was found. */
 int caddy_dp_available(void);
-int caddy_dp_unique_id(char* out128);
-int caddy_dp_init(caddy_ctx* ctx, const char* id128, int world_size, int rank, int overlap);
+int caddy_dp_unique_id(char* out256);
+int caddy_dp_init(caddy_ctx* ctx, const char* id256, int world_size, int rank, int overlap);
 int caddy_allreduce_grads(caddy_ctx* ctx);
 long caddy_dp_bucket_floats(caddy_ctx* ctx);
 int caddy_dp_shutdown(caddy_ctx* ctx);

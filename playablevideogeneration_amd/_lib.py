@@ -28,14 +28,14 @@ class ConvArgs(C.Structure):
                 ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float),
                 ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int), ("xcd_map", C.c_int),
                 ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int),
-                ("stats", C.c_void_p), ("stats_ld", C.c_int), ("sat_flag", C.c_void_p)]
+                ("stats", C.c_void_p), ("stats_ld", C.c_int), ("sat_flag", C.c_void_p), ("deterministic", C.c_int)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
                 ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long), ("precision", C.c_int),
-                ("src_bn_gs", C.c_long * CONV_MAX_SRC)]
+                ("src_bn_gs", C.c_long * CONV_MAX_SRC), ("det_slab", C.c_void_p), ("det_cap", C.c_long), ("det_stride", C.c_long)]
 
 
 class PackDesc(C.Structure):

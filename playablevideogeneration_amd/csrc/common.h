@@ -101,6 +101,9 @@ struct ConvArgs {
     // caller switches that context to the exact-fp32 forward (caddy_set_precision(0, ...)).  Not reachable with BatchNorm-normalised activations; it is the guard
     // for externally supplied networks and inputs (VGG19 with real weights on un-normalised frames).
     unsigned* sat_flag;
+    // Bit-reproducible mode (caddy_set_deterministic): the split-K of an under-filled ACCUMULATING launch (dgrad +=) goes through slabs of split_scratch and the
+    // fixed-order reduce (which then adds the previous contents of `out`) instead of fp32 atomics in arrival order
+    int deterministic;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
@@ -134,7 +137,18 @@ struct WgradArgs {
     long dy_gs;
     int precision;      // PREC_BF16X3: 3x3 layers with >= 32 channels on both sides run on the 16-bit matrix pipe (k_wgrad_hx); 0: exact fp32
     long src_bn_gs[CONV_MAX_SRC];   // time-batched launches: float distance between the (scale, shift) tables of consecutive groups of a lazily normalised source
+    // Bit-reproducible mode (caddy_set_deterministic): every pixel split of the launch flushes its partial weight gradient into its OWN zero-filled copy of the packed
+    // layout -- det_slab + split * det_stride -- and k_wgrad_det_reduce adds the copies to dwp in a fixed order; without it the splits meet in dwp through fp32 atomics
+    // in arrival order.  det_slab: scratch of det_cap floats, private to the launching stream (nullptr: atomics); det_stride is set by the launcher.
+    float* det_slab;
+    long det_cap;
+    long det_stride;
 };
+// destination of a pixel split's flush (see WgradArgs.det_slab): exactly one workgroup adds to an element of a slab
+#define WGRAD_DST(a_, split_) ((a_).det_slab ? (a_).det_slab + (long)(split_) * (a_).det_stride : (a_).dwp)
+// launcher side: clamp the number of pixel splits to the scratch, zero-fill the slabs (returns the splits to use; <= 0: deterministic mode cannot run this launch)
+long wgrad_det_begin(WgradArgs& a, long splits, hipStream_t st);
+int wgrad_det_end(const WgradArgs& a, long splits, hipStream_t st);      // dwp[i] += sum over the splits, in order
 
 // id of the kernel the last conv_*_launch on this host thread dispatched to (profiling; see CONV_KERNEL_NAMES in net.cpp)
 enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_OUT, CK_THIN_IN, CK_WGRAD_128, CK_WGRAD_64, CK_WGRAD_32, CK_WGRAD_SMALL, CK_WGRAD_THIN, CK_WGRAD_TILE, CK_NARROW,
@@ -158,7 +172,7 @@ int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
 extern int g_hx_big_override;
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
-                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0);
+                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
+                if (o < a.Cout) atomicAdd(WGRAD_DST(a, blockIdx.z) + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
             }
         }
     }
@@ -704,6 +704,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     // under-filled launches: split the channel chunks across blockIdx.z.  Accumulating launches (dgrad +=) combine with fp32 atomics; assigning
     // launches use the caller's slab scratch + the fixed-order k_split_reduce (bit-reproducible forward), as k_conv_fwd does.
     a.splitk = 1; a.split_stride = 0;
+    bool det_accum = false;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     const float* real_res = a.res;
     const long P = (long)a.N * a.H * a.W;
@@ -712,11 +713,13 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         if (want > nchunks) want = nchunks;                     // a slice is at least one chunk (= one staged halo tile) x nine taps
         if (want > 16) want = 16;
         if (want >= 2) {
-            if (a.accumulate && a.act == 0 && !a.bias && !a.res) a.splitk = want;
-            else if (!a.accumulate && a.split_scratch) {
+            const bool acc_ok = a.accumulate && a.act == 0 && !a.bias && !a.res;
+            if (acc_ok && !a.deterministic) a.splitk = want;      // fp32 atomics in arrival order
+            else if ((acc_ok || !a.accumulate) && a.split_scratch) {      // slabs + fixed-order reduce (deterministic mode: accumulating launches too; the reduce adds the old contents)
                 const int ldc = round_up(a.Cout, 4);
                 while (want >= 2 && (long)want * P * ldc > a.split_cap) want--;
-                if (want >= 2) { a.splitk = want; a.split_stride = P * ldc; a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr; }
+                if (want >= 2) { a.splitk = want; a.split_stride = P * ldc; a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr;
+                                 det_accum = a.accumulate != 0; a.accumulate = 0; }
             }
         }
     }
@@ -774,7 +777,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
 #undef HX_LAUNCH_DEEP
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
     if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
-                                                 stats_req, stats_req_ld, stats_cap);
+                                                 stats_req, stats_req_ld, stats_cap, det_accum ? 1 : 0);
     return 1;
 }
 
@@ -803,7 +806,10 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     long g = blocks / ((long)kt * ot);
     if (g < 1) g = 1;
     if (g > ntiles) g = ntiles;
-    if (occ == 2) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
-    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 1>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, a, tx, ty);
+    WgradArgs b = a;
+    if (b.det_slab) { g = wgrad_det_begin(b, g, st); if (g <= 0) return -1; }
+    if (occ == 2) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 1>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    if (b.det_slab) wgrad_det_end(b, g, st);
     return 1;
 }

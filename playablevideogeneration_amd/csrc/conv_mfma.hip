@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvArgs a) {
 
 // fixed-order sum of the split-K slabs of a forward conv: out[p][c] = sum_z slab_z[p][c]   (deterministic, unlike atomics)
 __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
-                                                      const float* res, long res_sn, int res_ld) {
+                                                      const float* res, long res_sn, int res_ld, int accumulate) {
     const int C4 = ldc >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < P * C4; i += (long)gridDim.x * 256) {
         long p = i / C4; int c = (int)(i - p * C4) * 4;
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long str
         if (act == 1) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
         else if (act == 3) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
         float* o = out + n * out_sn + (p - n * HW) * (long)out_ld + c;
+        if (accumulate) { v.x += o[0]; if (c + 1 < C) v.y += o[1]; if (c + 2 < C) v.z += o[2]; if (c + 3 < C) v.w += o[3]; }      // deterministic split-K of a dgrad: out += sum of the slabs
         if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
         else { if (c < C) o[0] = v.x; if (c + 1 < C) o[1] = v.y; if (c + 2 < C) o[2] = v.z; }
     }
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs a) {
             for (int r = 0; r < 16; r++) {
                 int o = o0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (o >= a.Cout) continue;
-                float* d = a.dwp + ((long)tap * a.Cout_pad + o) * a.Ktot + k;
+                float* d = WGRAD_DST(a, slab) + ((long)tap * a.Cout_pad + o) * a.Ktot + k;
                 if (a.slabs > 1) atomicAdd(d, acc[i][j][r]);
                 else *d += acc[i][j][r];
             }
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_tile(WgradArgs a, int tiles_
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
+                if (o < a.Cout) atomicAdd(WGRAD_DST(a, blockIdx.z) + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
             }
         }
     }
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_small(WgradArgs a, int tiles
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int o = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (o < a.Cout) atomicAdd(a.dwp + ((long)tap * a.Cout_pad + o) * a.Ktot + k, acc[t][j][r]);
+                if (o < a.Cout) atomicAdd(WGRAD_DST(a, blockIdx.x) + ((long)tap * a.Cout_pad + o) * a.Ktot + k, acc[t][j][r]);
             }
         }
     }
@@ -761,22 +762,25 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     int niter = a.KS * a.KS * (a.Ktot / BK);
     a.splitk = 1;
     long blocks = small ? (long)cdiv(P, 64) * (a.Cout_pad / 64) : blocks128;
+    bool det_accum = false;      // deterministic mode: the split of an accumulating launch goes through the slabs as well (k_split_reduce adds the old contents)
     if (a.accumulate && a.act == 0 && a.bias == nullptr && !a.mask && !a.res && blocks < 384 && niter >= 16 && a.KS == 3) {
         int want = (int)((512 + blocks - 1) / blocks);
-        a.splitk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
+        const int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);      // whole taps per slice
+        if (!a.deterministic) a.splitk = sk;
+        else if (a.split_scratch && sk > 1 && (long)sk * P * round_up(a.Cout, 4) <= a.split_cap) det_accum = true;
     }
     // under-filled forward launches (batch-1 roll-out, R's 16x16 maps): split K over taps into slabs of a scratch buffer and sum them in
     // a fixed order afterwards -- keeps the forward pass bit-reproducible (action indices!) where atomics would not
     a.split_stride = 0;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
     const float* real_res = a.res;
-    if (!a.accumulate && a.split_scratch && !generic_only && a.KS == 3 && niter >= 18 && blocks <= 256) {   // (bias / tanh are applied by the reduce)
+    if ((det_accum || !a.accumulate) && a.split_scratch && !generic_only && a.KS == 3 && (det_accum || (niter >= 18 && blocks <= 256))) {   // (bias / tanh are applied by the reduce)
         int want = (int)((512 + blocks - 1) / blocks);
         int sk = want >= 5 ? 9 : (want >= 2 ? 3 : 1);
         int ldc = round_up(a.Cout, 4);
         if (sk > 1 && (long)sk * P * ldc <= a.split_cap) {
             a.splitk = sk; a.split_stride = P * ldc;
-            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr;
+            a.out = a.split_scratch; a.out_sn = (long)a.H * a.W * ldc; a.out_ld = ldc; a.bias = nullptr; a.act = 0; a.res = nullptr; a.accumulate = 0;
         }
     }
     // (the exact-fp32 kernel: the in-loop split-bf16 planes / 32-channel steps of round 1 are no longer instantiated -- conv_hx.hip is the 16-bit path)
@@ -793,13 +797,14 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_fwd<1, 1, 4, 1, 0, 1>), grid, dim3(256), 0, st, a);
     }
 #undef LAUNCH_CONV
-    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
+    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
+                                                 nullptr, 0, 0, det_accum ? 1 : 0);
     return 0;
 }
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
-                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats, int stats_ld, long stats_cap_tiles) {
+                             const float* res, long res_sn, int res_ld, hipStream_t st, float* stats, int stats_ld, long stats_cap_tiles, int accumulate) {
     const int C4 = ldc >> 2;
-    if (stats && !bias && !act && !res && C4 <= 256 && 256 % C4 == 0) {      // BatchNorm partial sums of the reduced tensor (conv -> BatchNorm chains carry no bias / activation)
+    if (stats && !accumulate && !bias && !act && !res && C4 <= 256 && 256 % C4 == 0) {      // BatchNorm partial sums of the reduced tensor (conv -> BatchNorm chains carry no bias / activation)
         const int rows = 256 / C4;
         long ppb = rows * 4;                                                  // >= 4 pixels per thread ...
         while (cdiv(P, ppb) > 512) ppb *= 2;                                  // ... and at most 512 workgroups
@@ -812,7 +817,34 @@ int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc,
     }
     long items = P * (ldc >> 2);
     hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, C, out, out_sn, out_ld, bias, act,
-                       res, res_sn, res_ld);
+                       res, res_sn, res_ld, accumulate);
+    return 0;
+}
+
+// ---- bit-reproducible weight gradients (WgradArgs.det_slab) ----
+namespace {
+__global__ __launch_bounds__(256) void k_wgrad_det_reduce(float* dwp, const float* slab, int splits, long stride) {
+    for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < stride; i += (long)gridDim.x * 1024) {
+        float4 v = *reinterpret_cast<const float4*>(slab + i);
+        for (int s = 1; s < splits; s++) { const float4 w = *reinterpret_cast<const float4*>(slab + s * stride + i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        float4 o = *reinterpret_cast<float4*>(dwp + i);
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *reinterpret_cast<float4*>(dwp + i) = o;
+    }
+}
+}  // namespace
+long wgrad_det_begin(WgradArgs& a, long splits, hipStream_t st) {
+    a.det_stride = ((long)a.KS * a.KS * a.Cout_pad * a.Ktot + 3) / 4 * 4;
+    if (a.det_stride <= 0 || a.det_stride > a.det_cap) return 0;
+    const long fit = a.det_cap / a.det_stride;
+    if (splits > fit) splits = fit;
+    if (splits < 1) splits = 1;
+    hipMemsetAsync(a.det_slab, 0, sizeof(float) * (size_t)splits * a.det_stride, st);
+    return splits;
+}
+int wgrad_det_end(const WgradArgs& a, long splits, hipStream_t st) {
+    const long blocks = cdiv(a.det_stride, 1024);
+    hipLaunchKernelGGL(k_wgrad_det_reduce, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, a.dwp, (const float*)a.det_slab, (int)splits, a.det_stride);
     return 0;
 }
 
@@ -850,8 +882,10 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
         int grid = (int)(ntiles < 512 ? ntiles : 512);
         g_last_conv_kernel = CK_WGRAD_SMALL;
         if (dry) return 0;
+        if (a.det_slab) { grid = (int)wgrad_det_begin(a, grid, st); if (grid <= 0) return -1; }
         if (a.Ktot <= 32) hipLaunchKernelGGL((k_conv_wgrad_small<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_small<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+        if (a.det_slab) wgrad_det_end(a, grid, st);
         g_last_conv_kernel = CK_WGRAD_SMALL;
         return 0;
     }
@@ -865,11 +899,13 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
         long g = tile_blocks / ((long)kt * ot);
         if (g < 1) g = 1;
         if (g > ntiles) g = ntiles;
-        dim3 grid(kt, ot, (unsigned)g);
         g_last_conv_kernel = CK_WGRAD_TILE;
         if (dry) return 0;
+        if (a.det_slab) { g = wgrad_det_begin(a, g, st); if (g <= 0) return -1; }
+        dim3 grid(kt, ot, (unsigned)g);
         if (o32) hipLaunchKernelGGL((k_conv_wgrad_tile<1>), grid, dim3(256), 0, st, a, tx, ty);
         else hipLaunchKernelGGL((k_conv_wgrad_tile<2>), grid, dim3(256), 0, st, a, tx, ty);
+        if (a.det_slab) wgrad_det_end(a, g, st);
         g_last_conv_kernel = CK_WGRAD_TILE;
         return 0;
     }
@@ -886,9 +922,13 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     }
     g_last_conv_kernel = bmo == 128 ? CK_WGRAD_128 : (bmo == 64 ? CK_WGRAD_64 : CK_WGRAD_32);
     if (dry) return 0;
+    if (a.det_slab && a.slabs > 1) { a.slabs = (int)wgrad_det_begin(a, a.slabs, st); if (a.slabs <= 0) return -1; }
+    const bool det_slabs = a.det_slab && a.slabs > 1;
+    if (!det_slabs) a.det_slab = nullptr;      // one slab: the workgroup adds to dwp directly (plain read-modify-write, no atomics)
     dim3 grid(ktiles, otiles, taps * a.slabs);
     if (bmo == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
     else if (bmo == 64) hipLaunchKernelGGL((k_conv_wgrad<1, 2, 2, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_wgrad<1, 1, 1, 4>), grid, dim3(256), 0, st, a);
+    if (det_slabs) wgrad_det_end(a, a.slabs, st);
     return 0;
 }

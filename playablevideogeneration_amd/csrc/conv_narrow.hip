@@ -246,19 +246,26 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int tiles_x, 
     float* red = xs;
     for (int i = tid; i < NW; i += 256) red[i] = 0.f;
     __syncthreads();
+    // (the waves take turns, in order: one wave's lanes hit distinct elements, so plain read-modify-write -- and a fixed summation order, where ds_add_f32 from four
+    //  waves at once summed in arrival order)
+    for (int wv = 0; wv < 4; wv++) {
+        if (wave == wv) {
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+            for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int m = 0; m < CO16; m++)
+                for (int m = 0; m < CO16; m++)
 #pragma unroll
-            for (int n = 0; n < CI16; n++)
+                    for (int n = 0; n < CI16; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) atomicAdd(&red[((t * CO16 * 16) + m * 16 + 4 * g + r) * (CI16 * 16) + n * 16 + lp], acc[t][m][n][r]);
-    __syncthreads();
+                        for (int r = 0; r < 4; r++) red[((t * CO16 * 16) + m * 16 + 4 * g + r) * (CI16 * 16) + n * 16 + lp] += acc[t][m][n][r];
+        }
+        __syncthreads();
+    }
+    float* const dst = WGRAD_DST(a, blockIdx.x);
     for (int i = tid; i < NW; i += 256) {
         int k = i % (CI16 * 16), to = i / (CI16 * 16);
         int o = to % (CO16 * 16), t = to / (CO16 * 16);
-        if (k < a.Ktot && o < a.Cout) atomicAdd(a.dwp + ((long)t * a.Cout_pad + o) * a.Ktot + k, red[i]);
+        if (k < a.Ktot && o < a.Cout) atomicAdd(dst + ((long)t * a.Cout_pad + o) * a.Ktot + k, red[i]);
     }
 }
 }  // namespace
@@ -276,9 +283,13 @@ int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     const int grid = (int)(want < 64 ? (ntiles < 64 ? ntiles : 64) : (want < 512 ? want : 512));
     g_last_conv_kernel = CK_WGRAD_SMALL;
     if (dry) return 1;
-    if (ci == 1 && co == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
-    else if (ci == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
-    else hipLaunchKernelGGL((k_wgrad_narrow<2, 1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    WgradArgs b = a;
+    int gridn = grid;
+    if (b.det_slab) { gridn = (int)wgrad_det_begin(b, grid, st); if (gridn <= 0) return -1; }
+    if (ci == 1 && co == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 1>), dim3(gridn), dim3(256), 0, st, b, tx, ty);
+    else if (ci == 1) hipLaunchKernelGGL((k_wgrad_narrow<1, 2>), dim3(gridn), dim3(256), 0, st, b, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_narrow<2, 1>), dim3(gridn), dim3(256), 0, st, b, tx, ty);
+    if (b.det_slab) wgrad_det_end(b, gridn, st);
     g_last_conv_kernel = CK_WGRAD_SMALL;
     return 1;
 }
@@ -426,7 +437,8 @@ int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st) {
 namespace {
 template <int KS>
 __global__ __launch_bounds__(256) void k_wgrad_c4(const float* thin, long thin_sn, int TC, const float* wide, long wide_sn, int wide_ld, int WC,
-                                                   int N, int H, int W, int swap, int Cout_pad, int Ktot, float* dwp, int tiles_x, int tiles_y) {
+                                                   int N, int H, int W, int swap, int Cout_pad, int Ktot, float* dwp_all, int tiles_x, int tiles_y, float* det_slab, long det_stride) {
+    float* const dwp = det_slab ? det_slab + (long)blockIdx.x * det_stride : dwp_all;      // deterministic mode: this pixel split's own copy (WgradArgs.det_slab)
     constexpr int R = KS / 2, HW_ = NTW + 2 * R, HH_ = NTH + 2 * R, DXG = (KS + 3) / 4, TAPS = KS * KS;
     constexpr int NLT = (HH_ * HW_ + 255) / 256, NLW = NTH * NTW * 4 / 256;
     constexpr int NG = KS * DXG * 16 * 16;                     // floats of the per-workgroup partial G (dy, dx group, column, row)
@@ -496,13 +508,17 @@ __global__ __launch_bounds__(256) void k_wgrad_c4(const float* thin, long thin_s
     float* red = wd;
     for (int i = tid; i < NG; i += 256) red[i] = 0.f;
     __syncthreads();
+    for (int wv = 0; wv < 4; wv++) {      // waves in turn: fixed summation order (see k_wgrad_narrow)
+        if (wave == wv) {
 #pragma unroll
-    for (int i = 0; i < KS; i++)
+            for (int i = 0; i < KS; i++)
 #pragma unroll
-        for (int j = 0; j < DXG; j++)
+                for (int j = 0; j < DXG; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&red[((i * DXG + j) * 16 + lp) * 16 + 4 * g + r], acc[i][j][r]);
-    __syncthreads();
+                    for (int r = 0; r < 4; r++) red[((i * DXG + j) * 16 + lp) * 16 + 4 * g + r] += acc[i][j][r];
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < NG; e += 256) {
         int wr = e & 15, col = (e >> 4) & 15, ij = e >> 8;
         int j = ij % DXG, i = ij / DXG;
@@ -529,11 +545,14 @@ int conv_c4_wgrad_try(const WgradArgs& w, hipStream_t st, bool dry) {
     const long ntiles = (long)w.N * tx * ty;
     long want = ntiles / 4, cap = 512 / chunks > 32 ? 512 / chunks : 32;
     long gx = want < 32 ? (ntiles < 32 ? ntiles : 32) : (want < cap ? want : cap);
-    dim3 grid((unsigned)gx, chunks);
     g_last_conv_kernel = CK_WGRAD_THIN;
     if (dry) return 1;
-    if (w.KS == 7) hipLaunchKernelGGL((k_wgrad_c4<7>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
-    else hipLaunchKernelGGL((k_wgrad_c4<3>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty);
+    WgradArgs b = w;
+    if (b.det_slab) { gx = wgrad_det_begin(b, gx, st); if (gx <= 0) return -1; }
+    dim3 grid((unsigned)gx, chunks);
+    if (w.KS == 7) hipLaunchKernelGGL((k_wgrad_c4<7>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty, b.det_slab, b.det_stride);
+    else hipLaunchKernelGGL((k_wgrad_c4<3>), grid, dim3(256), 0, st, thin, thin_sn, TC, wide, wide_sn, wide_ld, WC, w.N, w.H, w.W, swap, w.Cout_pad, w.Ktot, w.dwp, tx, ty, b.det_slab, b.det_stride);
+    if (b.det_slab) wgrad_det_end(b, gx, st);
     g_last_conv_kernel = CK_WGRAD_THIN;
     return 1;
 }

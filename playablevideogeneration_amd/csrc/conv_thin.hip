@@ -179,6 +179,7 @@ struct ThinWgradArgs {
     int N, H, W, KS, swap, Cout_pad, Ktot;
     float* dwp;
     int tiles_x, tiles_y, chunks;
+    float* det_slab; long det_stride;      // deterministic mode: every pixel split (blockIdx.x) flushes into its own copy (WgradArgs.det_slab)
 };
 template <int TCP>
 __global__ __launch_bounds__(256) void k_wgrad_thin(ThinWgradArgs a) {
@@ -228,19 +229,22 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(ThinWgradArgs a) {
     float* red = wl;                                  // reuse the halo tile storage: IT * TCP * 4 floats
     for (int i = tid; i < IT * TCP * 4; i += 256) red[i] = 0.f;
     __syncthreads();
-    if (active) {
+    for (int s = 0; s < PSn; s++) {      // the pixel splits take turns, in order: fixed summation order (ds_add_f32 from all of them at once summed in arrival order)
+        if (active && ps == s) {
 #pragma unroll
-        for (int t = 0; t < TCP; t++)
+            for (int t = 0; t < TCP; t++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) atomicAdd(&red[(item * TCP + t) * 4 + e], acc[t][e]);
+                for (int e = 0; e < 4; e++) red[(item * TCP + t) * 4 + e] += acc[t][e];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    float* const dwp = a.det_slab ? a.det_slab + (long)blockIdx.x * a.det_stride : a.dwp;
     for (int i = tid; i < IT * TCP * 4; i += 256) {
         int e = i & 3, t = (i >> 2) % TCP, it = (i >> 2) / TCP;
         int tp = it >> 2, w = chunk * CK + (it & 3) * 4 + e;
         if (t >= a.TC || w >= a.WC) continue;
-        float* d = a.swap ? a.dwp + ((long)(taps - 1 - tp) * a.Cout_pad + w) * a.Ktot + t
-                          : a.dwp + ((long)tp * a.Cout_pad + t) * a.Ktot + w;
+        float* d = a.swap ? dwp + ((long)(taps - 1 - tp) * a.Cout_pad + w) * a.Ktot + t
+                          : dwp + ((long)tp * a.Cout_pad + t) * a.Ktot + w;
         atomicAdd(d, red[i]);
     }
 }
@@ -302,11 +306,14 @@ int conv_thin_wgrad_try(const WgradArgs& w, hipStream_t st, bool dry) {
     a.chunks = cdiv(a.WC, CK);
     long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
     long gx = 512 / a.chunks; if (gx < 32) gx = 32; if (gx > ntiles) gx = ntiles;
-    dim3 grid((unsigned)gx, a.chunks);
     g_last_conv_kernel = CK_WGRAD_THIN;
     if (dry) return 1;
+    WgradArgs b = w;
+    if (b.det_slab) { gx = wgrad_det_begin(b, gx, st); if (gx <= 0) return -1; a.det_slab = b.det_slab; a.det_stride = b.det_stride; }
+    dim3 grid((unsigned)gx, a.chunks);
     if (a.TC <= 4) hipLaunchKernelGGL((k_wgrad_thin<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_thin<12>), grid, dim3(256), 0, st, a);
+    if (b.det_slab) wgrad_det_end(b, gx, st);
     g_last_conv_kernel = CK_WGRAD_THIN;
     return 1;
 }

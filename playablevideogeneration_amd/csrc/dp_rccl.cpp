@@ -8,9 +8,20 @@
 // RCCL is resolved at run time (dlopen of the librccl the process already carries -- PyTorch-ROCm ships one -- or the ROCm one): the library has no link-time dependency
 // on it, loads without it (CPU build check, host simulator) and reports an error when a communicator is requested and no RCCL can be found.  The Python-side
 // `torch.distributed` hooks (engine.enable_data_parallel) remain for gloo (CPU tests) and as a fallback.
+//
+// Stream discipline: ONE COMMUNICATOR PER STREAM.  `comm` carries everything issued on the context's stream (the small reductions inside the forward / loss kernels and
+// the rest of the gradients), `comm2` the gradient buckets issued on the side stream during the backward.  A single communicator used from two streams is only correct
+// if RCCL serialises the two streams' operations identically on every rank; with one communicator per stream each communicator sees one totally ordered sequence of
+// collectives, and the host issues the calls of both in program order -- the same on every rank.  ncclCommInitRank blocks until every rank has called it: it runs in a
+// helper thread with a time limit (CADDY_DP_INIT_TIMEOUT_S, default 180) so that a rank that never arrives becomes an error message, not a silent hang.
 #include "net.h"
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace {
 struct UniqueId { char b[128]; };      // rccl.h: ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed to ncclCommInitRank BY VALUE
@@ -51,41 +62,82 @@ void small_allreduce(float* ptr, int count, void* user) {
     int rc = g_rccl.AllReduce(ptr, ptr, (size_t)count, kNcclFloat32, kNcclSum, c->comm, c->stream);
     if (rc != 0) { c->fail = true; nccl_fail("ncclAllReduce (small)", rc); }
 }
-// gradient buckets that become final during the backward (caddy_grads_ready_hook signature, user = ctx)
+// gradient buckets that become final during the backward (caddy_grads_ready_hook signature, user = ctx): the side stream's own communicator
 void bucket_allreduce(float* grads, long offset, long count, void* stream, void* user) {
     caddy_ctx* c = (caddy_ctx*)user;
-    if (!c->comm) return;
-    int rc = g_rccl.AllReduce(grads + offset, grads + offset, (size_t)count, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream);
+    if (!c->comm2) return;
+    int rc = g_rccl.AllReduce(grads + offset, grads + offset, (size_t)count, kNcclFloat32, kNcclSum, c->comm2, (hipStream_t)stream);
     if (rc != 0) { c->fail = true; nccl_fail("ncclAllReduce (bucket)", rc); return; }
     c->comm_buckets.push_back({offset, count});
     c->comm_bucket_stream = (hipStream_t)stream;
+}
+// ncclCommInitRank with a time limit: the call blocks until EVERY rank has made it.  It runs in a helper thread; when the limit passes the caller gets an error (the helper
+// stays blocked and is detached: the process is expected to exit -- there is no way to cancel a rendezvous that another rank never joins).
+struct InitJob { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; void* comm = nullptr; };
+int comm_init_guarded(void** out, int world_size, const UniqueId& id, int rank, const char* which) {
+    int device = 0;
+    hipGetDevice(&device);
+    auto job = std::make_shared<InitJob>();
+    const init_fn fn = g_rccl.CommInitRank;
+    std::thread([job, fn, world_size, id, rank, device]() {
+        hipSetDevice(device);      // (the helper thread must target the caller's GPU)
+        void* comm = nullptr;
+        const int rc = fn(&comm, world_size, id, rank);
+        std::lock_guard<std::mutex> g(job->m);
+        job->rc = rc; job->comm = comm; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    const char* e = getenv("CADDY_DP_INIT_TIMEOUT_S");
+    const long limit = e && atol(e) > 0 ? atol(e) : 180;
+    std::unique_lock<std::mutex> lk(job->m);
+    if (!job->cv.wait_for(lk, std::chrono::seconds(limit), [&] { return job->done; })) {
+        set_error(std::string("ncclCommInitRank (") + which + ") did not return within " + std::to_string(limit) + " s on rank " + std::to_string(rank) + " of " +
+                  std::to_string(world_size) + ": another rank never reached caddy_dp_init (CADDY_DP_INIT_TIMEOUT_S)");
+        return -3;
+    }
+    if (job->rc != 0) return nccl_fail("ncclCommInitRank", job->rc);
+    *out = job->comm;
+    return 0;
 }
 }  // namespace
 
 extern "C" {
 int caddy_dp_available(void) { return load_rccl() ? 1 : 0; }
-int caddy_dp_unique_id(char* out128) {
+// TWO unique ids (2 x 128 bytes): one communicator per stream (see the header comment of this file)
+int caddy_dp_unique_id(char* out256) {
     if (!load_rccl()) { set_error("no RCCL library found (librccl.so)"); return -1; }
-    char id[128]; memset(id, 0, sizeof(id));
-    int rc = g_rccl.GetUniqueId(id);
-    if (rc != 0) return nccl_fail("ncclGetUniqueId", rc);
-    memcpy(out128, id, 128);
+    for (int i = 0; i < 2; i++) {
+        char id[128]; memset(id, 0, sizeof(id));
+        int rc = g_rccl.GetUniqueId(id);
+        if (rc != 0) return nccl_fail("ncclGetUniqueId", rc);
+        memcpy(out256 + 128 * i, id, 128);
+    }
     return 0;
 }
-int caddy_dp_init(caddy_ctx* c, const char* id128, int world_size, int rank, int overlap) {
+int caddy_dp_init(caddy_ctx* c, const char* id256, int world_size, int rank, int overlap) {
     if (!load_rccl()) { set_error("no RCCL library found (librccl.so)"); return -1; }
     if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    UniqueId id; memcpy(id.b, id128, 128);
+    if (c->comm2) { g_rccl.CommDestroy(c->comm2); c->comm2 = nullptr; }
+    UniqueId id; memcpy(id.b, id256, 128);
     void* comm = nullptr;
-    int rc = g_rccl.CommInitRank(&comm, world_size, id, rank);
-    if (rc != 0) return nccl_fail("ncclCommInitRank", rc);
+    int rc = comm_init_guarded(&comm, world_size, id, rank, "stream communicator");
+    if (rc != 0) return rc;
     c->comm = comm; c->comm_world = world_size;
+    if (overlap) {      // the gradient buckets' own communicator (side stream)
+        memcpy(id.b, id256 + 128, 128);
+        void* comm2 = nullptr;
+        rc = comm_init_guarded(&comm2, world_size, id, rank, "bucket communicator");
+        if (rc != 0) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; return rc; }
+        c->comm2 = comm2;
+    }
     c->hook = small_allreduce; c->hook_user = c; c->world = world_size > 1 ? world_size : 1;
     if (overlap) { c->grads_hook = bucket_allreduce; c->grads_user = c; } else { c->grads_hook = nullptr; c->grads_user = nullptr; }
     return 0;
 }
 int caddy_dp_shutdown(caddy_ctx* c) {
-    if (c->comm) { hipStreamSynchronize(c->stream); if (c->side) hipStreamSynchronize(c->side); g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm || c->comm2) { hipStreamSynchronize(c->stream); if (c->side) hipStreamSynchronize(c->side); }
+    if (c->comm2) { g_rccl.CommDestroy(c->comm2); c->comm2 = nullptr; }
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     c->hook = nullptr; c->grads_hook = nullptr; c->world = 1;
     return 0;
 }

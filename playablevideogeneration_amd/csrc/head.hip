@@ -164,9 +164,9 @@ __global__ void k_head_bwd1(HeadBufs h, HeadParams p, SampleCfg c, int NS, int f
             for (int k = 0; k < K; k++) dl[k] += y[k] * (da[k] - dot);
         }
     }
-    for (int k = 0; k < K; k++) {
-        atomicAdd(&p.dbf[k], dl[k]);
-        for (int d = 0; d < Da; d++) { atomicAdd(&p.dWf[k * Da + d], dl[k] * h.dirs[n * Da + d]); dd[d] += p.Wf[k * Da + d] * dl[k]; }
+    for (int k = 0; k < K; k++) {      // (the final_fc parameter gradients are summed over the samples in a fixed order by k_head_bwd3, from the d(logits) left here)
+        h.d_logits[n * K + k] = dl[k];
+        for (int d = 0; d < Da; d++) dd[d] += p.Wf[k * Da + d] * dl[k];
     }
     for (int d = 0; d < Da; d++) {
         float dvar = h.ddist[(long)n * 2 * Da + Da + d];
@@ -188,7 +188,6 @@ __global__ void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
         float raw = h.raw[n * Da + d];
         gm[d] = gmu;
         gr[d] = gvar * (raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f));
-        atomicAdd(&p.dbm[d], gm[d]); atomicAdd(&p.dbv[d], gr[d]);
     }
     float* df = h.d_feat + (long)n * p.F;
     for (int d = 0; d < Da; d++) { h.g_mu[n * Da + d] = gm[d]; h.g_raw[n * Da + d] = gr[d]; }
@@ -198,14 +197,26 @@ __global__ void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
         df[k] = acc;
     }
 }
-// FC weight gradients: one thread per (d, k) loops over the samples (no atomics)
-__global__ void k_head_bwd3(HeadBufs h, HeadParams p, int NBT) {
+// FC parameter gradients: one thread per output loops over the samples in order (no atomics: bit-reproducible)
+__global__ void k_head_bwd3(HeadBufs h, HeadParams p, int NBT, int NS) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.Da * p.F) return;
     int d = i / p.F, k = i - d * p.F;
     float am = 0.f, av = 0.f;
     for (int n = 0; n < NBT; n++) { float f = h.feat[(long)n * p.F + k]; am += h.g_mu[n * p.Da + d] * f; av += h.g_raw[n * p.Da + d] * f; }
     p.dWm[i] += am; p.dWv[i] += av;
+    if (i < p.Da) {                        // mean_fc / variance_fc biases
+        float bm = 0.f, bv = 0.f;
+        for (int n = 0; n < NBT; n++) { bm += h.g_mu[n * p.Da + i]; bv += h.g_raw[n * p.Da + i]; }
+        p.dbm[i] += bm; p.dbv[i] += bv;
+    }
+    if (i < p.K * p.Da) {                  // final_fc weight (K, Da) and bias from the d(logits) k_head_bwd1 finalised (K * Da <= 128 <= Da * F)
+        const int kk = i / p.Da, dd = i - kk * p.Da;
+        float w = 0.f, b = 0.f;
+        for (int n = 0; n < NS; n++) { const float g = h.d_logits[n * p.K + kk]; w += g * h.dirs[n * p.Da + dd]; b += g; }
+        p.dWf[i] += w;
+        if (dd == 0) p.dbf[kk] += b;
+    }
 }
 
 // ---- losses ------------------------------------------------------------------------------------------------------------
@@ -386,6 +397,24 @@ __global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1
     }
 }
 __global__ void k_report_flag(const unsigned* flag, double* slot) { *slot = *flag != 0 ? 1.0 : 0.0; }
+// Evaluation, per frame (evaluation/evaluator.py:192,194: SequenceLossEvaluator over ObservationsLoss / StatesLoss): acc[n] += sum over image n of |a - b| (sq = 0) or
+// (a - b)^2 (sq = 1) over the first C channels; image n of `a` is frame (n / Tb) * Ta + n % Tb + a_off of the (B, Ta) sequence, image n of `b` is n.  blockIdx.y = n.
+__global__ __launch_bounds__(256) void k_diff_per_frame(TV a, int Ta, int a_off, TV b, int Tb, int C, int sq, double* acc) {
+    __shared__ double sh[4];
+    const int n = blockIdx.y, HW = b.H * b.W;
+    const float* ap = a.p + ((long)(n / Tb) * Ta + n % Tb + a_off) * a.sn;
+    const float* bp = b.p + (long)n * b.sn;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)HW * C; i += (long)gridDim.x * 256) {
+        const long pix = i / C; const int c = (int)(i - pix * C);
+        const float d = ap[pix * a.ld + c] - bp[pix * b.ld + c];
+        s += sq ? (double)d * d : (double)fabsf(d);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc + n, sh[0] + sh[1] + sh[2] + sh[3]);
+}
 __global__ void k_softmax_rows(const float* logits, float* prob, float* logp, int NS, int K) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= NS) return;
@@ -462,7 +491,7 @@ int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int 
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {
     hipLaunchKernelGGL(k_head_bwd1, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, c, B * (T - 1), first_call);
     hipLaunchKernelGGL(k_head_bwd2, dim3(cdiv((long)B * T, 64)), dim3(64), 0, st, h, p, B, T);
-    hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 64)), dim3(64), 0, st, h, p, B * T);
+    hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 64)), dim3(64), 0, st, h, p, B * T, B * (T - 1));
     return 0;
 }
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out, hipStream_t st) {
@@ -560,5 +589,11 @@ int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, doubl
 }
 int loss_report_flag(const unsigned* flag, double* slot, hipStream_t st) {
     hipLaunchKernelGGL(k_report_flag, dim3(1), dim3(1), 0, st, flag, slot);
+    return 0;
+}
+int loss_diff_per_frame(const TV& a, int Ta, int a_off, const TV& b, int Tb, int C, int sq, double* acc, hipStream_t st) {
+    const long items = (long)b.H * b.W * C;
+    const unsigned bx = (unsigned)(items / 2048 < 1 ? 1 : (items / 2048 > 64 ? 64 : items / 2048));
+    hipLaunchKernelGGL(k_diff_per_frame, dim3(bx, b.N), dim3(256), 0, st, a, Ta, a_off, b, Tb, C, sq, acc);
     return 0;
 }

@@ -250,6 +250,8 @@ void build_layers(caddy_ctx* c) {
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
     c->sat_flag = (unsigned*)c->persist.alloc(256);
+    c->wgrad_det_cap = 16L << 20;      // 64 MB: >= 3 copies of the largest packed weight gradient (ConvLSTM 1 gates, 9 x 1024 x 528), 256 of a 64 x 64 layer
+    c->wgrad_det = (float*)c->persist.alloc(sizeof(float) * c->wgrad_det_cap);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_aux2 = (float*)c->persist.alloc(CONV_AUX_BYTES);
     c->conv_split_cap = 9L * 4096 * 256;                      // 9 slabs x (<= 4096 pixels x 256 channels): only under-filled launches use it
@@ -483,7 +485,9 @@ void caddy_ctx::launch_wgrad_jobs() {
     for (auto& j : wgrad_jobs) RUN(launch_conv_wgrad(j.first, j.second, s2));
     wgrad_jobs.clear();
 }
-int caddy_ctx::launch_conv_wgrad(const WgradArgs& a, double flops, hipStream_t stream) {
+int caddy_ctx::launch_conv_wgrad(const WgradArgs& a0, double flops, hipStream_t stream) {
+    WgradArgs a = a0;
+    if (deterministic) { a.det_slab = wgrad_det; a.det_cap = wgrad_det_cap; }
     if (!prof) return conv_wgrad_launch(a, stream);
     int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
     const double px = (double)a.N * a.H * a.W;
@@ -554,7 +558,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                         RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmpv[s].d, sgv[s].t.g, sgv[s].t.sn, bd ? nullptr : Lp->dbias, stream));
                         bd = true;
                     }
-                    if (!bd) RUN(pw_colsum(dzv, Lp->dbias, stream));
+                    if (!bd) RUN(pw_colsum(dzv, Lp->dbias, stream, deterministic));
                 });
             }
             for (int s = 0; s < nseg; s++) {
@@ -563,7 +567,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 ConvArgs d{};
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
-                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux;
+                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux; d.deterministic = deterministic ? 1 : 0;
                 if (Lp->wqd[s] && prec_bwd != PREC_FP32) { d.wq = Lp->wqd[s]; d.precision = PREC_BF16X3; }
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
                 const int kind_save = prof_kind_override;
@@ -580,6 +584,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                         Lp->off_pending = true;      // (the consumer flushes the queued jobs before it waits for the event)
                         defer_aux([=]() mutable {      // (runs with stream / scratch of the auxiliary stream)
                             d.aux = conv_aux;
+                            if (deterministic) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
                             const int keepk = prof_kind_override; prof_kind_override = pk;
                             RUN(timed_conv_fwd(d, dfl));
                             prof_kind_override = keepk;
@@ -587,14 +592,14 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                             hipEventRecord(Lp->off_ev, stream);
                         });
                     } else {
-                        if (assign) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
+                        if (assign || deterministic) { d.split_scratch = conv_split; d.split_cap = conv_split_cap; }
                         RUN(timed_conv_fwd(d, dfl));
                     }
                 }
                 else {
                     d.out = tmp[s].d; d.out_sn = tmp[s].sn; d.out_ld = tmp[s].ld; d.accumulate = 0;
                     RUN(timed_conv_fwd(d, dfl));
-                    RUN(pw_spatial_sum(dv(tmp[s]), sg[s].t.g, sg[s].t.sn, stream));
+                    RUN(pw_spatial_sum(dv(tmp[s]), sg[s].t.g, sg[s].t.sn, stream, deterministic));
                 }
             }
         });
@@ -1462,7 +1467,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
 }
 extern "C" int caddy_dp_shutdown(caddy_ctx* c);
 void caddy_ctx_destroy(caddy_ctx* c) {
-    if (c && c->comm) caddy_dp_shutdown(c);
+    if (c && (c->comm || c->comm2)) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c && c->gstream) { if (c->graph_exec) hipStreamSynchronize(c->stream); hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
     if (c) for (ConvL* L : c->convs) if (L->off_ev) hipEventDestroy(L->off_ev);
@@ -1516,11 +1521,38 @@ int caddy_load_vgg(caddy_ctx* c, const float* vgg_flat) {
     return vgg_load(c, vgg_flat);
 }
 int caddy_set_perceptual_prefetch(caddy_ctx* c, int on) { c->perc_prefetch = on != 0; return 0; }
+// evaluation: per-position reconstruction / state losses of the last forward (evaluation/evaluator.py:192,194).  l1_host: B * Trec means of |frame - ground truth| (full
+// resolution, first 3 channels of the observation); mse_host: B * T means of (reconstructed state - state)^2.  Either may be NULL.
+int caddy_sequence_losses_per_frame(caddy_ctx* c, double* l1_host, double* mse_host) {
+    c->fail = false;
+    if (!c->have_forward) { set_error("caddy_sequence_losses_per_frame: no forward results available"); return -2; }
+    const caddy_config& g = c->cfg;
+    const int B = g.batch, T = g.seq_len, Trec = c->pretraining ? T : T - 1, t_off = c->pretraining ? 0 : 1;
+    hipStream_t st = c->stream;
+    c->act.off = c->fwd_off;
+    double* acc = c->dalloc((size_t)B * (Trec + T));
+    if (c->act.overflow()) { c->act.off = c->fwd_off; set_error("caddy_sequence_losses_per_frame: workspace too small"); return -1; }
+    hipMemsetAsync(acc, 0, sizeof(double) * (size_t)B * (Trec + T), st);
+    const T4& f = c->frames[0];
+    c->ck(loss_diff_per_frame(dv(c->obs), T, t_off, dv(f), Trec, 3, 0, acc, st), "per-frame L1");
+    T4 sa = c->x65_gt, sb = c->rec_x65;
+    c->ck(loss_diff_per_frame(dv(sa), T, 0, dv(sb), T, 64, 1, acc + (size_t)B * Trec, st), "per-frame state MSE");
+    std::vector<double> host((size_t)B * (Trec + T));
+    hipMemcpyAsync(host.data(), acc, sizeof(double) * host.size(), hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    c->act.off = c->fwd_off;
+    const double nf = 3.0 * f.H * f.W, ns = 64.0 * sa.H * sa.W;
+    if (l1_host) for (int i = 0; i < B * Trec; i++) l1_host[i] = host[i] / nf;
+    if (mse_host) for (int i = 0; i < B * T; i++) mse_host[i] = host[(size_t)B * Trec + i] / ns;
+    return finish(c);
+}
+int caddy_perceptual_per_frame(caddy_ctx* c, double* out_host) { c->fail = false; if (!out_host) { set_error("null output"); return -2; } return vgg_eval_per_frame(c, out_host); }
 int caddy_set_rollout_fold(caddy_ctx* c, int on) {
     if (c->graph_exec && !c->dry) { hipStreamSynchronize(c->stream); if (c->gstream) hipStreamSynchronize(c->gstream); }      // a launch of the graph may still be executing: never destroy its exec object under it
     c->use_fold = on != 0; c->drop_graph(); c->packed_fold = false; return 0;
 }
 int caddy_set_vgg_precision(caddy_ctx* c, int forward, int dgrad) { c->vgg_precision = forward; c->vgg_precision_bwd = dgrad; return 0; }
+int caddy_set_deterministic(caddy_ctx* c, int on) { c->deterministic = on != 0; return 0; }
 int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }
     c->prec_fwd = forward; c->prec_bwd = backward; return 0;

@@ -144,8 +144,13 @@ struct caddy_ctx {
     long s2h_lo = 0, s2h_hi = 0;     // state_to_hidden_state_layer: unused by forward_full_model -> its .grad is None there and torch's Adam skips it (no weight decay either)
     void early_gradient_buckets();   // data-parallel reductions of the K x K MI matrix / centroid sums
     // native data parallelism (dp_rccl.cpp): a communicator owned by the context; the hooks above then point at ncclAllReduce wrappers
-    void* comm = nullptr; int comm_world = 1; std::vector<std::pair<long, long>> comm_buckets; hipStream_t comm_bucket_stream = nullptr;
+    void* comm = nullptr; void* comm2 = nullptr;      // comm: everything on the context's stream; comm2: the gradient buckets on the side stream (one communicator per stream)
+    int comm_world = 1; std::vector<std::pair<long, long>> comm_buckets; hipStream_t comm_bucket_stream = nullptr;
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
+    // caddy_set_deterministic: the backward pass is bit-reproducible -- split-K dgrads through slabs + fixed-order reduce instead of fp32 atomics, every pixel split of a
+    // weight-gradient launch into its own copy of the packed layout + fixed-order reduce (WgradArgs.det_slab), single-workgroup bias sums
+    bool deterministic = false;
+    float* wgrad_det = nullptr; long wgrad_det_cap = 0;      // scratch of the deterministic weight gradients (the stream the weight gradients run on)
     unsigned* sat_flag = nullptr;    // f16 range guard of the split-f16 forward (ConvArgs.sat_flag): ORed by any staging thread that met |x| > 65504 since the last forward began
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)

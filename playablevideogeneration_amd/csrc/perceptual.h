@@ -20,3 +20,4 @@ void vgg_build(caddy_ctx* c);
 int vgg_load(caddy_ctx* c, const float* flat);
 void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv);
 void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off);
+int vgg_eval_per_frame(caddy_ctx* c, double* out_host);      // evaluation: per reconstructed frame and level, full resolution (5 x N doubles, host)

@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* 
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
+// per IMAGE: acc[n] += sum |f_rec - f_gt| over image n's feature map (blockIdx.y = image); the evaluator's per-position perceptual loss (evaluation/evaluator.py:193)
+__global__ __launch_bounds__(256) void k_feat_l1_img(const float* rec, const float* gt, long n4_img, double* acc) {
+    __shared__ double sh[4];
+    const float4* r4 = reinterpret_cast<const float4*>(rec) + (long)blockIdx.y * n4_img;
+    const float4* g4 = reinterpret_cast<const float4*>(gt) + (long)blockIdx.y * n4_img;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4_img; i += (long)gridDim.x * 256) {
+        const float4 r = r4[i], g = g4[i];
+        s += (double)fabsf(r.x - g.x) + (double)fabsf(r.y - g.y) + (double)fabsf(r.z - g.z) + (double)fabsf(r.w - g.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc + blockIdx.y, sh[0] + sh[1] + sh[2] + sh[3]);
+}
 // ground-truth frames for the VGG19 branch: first 3 channels of observation t + t_off, bilinearly resized like F.interpolate(align_corners=False)
 // does for exact factors (losses.py:450): f = 2 -> 2x2 mean, f = 4 -> mean of the central 2x2 of each 4x4 block (same arithmetic as k_loss_l1)
 __global__ __launch_bounds__(256) void k_gt_resize(TV gt, float* out, int Ho, int Wo, long npix, int f, int t_off, int Tobs, int Trec) {
@@ -392,4 +407,43 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
         hipStreamWaitEvent(st, e, 0);
     }
     c->act.off = mark_all;
+}
+
+// Evaluation: the full-resolution perceptual distance PER RECONSTRUCTED FRAME and feature level -- out_host[l * N + n] = mean |f_l(rec_n) - f_l(gt_n)|, n = b * Trec + t --
+// after a forward pass (any mode).  The reference evaluator applies ParallelPerceptualLoss to one sequence position at a time (evaluation/evaluator.py:55,62,193-197,
+// training/losses.py:652-713): position t's value is sum_l mean_b out[l][b, t].  Same VGG19 kernels as the training loss; nothing is back-propagated.
+int vgg_eval_per_frame(caddy_ctx* c, double* out_host) {
+    const caddy_config& g = c->cfg;
+    if (!g.perceptual || !c->vgg.loaded) { set_error("caddy_perceptual_per_frame needs a context created with caddy_config.perceptual = 1 and loaded VGG19 weights"); return -2; }
+    if (!c->have_forward) { set_error("caddy_perceptual_per_frame: no forward results available"); return -2; }
+    const int Trec = c->pretraining ? g.seq_len : g.seq_len - 1, t_off = c->pretraining ? 0 : 1;
+    const T4& rec = c->frames[0];
+    const int N = rec.N;
+    hipStream_t st = c->stream;
+    if (c->gt_prefetched) hipStreamWaitEvent(st, c->gt_done, 0);      // (a training-mode forward started the ground-truth branch on the side stream: its scratch lies below fwd_off, untouched here)
+    c->act.off = c->fwd_off;
+    const size_t mark = c->act.off;
+    const int tc[5] = {64, 128, 256, 512, 512};
+    T4 gi = valloc(c, N, g.height, g.width, 3);
+    const long npix = (long)N * g.height * g.width;
+    hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, st, dv(c->obs), gi.d, g.height, g.width, npix, 1, t_off, g.seq_len, Trec);
+    T4 tg[5], tr[5];
+    { int h = g.height, w = g.width; for (int l = 0; l < 5; l++) { tg[l] = valloc(c, N, h, w, tc[l]); tr[l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; } }
+    double* acc = c->dalloc(5 * (size_t)N);
+    hipMemsetAsync(acc, 0, sizeof(double) * 5 * (size_t)N, st);
+    const size_t mark2 = c->act.off;
+    { Branch G{}; vgg_forward(c, gi, G, tg, false); }
+    c->act.off = mark2;
+    { Branch R{}; vgg_forward(c, rec, R, tr, false); }
+    if (c->act.overflow()) { c->act.off = mark; set_error("caddy_perceptual_per_frame: workspace too small"); return -1; }
+    for (int l = 0; l < 5; l++) {
+        const long n4 = (long)tr[l].H * tr[l].W * (tr[l].C / 4);
+        const unsigned bx = (unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 64 ? 64 : n4 / 1024));
+        hipLaunchKernelGGL(k_feat_l1_img, dim3(bx, N), dim3(256), 0, st, (const float*)tr[l].d, (const float*)tg[l].d, n4, acc + (size_t)l * N);
+    }
+    hipMemcpyAsync(out_host, acc, sizeof(double) * 5 * (size_t)N, hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    for (int l = 0; l < 5; l++) { const double numel = (double)tr[l].H * tr[l].W * tr[l].C; for (int n = 0; n < N; n++) out_host[(size_t)l * N + n] /= numel; }
+    c->act.off = mark;
+    return c->fail ? -1 : 0;
 }

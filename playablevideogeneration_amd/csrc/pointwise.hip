@@ -315,6 +315,7 @@ struct RedArgs {
     double* partials;   // MODE 0/1: when set, block b writes its sums to partials[b][2C] (no atomics); k_sum_partials folds them
     const float *lz_scale, *lz_shift;   // MODE 1, act without a materialised output: the LeakyReLU slope is taken from x * scale + shift (lazily applied BatchNorm)
     PixDiv hw;                          // set by run_reduce: H * W of x
+    int det;                            // MODE 2 / 3: one workgroup per output vector (the float atomics then have a single contributor each: bit-reproducible)
 };
 // ACT (MODE 1): 0 = no activation between the BatchNorm and the gradient, 1 = LeakyReLU slope from the materialised output `outm`, 2 = from x * scale + shift (lazily
 // applied BatchNorm) -- a template parameter so that no branch stands between the loads of a trip: four pixels per trip, all their loads issued before the first use
@@ -462,12 +463,12 @@ int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
     a.hw = make_fdiv(HW);
     const bool full = (a.x.C & 3) == 0;      // (dout / outm share x's channel count)
     if (MODE == 2) {
-        int ppb = HW > 4096 ? 4096 : HW;
+        int ppb = (HW > 4096 && !a.det) ? 4096 : HW;
         a.pix_per_block = ppb;
         if (full) hipLaunchKernelGGL((k_reduce<MODE, true, 0>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_reduce<MODE, false, 0>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
     } else {
-        long maxb = (MODE <= 1 && a.partials) ? RED_MAX_BLOCKS : 1024;
+        long maxb = (MODE <= 1 && a.partials) ? RED_MAX_BLOCKS : ((MODE == 3 && a.det) ? 1 : 1024);
         long ppb = (P + maxb - 1) / maxb;
         int C4r = (a.x.C + 3) / 4; int ptr = 256 / (C4r < 256 ? C4r : 256);      // pixel rows handled in parallel by one block
         long minp = ptr * 4 > 16 ? ptr * 4 : 16;                                 // >= 4 pixels per thread
@@ -797,8 +798,8 @@ int pw_gap(const TV& x, float* out, hipStream_t st) {
     return run_reduce<2>(a, st);
 }
 int pw_gap_bwd(const float* dout, const TV& dx, hipStream_t st) { return run_map((long)dx.N * dx.H * dx.W, dx.C, FGapBwd{dx, dout, make_fdiv(dx.H * dx.W), 1.f / (float)(dx.H * dx.W)}, st, quads(dx.C)); }
-int pw_colsum(const TV& x, float* out, hipStream_t st) { RedArgs a{}; a.x = x; a.outf = out; return run_reduce<3>(a, st); }
-int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st) { RedArgs a{}; a.x = x; a.outf = out; a.out_sn = out_sn; a.scale = 1.f; return run_reduce<2>(a, st); }
+int pw_colsum(const TV& x, float* out, hipStream_t st, bool det) { RedArgs a{}; a.x = x; a.outf = out; a.det = det ? 1 : 0; return run_reduce<3>(a, st); }
+int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st, bool det) { RedArgs a{}; a.x = x; a.outf = out; a.out_sn = out_sn; a.scale = 1.f; a.det = det ? 1 : 0; return run_reduce<2>(a, st); }
 int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st) { return run_map((long)d.N * d.H * d.W, 1, FNchwToNhwc{src, src_sn, d, make_fdiv(d.H * d.W)}, st); }
 int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st) { return run_map((long)s.N * s.H * s.W, 1, FNhwcToNchw{s, dst, dst_sn, make_fdiv(s.H * s.W), acc}, st); }
 // bias of a conv with the following eval-mode BatchNorm folded in: out[o] = bias[o] * scale[o] + shift[o]

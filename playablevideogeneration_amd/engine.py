@@ -107,6 +107,9 @@ def _bind(lib):
     lib.caddy_set_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
     lib.caddy_f16_saturated.argtypes = [C.c_void_p]
+    lib.caddy_perceptual_per_frame.argtypes = [C.c_void_p, C.c_void_p]
+    lib.caddy_sequence_losses_per_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.caddy_set_deterministic.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_generate_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_bn_layer_count.argtypes = [C.c_void_p]
     lib.caddy_bn_calls.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
@@ -181,7 +184,7 @@ class Engine:
 
     def enable_data_parallel(self, process_group=None, force=False, overlap=True, native=None):
         """Data parallelism, one process per GPU.  native (default on the GPU when the library finds an RCCL): the three reductions are issued from C straight
-        into ncclAllReduce on a communicator the context owns (caddy_dp_init; the 128-byte unique id travels through torch.distributed once) -- no Python on the
+        into ncclAllReduce on a communicator the context owns (caddy_dp_init; the two 128-byte unique ids travel through torch.distributed once) -- no Python on the
         per-step path.  Otherwise torch.distributed hooks (gloo in the CPU tests, or RCCL through torch):
 
         Data parallelism over torch.distributed (RCCL on the MI355X, gloo in the CPU tests), one process per GPU.
@@ -200,9 +203,13 @@ class Engine:
         if native is None:      # (CADDY_DP_NATIVE=0: the torch.distributed hooks even where RCCL is loadable)
             native = (self.device.type == "cuda" and os.environ.get("CADDY_DP_NATIVE", "1") != "0"
                       and hasattr(self.lib, "caddy_dp_available") and self.lib.caddy_dp_available() == 1)
+        if world > 1:      # every rank must take the same branch BEFORE anyone enters the unique-id broadcast / ncclCommInitRank: agree on the weakest rank's capability
+            cap = torch.tensor([int(bool(native))], device=self.device if dist.get_backend(process_group) == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(cap, op=dist.ReduceOp.MIN, group=process_group)
+            native = bool(cap.item())
         if native:
             rank = dist.get_rank(process_group)
-            buf = C.create_string_buffer(128)
+            buf = C.create_string_buffer(256)      # two ncclUniqueIds: one communicator per stream (dp_rccl.cpp)
             ok = 1
             if rank == 0:
                 ok = int(self.lib.caddy_dp_unique_id(buf) == 0)
@@ -213,6 +220,8 @@ class Engine:
             if ok:
                 self._stream()
                 ok = int(self.lib.caddy_dp_init(self.ctx, uid, world, rank, int(bool(overlap))) == 0)
+            if not ok and "did not return within" in self._err():      # a rank never arrived: the other ranks' state is unknown, there is nothing to fall back to
+                raise RuntimeError(self._err())
             if world > 1:      # every rank must take the same path: one failed communicator sends all of them to the hook path
                 flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
@@ -320,6 +329,11 @@ class Engine:
         """roll-out with the eval-mode BatchNorms folded into the preceding convolutions (default) or as separate launches; takes effect at the next
         start_inference / generate_next"""
         self._check(self.lib.caddy_set_rollout_fold(self.ctx, 1 if on else 0))
+
+    def set_deterministic(self, on: bool):
+        """bit-reproducible backward pass (slabs + fixed-order reduces instead of fp32 atomics in arrival order; the forward pass always is): two backward passes over the
+        same forward give bit-identical gradients, as the reference's CPU path does.  Slower (see profiles/); default off."""
+        self._check(self.lib.caddy_set_deterministic(self.ctx, int(bool(on))))
 
     def set_precision(self, forward: int, backward: int):
         """arithmetic of the model's wide 3x3 convolutions: forward 0 (exact fp32) | 16 (split f16, default); backward 0 | 17 (split bf16, default)"""
@@ -484,6 +498,25 @@ class Engine:
                                              weight_decay, step, grad_scale))
 
     # ---- roll-out (Model.start_inference / generate_next) ----
+    def sequence_losses_per_frame(self, pretraining=False):
+        """evaluator quantities of the last forward from the loss kernels: (l1 (B, Trec), state_mse (B, T)) float64 CPU tensors -- mean |frame - observation[:3]| per
+        reconstructed frame and mean (reconstructed state - state)^2 per frame (evaluation/evaluator.py:192,194)"""
+        Trec = self.T if pretraining else self.T - 1
+        l1 = torch.zeros(self.B, Trec, dtype=torch.float64)
+        mse = torch.zeros(self.B, self.T, dtype=torch.float64)
+        self._stream()
+        self._check(self.lib.caddy_sequence_losses_per_frame(self.ctx, l1.data_ptr(), mse.data_ptr()))
+        return l1, mse
+
+    def perceptual_per_frame(self, pretraining=False) -> torch.Tensor:
+        """(5, B, Trec) float64 CPU tensor: full-resolution VGG19 feature distance mean |relu{l+1}_1(rec) - relu{l+1}_1(gt)| per reconstructed frame and level, through
+        the HIP loss network (evaluation/evaluator.py:55,193: the per-position perceptual loss is sum_l mean_b of column t)"""
+        Trec = self.T if pretraining else self.T - 1
+        out = torch.zeros(5, self.B, Trec, dtype=torch.float64)
+        self._stream()
+        self._check(self.lib.caddy_perceptual_per_frame(self.ctx, out.data_ptr()))
+        return out
+
     def f16_saturated(self) -> bool:
         """True if a split-f16 forward convolution (model or VGG19) met |x| > 65504 since the last forward / start_inference began: the value was clamped to the f16 range.
         Remedy: `set_precision(0, 17)` / `set_vgg_precision(0, 17)` (exact-fp32 forward).  Waits for the stream."""

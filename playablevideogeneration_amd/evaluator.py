@@ -2,7 +2,9 @@
 the same quantities -- per-position observation / state losses of the gt_init = 1 roll-out, action entropies, direction KL, mutual
 information, Hungarian action accuracy and the ground-truth -> model action mapping -- computed from the HIP forward pass, without the
 reference's wandb / image-grid / plotting side effects (and without `sklearn.utils.linear_assignment_`, removed from sklearn >= 0.23:
-`scipy.optimize.linear_sum_assignment` gives the same optimum).  The VGG perceptual sequence loss is omitted (no pretrained weights).
+`scipy.optimize.linear_sum_assignment` gives the same optimum).  The per-position observation / state / perceptual losses come from the library's loss kernels
+(caddy_sequence_losses_per_frame, caddy_perceptual_per_frame: the VGG19 of the training loss, evaluator.py:55,62,193-197); the perceptual entries appear when the model
+carries VGG19 weights (trainer: `training.vgg19_weights` / `vgg19_from_torchvision`, or model.enable_perceptual(state_dict)).
 
     ev = evaluator(config, dataset, logger, action_sampler=None, logger_prefix="test")
     log_data = ev.evaluate(model, step)              # dict with the reference's keys: "<prefix>/observations_loss/pos_3", ".../actions_accuracy", ...
@@ -112,11 +114,23 @@ class Evaluator:
                 r = model(bt, ground_truth_observations_init=1, action_sampler=self.action_sampler)
                 frames, states, rec_states, selected, logits, samples = r[0], r[3], r[2], r[5], r[6], r[7]
                 ddist, r_logits = r[10], r[15]
-                obs = bt[0].to(frames.device)
-                avg, pos = sequence_loss(obs, frames, observations_l1)
-                add({"observations_loss/avg": avg, **{f"observations_loss/pos_{j}": v for j, v in enumerate(pos)}})
-                avg, pos = sequence_loss(states, rec_states, lambda a, b: F.mse_loss(a, b))
-                add({"states_loss/avg": avg, **{f"states_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                eng = getattr(model.module if hasattr(model, "module") else model, "last_engine", None)
+                if eng is not None and hasattr(eng, "sequence_losses_per_frame"):      # per-frame sums from the loss kernels; positions = means over the batch
+                    l1, mse = eng.sequence_losses_per_frame()
+                    pos = [0.0] + l1.mean(0).tolist()                 # the reconstruction is one element shorter: position 0 counts as 0 (losses.py:683-689)
+                    add({"observations_loss/avg": float(np.mean(pos[1:])), **{f"observations_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                    pos = mse.mean(0).tolist()
+                    add({"states_loss/avg": float(np.mean(pos)), **{f"states_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                    if getattr(eng, "perceptual", False) and getattr(eng, "vgg_loaded", False):
+                        pl = eng.perceptual_per_frame()                # (5, B, T - 1): sum over the levels of the per-level batch means (ParallelPerceptualLoss: total_loss.mean())
+                        pos = [0.0] + pl.mean(1).sum(0).tolist()
+                        add({"perceptual_loss/avg": float(np.mean(pos[1:])), **{f"perceptual_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                else:      # (a model object without the engine interface)
+                    obs = bt[0].to(frames.device)
+                    avg, pos = sequence_loss(obs, frames, observations_l1)
+                    add({"observations_loss/avg": avg, **{f"observations_loss/pos_{j}": v for j, v in enumerate(pos)}})
+                    avg, pos = sequence_loss(states, rec_states, lambda a, b: F.mse_loss(a, b))
+                    add({"states_loss/avg": avg, **{f"states_loss/pos_{j}": v for j, v in enumerate(pos)}})
                 fl = logits.reshape(-1, logits.shape[-1])
                 pd = ddist.reshape(-1, 2, ddist.shape[-1])
                 p1, p2 = torch.softmax(fl, -1), torch.softmax(r_logits.reshape(fl.shape), -1)

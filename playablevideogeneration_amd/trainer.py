@@ -43,8 +43,11 @@ class Trainer:
         need_vgg = self.perceptual_lambda != 0.0 or self.perceptual_lambda_pretraining != 0.0 or bool(tr.get("log_perceptual", False))
         self.vgg_state = self._find_vgg_weights(tr) if need_vgg else None      # (a zero-weight term would still cost a full VGG19 forward per step)
         if (self.perceptual_lambda != 0.0 or self.perceptual_lambda_pretraining != 0.0) and self.vgg_state is None:
-            raise Exception("loss_weights.perceptual_loss_lambda is non-zero but no VGG19 weights are available: set training.vgg19_weights to a "
-                            "torchvision vgg19 state_dict file (the reference downloads it, model/layers/vgg.py:16) or set the lambdas to 0")
+            raise Exception("loss_weights.perceptual_loss_lambda is non-zero but no VGG19 weights are available.  The reference builds torchvision's pretrained vgg19 "
+                            "unconditionally (model/layers/vgg.py:16, a download on first use); this plugin never downloads implicitly.  Either set "
+                            "training.vgg19_weights to a torchvision vgg19 state_dict file (vgg19().state_dict() or .features.state_dict()), or set "
+                            "training.vgg19_from_torchvision: true to let torchvision load its cached / downloadable weights as the reference does, "
+                            "or set the perceptual lambdas to 0")
         if self.vgg_state is not None:
             model.module.enable_perceptual(self.vgg_state)
         self.dataloader = self._build_dataloader(config, dataset)

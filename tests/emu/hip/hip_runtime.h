@@ -158,6 +158,8 @@ hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipDeviceSynchronize();
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 // graph API: the simulator has no stream capture -- hipStreamBeginCapture fails and the driver keeps its eager roll-out path
 typedef struct emu_graph_t* hipGraph_t;
 typedef struct emu_graph_exec_t* hipGraphExec_t;

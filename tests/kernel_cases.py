@@ -153,6 +153,20 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     for i in range(nw):
         e = (gws_d[i].cpu() - ws_r[i].grad).abs().max().item()
         assert e < (wgrad_tol or tol) * max(1.0, ws_r[i].grad.abs().max().item()) * 4, ("wgrad", i, e)
+    # bit-reproducible mode (WgradArgs.det_slab: one zero-filled copy of the packed layout per pixel split + fixed-order reduce): same dW (up to the summation order), and two
+    # launches give IDENTICAL bits -- whichever kernel the launcher picked for this shape
+    det = torch.zeros(1 << 22, device=dev)
+    dws = []
+    for _ in range(2):
+        dwp_d = torch.zeros_like(wp)
+        wa.dwp, wa.det_slab, wa.det_cap = dwp_d.data_ptr(), det.data_ptr(), det.numel()
+        assert lib.caddy_k_conv_wgrad(C.byref(wa), st) == 0
+        sync(dev)
+        dws.append(dwp_d)
+    wa.dwp, wa.det_slab, wa.det_cap = dwp.data_ptr(), None, 0
+    e = (dws[0] - dwp).abs().max().item()
+    assert e < (wgrad_tol or tol) * max(1.0, dwp.abs().max().item()) * 4, ("deterministic wgrad vs atomics", e)
+    assert torch.equal(dws[0], dws[1]), "deterministic wgrad not bit-reproducible"
     # time-batched addressing (WgradArgs.group_n): the same batch laid out as 2 groups with a padded group stride must give the same dW
     if N % 2 == 0:
         gn = N // 2
@@ -201,6 +215,22 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
             got = got.sum(dim=(2, 3))
         e = (got - x_r.grad).abs().max().item()
         assert e < tol * 8 * max(1.0, x_r.grad.abs().max().item()), ("dgrad", si, e)
+        # deterministic split-K of the accumulating launch (ConvArgs.deterministic: slabs + fixed-order reduce that adds the old contents)
+        scr = torch.zeros(9 * N * H * W * round_up(c, 4), device=dev)
+        outs = []
+        for _ in range(2):
+            gx2 = torch.ones((N, H, W, round_up(c, 4)), device=dev)
+            da.out, da.deterministic, da.split_scratch, da.split_cap = gx2.data_ptr(), 1, scr.data_ptr(), scr.numel()
+            assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0
+            sync(dev)
+            outs.append(gx2)
+        da.deterministic, da.split_scratch, da.split_cap = 0, None, 0
+        got2 = to_nchw(outs[0], c) - 1.0
+        if bc:
+            got2 = got2.sum(dim=(2, 3))
+        e = (got2 - x_r.grad).abs().max().item()
+        assert e < tol * 8 * max(1.0, x_r.grad.abs().max().item()), ("deterministic dgrad", si, e)
+        assert torch.equal(outs[0], outs[1]), "deterministic dgrad not bit-reproducible"
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -63,7 +63,7 @@ def _oracle_run(c, d, P, obs, dtype, record):
     return Po, out
 
 
-def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
+def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
     """forward_full_model + losses + backward + BN buffers + centroids + MI-EMA.
 
     Forward / losses / buffers: against the REFERENCE's golden vectors (and the oracle).  Gradients are compared with an
@@ -73,7 +73,8 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
     (0.2 <-> 1) and shift the BatchNorm-backward means -- O(1e-3) relative, data dependent (verified element by element
     with the caddy_debug_* introspection API; single-step graphs, where no flip occurs, agree to 2e-5).  Criterion:
     relative L2 error <= max(5 x fp32-oracle error, 3e-2) and per-parameter max error <= max(5 x, 1e-1); a missing
-    or wrong term in the backward graph shows up as O(0.1 - 1).
+    or wrong term in the backward graph shows up as O(0.1 - 1).  deterministic=True (caddy_set_deterministic: no arrival-order atomics, so no run-to-run noise
+    on top of the arithmetic's own error): relative L2 error <= max(2 x fp32-oracle error, 5e-3).
     """
     c, z = H.load_case(name)
     d, P, obs = H.inputs_of(c)
@@ -97,6 +98,8 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
     # frame MSE criterion of the north star (evaluation/metrics/mse.py:21): mean over C,H,W per (b,t), within 1e-5
     mse = ((out[0].cpu() - torch.from_numpy(z["out0"])) ** 2).mean(dim=(2, 3, 4))
     assert mse.max().item() < 1e-5
+    if deterministic:
+        eng.set_deterministic(True)
     losses = eng.loss_backward(H.LOSS_W, smooth_mi=smooth, mi_alpha=0.2)
     assert abs(losses["total"] - float(z["loss_total"])) < 2e-5, (losses["total"], float(z["loss_total"]))
     for k in ("rec", "states", "entropy", "dir_kl", "mi", "state_kl"):
@@ -120,7 +123,7 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None):
         worst_h, worst_o = max(worst_h, (g - g64).abs().max().item() / s), max(worst_o, (g32 - g64).abs().max().item() / s)
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
-    assert rel_h <= max(5 * rel_o, 3e-2), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+    assert rel_h <= (max(2 * rel_o, 5e-3) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
     assert worst_h <= max(5 * worst_o, 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
     # reference's own gradient summaries (loose: same conditioning caveat)
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
@@ -505,6 +508,45 @@ def property_case(lib, dev, c, seed=3, perceptual=False):
             if x.dim() >= 1 and x.shape[0] == B:
                 assert torch.equal(x[perm], y), ("eval-mode output is not batch-permutation equivariant", i)
     return eng
+
+
+def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False):
+    """caddy_set_deterministic: two backward passes over the same forward give BIT-IDENTICAL flat gradients (slabs + fixed-order reduces instead of fp32
+    atomics in arrival order); the backward is then exactly linear in the loss weights for a power-of-two factor; and the deterministic gradient agrees with the default
+    (atomic) one up to its run-to-run noise.  Returns the measured distances."""
+    from playablevideogeneration_amd.init import init_parameters, random_vgg19_state
+    B, T, K, Da, S, Hh, W = c["B"], c["T"], c["K"], c["Da"], c["S"], c["H"], c["W"]
+    eng = make_engine(c, lib, dev, perceptual=perceptual)
+    init_parameters(eng, seed)
+    if perceptual:
+        eng.load_vgg(random_vgg19_state(0))
+    g = torch.Generator(device=dev).manual_seed(seed)
+    obs = torch.rand(B, T, 3 * S, Hh, W, device=dev, generator=g) * 2 - 1
+    n = T - 1
+    noise = {"eps_states": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs": torch.randn(B * n, Da, device=dev, generator=g),
+             "gumbel_uniform": torch.rand(B * n, K, device=dev, generator=g),
+             "eps_states_rec": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs_rec": torch.randn(B * n, Da, device=dev, generator=g)}
+    eng.forward_full(obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
+    w1 = dict(H.LOSS_W, perceptual=1.0) if perceptual else dict(H.LOSS_W)
+    rel = lambda a, b: ((a - b).double().norm() / b.double().norm()).item()
+    eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    g_atomic = eng.grads.clone()
+    eng.set_deterministic(True)
+    gs = []
+    for _ in range(3):
+        eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+        gs.append(eng.grads.clone())
+    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2]), ("deterministic backward not bit-reproducible", rel(gs[1], gs[0]), rel(gs[2], gs[0]))
+    assert torch.isfinite(gs[0]).all() and gs[0].abs().max().item() > 0
+    eng.loss_backward({k: 2 * v for k, v in w1.items() if k != "mi_entropy"}, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    lin = rel(eng.grads, 2 * gs[0])
+    # all weights x2: every gradient seed doubles exactly (power of two) and every kernel is linear in its gradient operand -- up to the split-bf16 rounding of the gradient
+    # operands, which is scale-invariant as well: exact equality
+    assert lin == 0.0 or (not tight and lin < 1e-6), ("deterministic backward not linear in the loss weights", lin)
+    noise_atomic = rel(g_atomic, gs[0])
+    assert noise_atomic < 1e-3, ("deterministic vs atomic gradients", noise_atomic)
+    eng.set_deterministic(False)
+    return dict(atomic_vs_deterministic=noise_atomic, linearity=lin)
 
 
 def full_geometry_case(lib, dev, c):

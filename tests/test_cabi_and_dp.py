@@ -170,7 +170,8 @@ def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
         assert k in res
 
 
-def _trainer_worker(rank, world, port, out):
+def _trainer_worker(rank, world, port, out, skew=0.0):
+    import time
     import torch.distributed as dist
     from tests.test_host_api_emu import _config, _make_model
     from playablevideogeneration_amd import smooth_mi_trainer
@@ -188,7 +189,9 @@ def _trainer_worker(rank, world, port, out):
     obs = torch.rand(1, 4, 3, 32, 32, generator=torch.Generator().manual_seed(10 + rank)) * 2 - 1      # each rank: its own shard
     for i in range(2):
         torch.manual_seed(50 + 7 * rank + i)
+        time.sleep(skew * ((rank * 3 + i) % world))      # ranks arrive at the collectives in a different order every step
         tr.compute_losses(m, (obs, None, None, None), 4)
+        time.sleep(skew * ((rank + 2 * i + 1) % world))
         tr.optimizer_step(m)
     torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone()}, os.path.join(out, f"t{rank}.pt"))
     dist.barrier()
@@ -201,3 +204,14 @@ def test_trainer_mirror_is_data_parallel_aware_gloo_world2(tmp_path):
     mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t0, t1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
     assert torch.equal(t0["params"], t1["params"]) and torch.equal(t0["centroids"], t1["centroids"])
+
+
+def test_trainer_mirror_data_parallel_gloo_world4_skewed_ranks(tmp_path):
+    """four ranks with unequal step timing (every rank sleeps a different time before the forward and before the optimiser step, differently each step): the order in which
+    ranks reach the three reductions varies, the replicas must still end identical -- ordering bugs of the collective sequence show up as a hang or as diverging replicas"""
+    import torch.multiprocessing as mp
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_trainer_worker, args=(4, port, str(tmp_path), 0.15), nprocs=4, join=True)
+    ts = [torch.load(tmp_path / f"t{r}.pt") for r in range(4)]
+    for t in ts[1:]:
+        assert torch.equal(ts[0]["params"], t["params"]) and torch.equal(ts[0]["centroids"], t["centroids"])

@@ -215,9 +215,45 @@ def headless_evaluator_case(make_model, dev):
     assert abs(log["val/actions_accuracy"] - best) < 1e-9 and set(ev.get_best_action_mappings().keys()) == {0, 1, 2}
 
 
+def headless_evaluator_perceptual_case(make_model, dev):
+    """the evaluator's per-position perceptual loss (evaluation/evaluator.py:55,62,193-197: SequenceLossEvaluator(ParallelPerceptualLoss())) through the HIP loss network on
+    seeded VGG19 weights, against the oracle's perceptual_loss applied position by position; the per-position observation / state losses from the loss
+    kernels against plain torch on the oracle's forward."""
+    from playablevideogeneration_amd import evaluator as EV
+    cfg = _config(res=(8, 8))
+    cfg["evaluation"] = {"evaluator": "playablevideogeneration_amd.evaluator", "batching": {"batch_size": 2}, "max_evaluation_batches": None}
+    m = make_model(cfg)
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    P = O.make_params(d, seed=7)
+    m.load_state_dict(P)
+    V = O.make_vgg_params()
+    m.enable_perceptual(V)
+    obs = torch.rand(2, 3, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    ev = EV.evaluator(cfg, [(obs, None, None, None)], logger=None, action_sampler=None, logger_prefix="val")
+    torch.manual_seed(9)
+    log = ev.evaluate(m, step=3)
+    torch.manual_seed(9)
+    with torch.no_grad():
+        ref = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=False).forward_full(obs, 1, tau=1.0)
+        assert log["val/perceptual_loss/pos_0"] == 0.0
+        for t in range(1, 3):
+            want = O.perceptual_loss(obs[:, t:t + 1], ref[0][:, t - 1:t], V)[0].item()
+            assert abs(log[f"val/perceptual_loss/pos_{t}"] - want) < 2e-4 * max(1.0, abs(want)), (t, log[f"val/perceptual_loss/pos_{t}"], want)
+            want = (obs[:, t, :3] - ref[0][:, t - 1]).abs().mean().item()
+            assert abs(log[f"val/observations_loss/pos_{t}"] - want) < 2e-4
+        for t in range(3):
+            want = ((ref[2][:, t] - ref[3][:, t]) ** 2).mean().item()
+            assert abs(log[f"val/states_loss/pos_{t}"] - want) < 2e-4 * max(1.0, want)
+    assert abs(log["val/perceptual_loss/avg"] - np.mean([log[f"val/perceptual_loss/pos_{t}"] for t in range(1, 3)])) < 1e-9
+
+
 PRE_W = {"reconstruction_loss_lambda_pretraining": 1.0, "perceptual_loss_lambda_pretraining": 0.0, "hidden_states_rec_lambda_pretraining": 1.0,
          "states_rec_lambda_pretraining": 0.2, "entropy_lambda_pretraining": 0.0, "action_directions_kl_lambda_pretraining": 1e-4,
          "action_mutual_information_lambda_pretraining": 0.15, "action_state_distribution_kl_lambda_pretraining": 0.0}     # as in tools/gen_trainer_golden.py
+
+
+def test_headless_evaluator_perceptual_on_simulator():
+    headless_evaluator_perceptual_case(_make_model, "cpu")
 
 
 def trainer_golden_case(name, make_model, with_vgg):

@@ -129,3 +129,15 @@ def test_merged_weight_packing_equals_per_layer_launches():
         assert rel < 2e-4, ("gradients", rel)
     finally:
         M.SIM_SPLIT = False
+
+
+def test_deterministic_backward_mode():
+    """caddy_set_deterministic on the simulator (workgroups run on several host threads, so the default mode's atomics really arrive in varying order): three backward passes
+    bit-identical, split-operand arithmetic, both model variants"""
+    lib = load_emu()
+    M.SIM_SPLIT = True
+    try:
+        M.deterministic_case(lib, "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7))
+        M.deterministic_case(lib, "cpu", dict(variant="main", K=7, Da=2, Ch=128, S=2, B=2, T=3, H=32, W=48, gt=1, tau=0.7))
+    finally:
+        M.SIM_SPLIT = False

@@ -21,6 +21,14 @@ def test_full_model_parity(lib, name):
     M.full_case(name, lib, "cuda")
 
 
+@pytest.mark.parametrize("name", ["full_reduced_s1", "full_main_s1", "full_main_s4_hard"])
+def test_full_model_parity_deterministic_backward(lib, name):
+    """the same goldens with the bit-reproducible backward (caddy_set_deterministic) and the tighter gradient bound it allows: relative L2 distance to the fp64 oracle's
+    gradients <= max(2 x the fp32 oracle's own, 5e-3)"""
+    _, info = M.full_case(name, lib, "cuda", deterministic=True)
+    print(info)
+
+
 @pytest.mark.parametrize("name", ["full_reduced_s1_plainmi", "full_main_s1_nogumbel", "full_reduced_s1_novar"])
 def test_full_model_parity_config_branches(lib, name):
     """reference configuration branches outside the BAIR / Breakout YAMLs: the plain MutualInformationLoss of `training.trainer` (03_tennis.yaml,
@@ -161,6 +169,24 @@ def test_baseline_geometry_properties_with_perceptual_term(lib):
     branch on the side stream beside the forward, half / quarter-resolution levels beside the full-resolution one, 8-wave tiles at N = 120):
     reproducible forward, loss composition incl. the perceptual term, linearity of the backward in the weights, repeatable + finite gradients."""
     M.property_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=8, T=16, H=256, W=256, gt=6, tau=1.0), perceptual=True)
+    torch.cuda.empty_cache()
+
+
+def test_deterministic_backward_at_baseline_geometry(lib):
+    """caddy_set_deterministic at BASELINE.json configs[1] (BAIR 256x256, T=16, B=8, gt=6): three backward passes over one forward are bit-identical on the flat gradient
+    (torch.equal), the backward is exactly linear in the loss weights, and the deterministic gradient lies within the default mode's run-to-run noise."""
+    import json, os
+    res = M.deterministic_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=8, T=16, H=256, W=256, gt=6, tau=1.0), tight=True)
+    print(res)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/deterministic_mode.json", "w") as f:
+        json.dump(res, f, indent=1)
+    torch.cuda.empty_cache()
+
+
+def test_deterministic_backward_with_perceptual_term(lib):
+    """the same with the VGG19 term inside the step (levels on two streams), Breakout 160x160 T=9 B=8"""
+    M.deterministic_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=8, T=9, H=160, W=160, gt=6, tau=0.4), perceptual=True, tight=True)
     torch.cuda.empty_cache()
 
 
