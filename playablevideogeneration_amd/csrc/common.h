@@ -174,6 +174,7 @@ extern int g_hx_big_override;
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
                              const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
+int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA

@@ -1,0 +1,176 @@
+// Image heads of the rendering network on the 16-bit matrix pipe: nn.Conv2d(C -> 3, k = 3 | 7, padding = k / 2) + tanh of the FinalBlocks
+// (model/layers/final_block.py:9-29, model/main_model/rendering_network.py:39-41,62-69), forward.
+//
+// Why a kernel of its own: 3 output channels.  The vector-ALU kernel these layers ran on (conv_thin.hip) reached 26 - 32 TFLOP/s on the 7x7 head (155 us per 8 frames of
+// 256 x 256, profiles/r03_*_phases_and_layers.txt) although the layer only has to stream 67 MB -- it is bound by its 49 x 32 fp32 FMAs per output value.  Here the three
+// output channels are the (padded) M = 16 rows of v_mfma_f32_16x16x32_f16, 16 pixels the N columns, 32 input channels the K of one instruction; operands are split as in
+// conv_hx.hip (x = hi + lo in f16, three products per fp32 product, fp32 accumulation: fp32-class accuracy).  13 of the 16 rows are padding -- the instruction count per output
+// value still drops from 1568 FMAs to 49 x 3 x (1/16 of a matrix instruction per pixel), and the kernel becomes LDS-read / staging bound instead of FMA bound.
+//
+// Layout.  A workgroup owns a TH x TW pixel tile.  Per 32-channel chunk the (TH + 2R) x (TW + 2R) halo of the fp32 input is staged once, split, into EIGHT LDS arrays
+// [k-block 0..3][plane hi | lo][pixel][8 halves]: the B fragment of the instruction is (pixel = lane & 15, k-block = lane >> 4) -> one 16-byte read, and ds_read_b128 serves
+// the lanes {0-3, 12-15, 20-27} together, i.e. pixels {0-3, 12-15} of k-block 0 and pixels {4-11} of k-block 1: with 16 bytes per pixel and the arrays a multiple of 256 B
+// apart those 16 reads fall on the 16 distinct 16-byte slots of the bank row (a [pixel][32 channels] row-major image would put 7 of them on busy slots).  The weights of
+// the chunk -- 3 rows x 32 channels per tap, converted from the packed fp32 layout by the workgroup itself, so no extra packed form is kept -- sit in LDS as
+// [tap][row 0..3][hi 32 | lo 32] with row 3 all zero: lanes of the padding rows read row 3 (one broadcast address).  All taps of a chunk read the same staged image: no barrier
+// inside the tap loop.
+//
+// Epilogue: rows 0..2 of the accumulator tile belong to lanes 0..15 (row = 4 (lane >> 4) + r, col = lane & 15): bias, tanh, three stores per pixel.
+// Roofline: HBM (67 MB read + 6 MB written per 8 frames at 256 x 256 = 12 us); achieved is bounded by the staging (2.4 x halo over-fetch from L2) and the fragment reads.
+#include "common.h"
+
+namespace {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD_KC = 32;                                   // channels per chunk = K of one instruction
+#define HD_F16_MAX 65504.f
+
+// NW waves per workgroup.  Tile choice = halo over-fetch vs occupancy: the 7x7 head on 8 x 16 tiles re-reads its input 2.4 x (14 x 22 halo pixels per 128 outputs) and was
+// bound by exactly that traffic (138 us per 8 frames of 256 x 256); 16 x 32 tiles (22 x 38: 1.6 x) need 136 KB of LDS -- one workgroup per CU, so eight waves keep two per SIMD.
+template <int KS, int TH, int TW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NT = 64 * NW;
+    constexpr int R = KS / 2, HH = TH + 2 * R, HW = TW + 2 * R, HPX = HH * HW, TAPS = KS * KS;
+    constexpr int ARR = (HPX * 8 + 127) / 128 * 128;        // halves per array: a multiple of 256 B
+    constexpr int WROW = 2 * HD_KC + 8;                      // weight row pitch in halves (hi 32 | lo 32 | pad)
+    constexpr int NG = TH * TW / 16 / NW;                    // 16-pixel groups per wave
+    constexpr int GPR = TW / 16;                             // groups per tile row
+    static_assert(TW % 16 == 0 && (TH * TW) % (16 * NW) == 0, "tile");
+    __shared__ __attribute__((aligned(16))) _Float16 Xs[8 * ARR];
+    __shared__ __attribute__((aligned(16))) _Float16 Wl[TAPS * 4 * WROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tile = blockIdx.x;
+    const int n = tile / (tiles_x * tiles_y);
+    tile -= n * tiles_x * tiles_y;
+    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
+    const ConvSrc s = a.src[0];
+    const int nchunks = (s.C + HD_KC - 1) / HD_KC;
+
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: A = weights (row = lane & 15 -> rows >= 3 read the zero row), B = pixels of this wave's groups
+    const int kb = lane >> 4;
+    const int arow = (lane & 15) < 3 ? (lane & 15) : 3;
+    const int aoff = arow * WROW + kb * 8;
+    int boff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int gi = wave * NG + g;
+        boff[g] = (2 * kb) * ARR + ((gi / GPR) * HW + (gi % GPR) * 16 + (lane & 15)) * 8;
+    }
+    const bool bn = s.bn_scale != nullptr;                   // lazily applied BatchNorm of the producer (ConvSrc.bn_*)
+    const float slope = s.bn_act ? 0.2f : 1.f;
+    float amax = 0.f;
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+        if (chunk > 0) __syncthreads();                     // every wave is done with the previous chunk's image and weights
+        // ---- weights of this chunk: packed fp32 [tap][Cout_pad][Ktot] -> split f16 (x 64: see HX_WSCALE), rows 0..2 + the zero row ----
+        for (int i = tid; i < TAPS * 4 * (HD_KC / 4); i += NT) {
+            const int q = i % (HD_KC / 4), rr = (i / (HD_KC / 4)) & 3, tap = i / (HD_KC / 4) / 4;
+            const int k = chunk * HD_KC + 4 * q;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < a.Cout && k < a.Ktot) w = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + rr) * a.Ktot + k);
+            const float wv[4] = {w.x * HX_WSCALE, w.y * HX_WSCALE, w.z * HX_WSCALE, w.w * HX_WSCALE};
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { hi[e] = (_Float16)wv[e]; lo[e] = (_Float16)(wv[e] - (float)hi[e]); }
+            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + 4 * q]) = hi;
+            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + HD_KC + 4 * q]) = lo;
+        }
+        // ---- halo image of this chunk: thread = (pixel, channel quad q of 8); all loads of a thread are issued before the first conversion (clamped addresses, no branch
+        //      around a load: a loop of load -> convert -> store leaves one load in flight per thread) ----
+        constexpr int NL = (HPX * 8 + NT - 1) / NT, PP = NT / 8;      // float4 loads per thread, pixels per pass
+        float4 ld[NL];
+        const int q = tid & 7, c = chunk * HD_KC + 4 * q;
+        const bool cok = c < s.C;
+        const float* base = s.p + (long)n * s.sn + (cok ? c : 0);
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int p = (tid >> 3) + PP * i;
+            const int hy = p / HW, hx = p - hy * HW;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            const bool ok = cok && p < HPX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            ld[i] = *reinterpret_cast<const float4*>(base + (ok ? ((long)y * a.W + x) * s.ld : 0L));
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bn && cok) { sc = *reinterpret_cast<const float4*>(s.bn_scale + c); sh = *reinterpret_cast<const float4*>(s.bn_shift + c); }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int p = (tid >> 3) + PP * i;
+            if (NL * PP > HPX && p >= HPX) continue;
+            const int hy = p / HW, hx = p - hy * HW;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            const bool ok = cok && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            float v[4] = {ld[i].x, ld[i].y, ld[i].z, ld[i].w};
+            if (bn) {      // act(x * scale + shift); the zero padding below applies to the NORMALISED tensor
+                v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+            }
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float t = (ok && c + e < s.C) ? v[e] : 0.f;
+                amax = fmaxf(amax, fabsf(t));
+                t = fabsf(t) > HD_F16_MAX ? copysignf(HD_F16_MAX, t) : t;      // f16 range guard (ConvArgs.sat_flag)
+                hi[e] = (_Float16)t; lo[e] = (_Float16)(t - (float)hi[e]);
+            }
+            _Float16* d = &Xs[(2 * (q >> 1)) * ARR + p * 8 + 4 * (q & 1)];
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + ARR) = lo;
+        }
+        __syncthreads();
+        // ---- 16 x 16 x 32 products: D[cout][pixel] += W[cout][k] X[k][pixel], three products per tap and group ----
+#pragma unroll 7
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+            const h8 wh = *reinterpret_cast<const h8*>(&Wl[tap * 4 * WROW + aoff]);
+            const h8 wlo = *reinterpret_cast<const h8*>(&Wl[tap * 4 * WROW + aoff + HD_KC]);
+            const int toff = (dy * HW + dx) * 8;
+            h8 xh[NG], xl[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) { xh[g] = *reinterpret_cast<const h8*>(&Xs[boff[g] + toff]); xl[g] = *reinterpret_cast<const h8*>(&Xs[boff[g] + toff + ARR]); }
+            // (product-major order: consecutive matrix instructions write different accumulators -- three back-to-back products into one accumulator wait for each other)
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[g], acc[g], 0, 0, 0);      // small terms first
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[g], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[g], acc[g], 0, 0, 0);
+        }
+    }
+    if (a.sat_flag != nullptr && amax > HD_F16_MAX) atomicOr(a.sat_flag, 1u);
+    // ---- epilogue: lanes 0..15 hold rows (= output channels) 0..3 of their pixel column ----
+    if (lane < 16) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int gi = wave * NG + g;
+            const int y = y0 + gi / GPR, x = x0 + (gi % GPR) * 16 + lane;
+            if (y >= a.H || x >= a.W) continue;
+            float* o = a.out + (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld;
+            for (int cc = 0; cc < a.Cout; cc++) {
+                float v = acc[g][cc] * (1.0f / HX_WSCALE) + (a.bias ? a.bias[cc] : 0.f);
+                if (a.act == 1) v = tanhf(v);
+                o[cc] = v;
+            }
+        }
+    }
+}
+}  // namespace
+
+// 1 = handled: forward of a FinalBlock head on the split-f16 matrix pipe (precision == PREC_F16X3 marks the layer as eligible: the context runs exact fp32 otherwise)
+int conv_head_fwd_try(const ConvArgs& a, hipStream_t st) {
+    if (a.precision != PREC_F16X3 || a.wq || a.nsrc != 1 || a.src[0].bcast || a.Cout > 3 || a.Cout < 1 || (a.KS != 3 && a.KS != 7)) return 0;
+    if (a.accumulate || a.res || a.mask || a.pool_out || a.skip_out || a.stats || (a.act != 0 && a.act != 1)) return 0;
+    if (a.src[0].C < 16 || (a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.src[0].C & 3) || (a.Ktot & 3)) return 0;
+    if (a.KS == 7) {
+        const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 16);
+        hipLaunchKernelGGL((k_conv_head<7, 16, 32, 8>), dim3((unsigned)((long)a.N * tx * ty)), dim3(512), 0, st, a, tx, ty);
+    } else {
+        const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 8);
+        hipLaunchKernelGGL((k_conv_head<3, 8, 32, 4>), dim3((unsigned)((long)a.N * tx * ty)), dim3(256), 0, st, a, tx, ty);
+    }
+    g_last_conv_kernel = CK_THIN_OUT;
+    return 1;
+}

@@ -32,6 +32,9 @@ pytestmark = pytest.mark.emu
     dict(N=1, H=16, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1),    # FinalBlock at 64x64 scale: dgrad = 3 -> 128 on k_conv_c4<3,4> x 2 groups
     dict(N=2, H=12, W=40, segs=[(3, 0)], Cout=16, KS=7),                       # 7x7 stem shape on k_conv_c4<7,1>
     dict(N=1, H=9, W=33, segs=[(3, 0)], Cout=40, KS=3, bias=True),             # k_conv_c4<3,2>, two output groups, channel tail
+    dict(N=2, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, precision=16),     # conv_head.hip <7>: ragged 8x16 tiles, tanh
+    dict(N=1, H=17, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1, precision=16),   # conv_head.hip <3>: four 32-channel chunks, ragged 8x32 tiles
+    dict(N=1, H=9, W=20, segs=[(16, 0)], Cout=3, KS=7, act=1, precision=16),                # conv_head.hip <7>: half-filled chunk (reduced model: 16 -> 3)
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)

@@ -22,6 +22,7 @@ SHAPES = [
     ("wgrad", "D up 64->32 @256 x5", 40, 256, 256, 64, 32), ("wgrad", "D res 128->128 @64 x5", 40, 64, 64, 128, 128), ("wgrad", "D res 64->64 @128 x5", 40, 128, 128, 64, 64),
     ("wgrad", "D up 128->64 @128 x5", 40, 128, 128, 128, 64), ("wgrad", "R lstm1 gates 528->1024 @16 x5", 40, 16, 16, 528, 1024), ("wgrad", "R lstm0 gates 272->512 @32 x5", 40, 32, 32, 272, 512),
     ("wgrad", "R lstm2 gates 208->512 @32 x5", 40, 32, 32, 208, 512),
+    ("head7", "D final 32->3 k7 @256", 8, 256, 256, 32, 3), ("head3", "D final 64->3 k3 @128", 8, 128, 128, 64, 3), ("head3", "D final 128->3 k3 @64", 8, 64, 64, 128, 3),
 ]
 
 
@@ -35,12 +36,25 @@ def run(path):
             continue
         ldx = round_up(Cin, 4)
         x = torch.randn(N, H, W, ldx, device="cuda")
-        flops = 2.0 * N * H * W * 9 * Cin * Cout
+        KS = 7 if kind == "head7" else 3
+        flops = 2.0 * N * H * W * KS * KS * Cin * Cout
         d = PackDesc()
         d.nw, d.Co_each, d.Cin, d.KS, d.nseg = 1, Cout, Cin, 3, 1
         d.seg_off[0], d.seg_C[0], d.seg_Cpad[0] = 0, Cin, round_up(Cin, 16)
         d.Cout, d.Cout_pad, d.Ktot = Cout, round_up(Cout, lib.caddy_k_conv_pick_bn(Cout)), round_up(Cin, 16)
-        if kind == "wgrad":
+        if kind.startswith("head"):      # FinalBlock heads: conv_head.hip (precision 16, weights split inside the kernel) + tanh
+            wp = torch.randn(KS * KS * d.Cout_pad * d.Ktot, device="cuda") * 0.05
+            out = torch.zeros(N, H, W, 4, device="cuda")
+            bias = torch.zeros(4, device="cuda")
+            a = ConvArgs()
+            a.src[0] = ConvSrc(x.data_ptr(), H * W * ldx, ldx, Cin, round_up(Cin, 16), 0)
+            a.nsrc, a.N, a.H, a.W, a.KS, a.wp, a.Ktot, a.Cout, a.Cout_pad = 1, N, H, W, KS, wp.data_ptr(), d.Ktot, Cout, d.Cout_pad
+            a.out, a.out_sn, a.out_ld, a.bias, a.act = out.data_ptr(), H * W * 4, 4, bias.data_ptr(), 1
+            a.precision = int(os.environ.get("BENCH_HEAD_PREC", "16"))
+            aux = torch.zeros(128 * 1024 // 4, device="cuda")
+            a.aux = aux.data_ptr()
+            fn = lambda: lib.caddy_k_conv_fwd(C.byref(a), st)
+        elif kind == "wgrad":
             dy = torch.randn(N, H, W, round_up(Cout, 4), device="cuda")
             dwp = torch.zeros(9 * d.Cout_pad * d.Ktot, device="cuda")
             wa = WgradArgs()
