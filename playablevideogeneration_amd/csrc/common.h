@@ -96,8 +96,8 @@ struct ConvArgs {
     // second pass over the conv output.  The launcher reports the number of tiles in g_last_conv_stats_tiles (0: this launch did not produce them).
     float* stats;
     int stats_ld;
-    // Split-f16 forward only: |x| > 65504 does not fit the high half.  The staging clamps such a value to the f16 range (instead of producing inf - inf = NaN in the
-    // low half) and the launch ORs 1 into *sat_flag (nullable): the context reports it with the losses (CADDY_LOSS_F16_SATURATED) / caddy_f16_saturated(), and the
+    // Split-f16 forward only: |x| > 65504 does not fit the high half.  The staging clamps such a value (also an inf or a NaN) to the f16 range (instead of producing
+    // inf - inf = NaN in the low half) and the launch ORs 1 into *sat_flag (nullable): the context reports it with the losses (CADDY_LOSS_F16_SATURATED) / caddy_f16_saturated(), and the
     // caller switches that context to the exact-fp32 forward (caddy_set_precision(0, ...)).  Not reachable with BatchNorm-normalised activations; it is the guard
     // for externally supplied networks and inputs (VGG19 with real weights on un-normalised frames).
     unsigned* sat_flag;

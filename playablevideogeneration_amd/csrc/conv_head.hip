@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
     }
     const bool bn = s.bn_scale != nullptr;                   // lazily applied BatchNorm of the producer (ConvSrc.bn_*)
     const float slope = s.bn_act ? 0.2f : 1.f;
-    float amax = 0.f;
+    unsigned amax = 0u;                                      // largest staged magnitude as a bit pattern (NaN > inf > finite): f16 range guard, see conv_hx.hip
     for (int chunk = 0; chunk < nchunks; chunk++) {
         if (chunk > 0) __syncthreads();                     // every wave is done with the previous chunk's image and weights
         // ---- weights of this chunk: packed fp32 [tap][Cout_pad][Ktot] -> split f16 (x 64: see HX_WSCALE), rows 0..2 + the zero row ----
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float t = (ok && c + e < s.C) ? v[e] : 0.f;
-                amax = fmaxf(amax, fabsf(t));
-                t = fabsf(t) > HD_F16_MAX ? copysignf(HD_F16_MAX, t) : t;      // f16 range guard (ConvArgs.sat_flag)
+                amax = max(amax, __float_as_uint(t) & 0x7fffffffu);
+                t = __builtin_amdgcn_fmed3f(t, -HD_F16_MAX, HD_F16_MAX);      // f16 range guard (ConvArgs.sat_flag)
                 hi[e] = (_Float16)t; lo[e] = (_Float16)(t - (float)hi[e]);
             }
             _Float16* d = &Xs[(2 * (q >> 1)) * ARR + p * 8 + 4 * (q & 1)];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[g], acc[g], 0, 0, 0);
         }
     }
-    if (a.sat_flag != nullptr && amax > HD_F16_MAX) atomicOr(a.sat_flag, 1u);
+    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);
     // ---- epilogue: lanes 0..15 hold rows (= output channels) 0..3 of their pixel column ----
     if (lane < 16) {
 #pragma unroll

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
     float4 ra[NA];
-    float amax = 0.f;                                         // split-f16 only: largest |x| this thread staged (saturation guard, ConvArgs.sat_flag)
+    unsigned amax = 0u;                                       // split-f16 only: largest |x| this thread staged, as a bit pattern -- NaN > inf > finite (saturation guard, ConvArgs.sat_flag)
     float4 rsc, rsh;                                          // lazily applied BatchNorm of the producer (ConvSrc.bn_*): scale / shift of this thread's four channels, chunk in flight
 #define HX_SEG_OF(chunk_)                                                                                                          \
         int s_ = 0, c0_ = (chunk_) * KC;                                                                                          \
@@ -160,10 +160,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 }                                                                                                                  \
                 float x0_ = ok_ ? v_.x : 0.f, x1_ = (ok_ && m1_) ? v_.y : 0.f;                                                     \
                 float x2_ = (ok_ && m2_) ? v_.z : 0.f, x3_ = (ok_ && m3_) ? v_.w : 0.f;                                            \
-                if (!is_bf16<T>::value) {      /* f16 range guard: clamp (a NaN stays a NaN), remember the largest magnitude */    \
-                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x0_), fabsf(x1_))), fmaxf(fabsf(x2_), fabsf(x3_)));                       \
-                    x0_ = fabsf(x0_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x0_) : x0_; x1_ = fabsf(x1_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x1_) : x1_; \
-                    x2_ = fabsf(x2_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x2_) : x2_; x3_ = fabsf(x3_) > HX_F16_MAX ? copysignf(HX_F16_MAX, x3_) : x3_; \
+                if (!is_bf16<T>::value) {      /* f16 range guard: 2.5 VALU per element (an unsigned max of the magnitude bits -- it orders NaN above inf above every */ \
+                    /* finite value -- and one v_med3 clamp; a NaN is clamped too, but it raises the flag) */                     \
+                    amax = max(max(amax, max(__float_as_uint(x0_) & 0x7fffffffu, __float_as_uint(x1_) & 0x7fffffffu)),             \
+                               max(__float_as_uint(x2_) & 0x7fffffffu, __float_as_uint(x3_) & 0x7fffffffu));                       \
+                    x0_ = __builtin_amdgcn_fmed3f(x0_, -HX_F16_MAX, HX_F16_MAX); x1_ = __builtin_amdgcn_fmed3f(x1_, -HX_F16_MAX, HX_F16_MAX); \
+                    x2_ = __builtin_amdgcn_fmed3f(x2_, -HX_F16_MAX, HX_F16_MAX); x3_ = __builtin_amdgcn_fmed3f(x3_, -HX_F16_MAX, HX_F16_MAX); \
                 }                                                                                                                  \
                 v4 hi_, lo_;                                                                                                       \
                 hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         }
     }
 
-    if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > HX_F16_MAX) atomicOr(a.sat_flag, 1u);      // (rare: one atomic per saturating thread)
+    if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);      // (rare: one atomic per saturating thread)
     // ---- epilogue: D fragment map col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile) ----
     float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
 #pragma unroll

@@ -139,6 +139,9 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }      /* v_med3_f32 (a NaN drops out) */
+using std::max;
 #define __expf expf
 #define __logf logf
 static inline float __fdividef(float a, float b) { return a / b; }
