@@ -37,9 +37,6 @@ template <> struct Vec<__bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-#ifndef HX_EXPERIMENT
-#define HX_EXPERIMENT 0      // timing experiments only (tools/gpu_hx_experiments.sh): 1 = no weight-tile traffic in the K loop, 2 = no activation staging, 4 = no per-tap barrier
-#endif
 constexpr int KC = HX_KC;      // channels per chunk
 #define HX_F16_MAX 65504.f
 struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int idx; const float* bn_scale; const float* bn_shift; int bn_act; int bn_gn; long bn_gs; };
@@ -142,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         rsc = *reinterpret_cast<const float4*>(sg_.bn_scale ? sg_.bn_scale + bo_ : sg_.p);                                        \
         rsh = *reinterpret_cast<const float4*>(sg_.bn_scale ? sg_.bn_shift + bo_ : sg_.p);                                        \
     } while (0)
-#define HX_STORE_A(chunk_)                                                                                                         \
+#define HX_STORE_A(chunk_)                                                                                                          \
     do {                                                                                                                           \
         HX_SEG_OF(chunk_)                                                                                                          \
         const bool m1_ = c_ + 1 < sg_.C, m2_ = c_ + 2 < sg_.C, m3_ = c_ + 3 < sg_.C;                                              \
@@ -232,27 +229,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     int bbuf = 0, step = 0;
     for (int chunk = ch0; chunk < ch1; chunk++) {
         __syncthreads();                                      // every wave is done reading As (previous chunk)
-#if !(HX_EXPERIMENT & 2)
         HX_STORE_A(chunk);
-#endif
         // (D = 3: fully unrolled -- hipcc drains vmcnt to 0 at every loop back-edge, which would cut the ring back to depth 1 every third step)
 #pragma unroll
         for (int tap0 = 0; tap0 < 9; tap0 += D) {
 #pragma unroll
             for (int d = 0; d < D; d++, step++) {
                 const int tap = tap0 + d;
-#if !(HX_EXPERIMENT & 1)
                 HX_STORE_B(d, bbuf);
-#endif
-#if !(HX_EXPERIMENT & 4)
                 __syncthreads();
-#endif
-#if !(HX_EXPERIMENT & 1)
                 HX_LOAD_B_STEP(d, step + D);                  // refill the register set just drained
-#endif
-#if !(HX_EXPERIMENT & 2)
                 if (tap == (D == 1 ? 0 : 3)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile: consumed >= 6 steps later (last chunk: re-requested, unused)
-#endif
                 const int toff = (tap / 3) * AROW + (tap % 3) * PITCH;
                 const T* Bt = Bs[bbuf];
 #pragma unroll
@@ -654,12 +641,11 @@ int hx_pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 int g_hx_big_override = -1;      // tests: force (1) / forbid (0) the 8-wave 16x16x128 tile variant regardless of the grid size
 
 // does conv_hx_try run a launch of this geometry on one of the two tile variants that carry the fused max-pool epilogue (EP = 1)?
-// (the same decisions as below, incl. the test / environment overrides)
+// (the same decisions as below, incl. the test override)
 bool conv_hx_pool_ok(int N, int H, int W, int Cout) {
     const int bn = hx_pick_bn(Cout);
     const long wgs = (long)N * cdiv(W, 16) * cdiv(H, 16) * (round_up(Cout, bn) / bn);
-    static const int env_big = getenv("CADDY_HX_BIG") ? atoi(getenv("CADDY_HX_BIG")) : -1;
-    const int force_big = g_hx_big_override >= 0 ? g_hx_big_override : env_big;
+    const int force_big = g_hx_big_override;
     if (bn == 128) return force_big >= 0 ? force_big == 1 : wgs >= 384;
     if (bn == 64) return force_big == 1 || wgs >= 384;
     return false;
@@ -689,13 +675,11 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     // under-filled wide layers (R's gate / SameBlock convolutions on 16x16 .. 32x32 maps, A, D's first stage at batch 8): 64-channel tiles on the same
     // 128-row packed weights -> twice the workgroups, two co-resident per CU hiding each other's barrier / LDS latencies (one 4-wave workgroup per CU
     // runs its serial chain of (tap, chunk) steps at ~30 % of the MFMA rate).  Measured, E/R/A/D step: 79.5 -> 78.2 ms, flat for thresholds 256 / 512 / 1024.
-    static const int env_r64 = getenv("CADDY_HX_R64") ? atoi(getenv("CADDY_HX_R64")) : 256;      // A/B aid: workgroup threshold (0 = off)
-    if (env_r64 > 0 && bn == 128 && g_hx_big_override < 0 && !a.pool_out && !a.skip_out && !a.mask &&
-        (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 8) * (a.Cout_pad / 128) <= env_r64) bn = 64;
+    if (bn == 128 && g_hx_big_override < 0 && !a.pool_out && !a.skip_out && !a.mask &&
+        (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 8) * (a.Cout_pad / 128) <= 256) bn = 64;
     // tiles: 128-channel layers -> 16x16 pixels x 128 channels on 8 waves with the 3-deep weight-tile ring when that fills the chip, else
     // 8x16 pixels on 4 waves (R's small feature maps); 16x16 x 64 / 32 channels for the narrower layers
-    static const int env_big = getenv("CADDY_HX_BIG") ? atoi(getenv("CADDY_HX_BIG")) : -1;      // A/B aid: 0 never, 1 always (128-channel layers)
-    const int force_big = g_hx_big_override >= 0 ? g_hx_big_override : env_big;
+    const int force_big = g_hx_big_override;                   // tests: 0 never, 1 always (128-channel layers)
     bool big = bn == 128 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) >= 384;
     if (force_big >= 0) big = bn == 128 && force_big == 1;
     // narrower layers: 16x16-pixel tiles, or 8x16 when those would leave CUs idle (E / A on one time step's frames, R's side branches)
@@ -732,28 +716,18 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     if (a.stats && (a.splitk != 1 || a.mask || a.pool_out || a.skip_out || a.precision == PREC_F16X1 || a.precision == PREC_BF16X1)) a.stats = nullptr;
     g_last_conv_stats_tiles = a.stats ? (int)((long)a.N * tx * ty) : 0;
     dim3 grid((unsigned)((long)a.N * tx * ty), a.Cout_pad / bn, a.splitk);
-    // launches of at most one workgroup per CU (batch-1 roll-out, R's side branches): every workgroup is a serial chain of (tap, chunk) steps whose
-    // weight tile comes from L2 / HBM; the 3-deep register ring (occupancy does not matter here) takes ~3 % off a roll-out frame
-    // (measured, E/R/A/D step: ring on launches of <= 256 / 512 / 1024 workgroups / always: 77.2 / 75.5 / 75.8 / 75.5 ms -- with one step of prefetch the next weight tile
-    //  has ~0.4 us to arrive from L2, less than its latency under load, in every 4-wave launch)
-    static const int env_deep = getenv("CADDY_HX_DEEP") ? atoi(getenv("CADDY_HX_DEEP")) : 1 << 30;      // A/B aid: workgroup threshold of the 3-deep weight-tile register ring (0 = never)
-    const bool deep = env_deep > 0 && !big && (a.precision == PREC_F16X3 || a.precision == PREC_BF16X3) && blocks * a.splitk <= (env_deep == 1 ? 256 : env_deep);
-#define HX_LAUNCH_DEEP(T_, EP_)                                                                                                   \
-    do {                                                                                                                          \
-        if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 128, 2, 2, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);       \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 64, 2, 2, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, 2, 8, 16, 32, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty); \
-        else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 32, 4, 1, 3, EP_>), grid, dim3(256), 0, st, a, tx, ty);                 \
-    } while (0)
+    // 4-wave variants: 3-deep register ring of weight tiles (with one step of prefetch the next tile has ~0.4 us to arrive from L2, less than its latency under load; measured,
+    // E/R/A/D step: ring on launches of <= 256 / 512 / 1024 workgroups / always: 77.2 / 75.5 / 75.8 / 75.5 ms, batch-1 roll-out frame -3 %).  The single-product study
+    // precisions (PREC_*X1, tools/bench_hx.py) keep one step of prefetch.
 #define HX_LAUNCH(T_, NPL_, EP_)                                                                                                  \
     do {                                                                                                                          \
-        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_>), grid, dim3(512), 0, st, a, tx, ty);         \
-        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);    \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);     \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);  \
-        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, 1, EP_>), grid, dim3(256), 0, st, a, tx, ty);                   \
+        constexpr int D_ = NPL_ == 2 ? 3 : 1;                                                                                     \
+        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_>), grid, dim3(512), 0, st, a, tx, ty);    \
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);    \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty); \
+        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);                  \
     } while (0)
     const bool vgg_bwd = a.mask != nullptr;      // ReLU mask / L1 seed epilogue (VGG19 dgrad chain): split-bf16 instances with EP = 2
     if (a.pool_out || a.skip_out) {      // VGG19 layers in front of a max-pool: the two tile variants those layers run on (perceptual.hip asks only when this holds)
@@ -766,17 +740,15 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     switch (a.precision) {
         case PREC_F16X3:
             if (vgg_bwd) return -1;      // (masks exist on the gradient side only)
-            if (deep) HX_LAUNCH_DEEP(_Float16, 0); else HX_LAUNCH(_Float16, 2, 0);
+            HX_LAUNCH(_Float16, 2, 0);
             break;
         case PREC_BF16X3:
-            if (vgg_bwd) { if (deep) HX_LAUNCH_DEEP(__bf16, 2); else HX_LAUNCH(__bf16, 2, 2); }
-            else { if (deep) HX_LAUNCH_DEEP(__bf16, 0); else HX_LAUNCH(__bf16, 2, 0); }
+            if (vgg_bwd) HX_LAUNCH(__bf16, 2, 2); else HX_LAUNCH(__bf16, 2, 0);
             break;
         case PREC_F16X1: HX_LAUNCH(_Float16, 1, 3); break;
         default: HX_LAUNCH(__bf16, 1, 3); break;
     }
 #undef HX_LAUNCH
-#undef HX_LAUNCH_DEEP
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
     if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
                                                  stats_req, stats_req_ld, stats_cap, det_accum ? 1 : 0);
@@ -786,8 +758,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
 // 1 = handled: 3x3 weight gradient with >= 32 channels on both sides on the 16-bit matrix pipe (split bf16 operands).  Same packed fp32
 // gradient layout (dwp[tap][Cout_pad][Ktot], segments padded to 16) and (group, sample) time-batched addressing as k_conv_wgrad_tile.
 static bool wgrad_hx_applies(const WgradArgs& a) {
-    static const bool off = getenv("CADDY_WGRAD_HX") && atoi(getenv("CADDY_WGRAD_HX")) == 0;      // A/B aid
-    if (off || a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return false;
+    if (a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return false;
     for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return false;
     if ((a.dy_ld & 3) || (a.dy_sn & 3)) return false;
     return true;
@@ -803,15 +774,12 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     // Register bound 2 (256 per lane) with still ONE persistent workgroup per CU: the side stream's workgroup then leaves half of every SIMD's register file
     // to the BPTT chain on the main stream, which shares the CU with it (measured, E/R/A/D step: unbounded 89.0 ms; bound 2 with 256 / 384 / 512 workgroups
     // 85.6 / 87.2 / 89.6 ms; serialised streams 94.5 -> 91.6 ms)
-    static const int occ = getenv("CADDY_WGRAD_OCC") ? atoi(getenv("CADDY_WGRAD_OCC")) : 2;      // A/B aid
-    static const int blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;
-    long g = blocks / ((long)kt * ot);
+    long g = 256 / ((long)kt * ot);
     if (g < 1) g = 1;
     if (g > ntiles) g = ntiles;
     WgradArgs b = a;
     if (b.det_slab) { g = wgrad_det_begin(b, g, st); if (g <= 0) return -1; }
-    if (occ == 2) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
-    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 1>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
     if (b.det_slab) wgrad_det_end(b, g, st);
     return 1;
 }

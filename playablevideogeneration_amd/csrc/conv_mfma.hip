@@ -896,7 +896,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
         int kt = cdiv(a.Ktot, WT_KC);
         bool o32 = a.Cout <= 32;
         int ot = o32 ? 1 : cdiv(a.Cout, 64);
-        static const int tile_blocks = getenv("CADDY_WGRAD_BLOCKS") ? atoi(getenv("CADDY_WGRAD_BLOCKS")) : 256;   // one persistent workgroup per CU: measured best inside the training step (the BPTT chain shares the chip)
+        const int tile_blocks = 256;   // one persistent workgroup per CU: measured best inside the training step (the BPTT chain shares the chip)
         long g = tile_blocks / ((long)kt * ot);
         if (g < 1) g = 1;
         if (g > ntiles) g = ntiles;
