@@ -1,5 +1,5 @@
 """Latency of the under-filled (batch-1 roll-out) convolutions: back-to-back launches of one shape through caddy_k_conv_fwd.
-   python tools/bench_tiny.py        (CADDY_HX_DEEP=0 etc. as A/B)"""
+   python tools/bench_tiny.py        (A/B: a second library through CADDY_HIP_LIB)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

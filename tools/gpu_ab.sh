@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one environment switch on the E/R/A/D-only step:  bash tools/gpu_ab.sh VAR a b [tests]
+# A/B of one environment variable (e.g. CADDY_HIP_LIB=<baseline .so> against the in-tree library, CADDY_STREAMS, CADDY_PRECISION) on the E/R/A/D-only step:  bash tools/gpu_ab.sh VAR a b [tests]
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 B="python bench.py --no-perceptual --no-cpu-baseline --no-rollout --no-extra-legs --profile-steps 0 --steps 10 --warmup 3"
