@@ -376,8 +376,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int WG_TH = 4, WG_TW = 16, WG_KC = 64, WG_OC = 64;
 constexpr int WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
 constexpr int WG_PITCH = 2 * 64 + 32;                       // 16-bit elements per pixel row: hi 64 | lo 64 | pad
-constexpr int WG_XLOADS = (WG_HH * WG_HW * 16 + 255) / 256; // float4 per thread for the X halo (16 float4 per pixel)
-constexpr int WG_YLOADS = WG_TH * WG_TW * 16 / 256;
 
 __device__ __forceinline__ SegRefH find_seg16(const ConvSrc* src, int nsrc, int k) {
     int s = 0;
@@ -398,7 +396,9 @@ __device__ __forceinline__ typename Vec<T>::v8 tr_frag(const T* base, int off0, 
 
 // OCC: workgroups per CU the register allocation is bounded for (2: 256 registers per lane -- 144 accumulators + everything else, ~2 spilled -- so that the
 // LDS-store / barrier phase of one workgroup runs under the MFMA phase of the other; 1: the unconstrained allocation, one workgroup per CU)
-template <typename T, int OCC>
+// RSPLIT (layers of <= 32 output channels, round 4): the two wave rows split the tile's PIXEL rows instead of the output channels -- with the 64-channel block half empty
+// the wm = 1 waves multiplied zeros (D's last UpBlock conv 64 -> 32 @256x256, the largest weight gradient of the step); their partial sums meet in the final atomics.
+template <typename T, int OCC, bool RSPLIT>
 __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -407,92 +407,115 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int k0 = blockIdx.x * WG_KC, o0 = blockIdx.y * WG_OC;
-    const long ntiles = (long)a.N * tiles_x * tiles_y;
+    const int ntiles = a.N * tiles_x * tiles_y;               // (< 2^31: the launcher checks)
 
-    // loader roles: float4 column q (0..15) fixed per thread; X halo pixel = (tid >> 4) + 16 i, dY pixel = (tid >> 4) + 16 i
-    const int q = tid & 15;
+    // loader roles (round 4: one halo ROW per pass -- row validity and row offset are scalars, the column part of the address is computed once per tile; the former
+    // pixel = (tid >> 4) + 16 i map cost ~1000 instructions per tile in divisions, 64-bit offset products and branches around every load, against 108 MFMAs per wave):
+    // float4 column q (0..15) fixed per thread; p0 = tid >> 4.  X halo: passes 0..5 -> pixel (row i, column p0), pass 6 -> the two right-most columns (16, 17) of row p0 >> 1
+    // (p0 < 12).  dY: pass i -> pixel (row i, column p0).
+    const int q = tid & 15, p0 = tid >> 4;
     const int kx = k0 + (q >> 2) * CONV_BK;
     const bool kok = kx < a.Ktot;
     const SegRefH sg = find_seg16(a.src, a.nsrc, kok ? kx : 0);
     const int cx = sg.c0 + (q & 3) * 4;                       // channel inside the segment
     const int yc = o0 + q * 4;
-    float4 rx[WG_XLOADS], ry[WG_YLOADS];
-    float4 rxs, rxh;                                          // lazily applied BatchNorm of the X source (ConvSrc.bn_*): scale / shift of this thread's four channels, tile in flight
+    const bool cok = kok && cx < sg.C, yok = yc < a.Cout;
+    const bool xm1 = cx + 1 < sg.C, xm2 = cx + 2 < sg.C, xm3 = cx + 3 < sg.C;
+    const bool ym1 = yc + 1 < a.Cout, ym2 = yc + 2 < a.Cout, ym3 = yc + 3 < a.Cout;
+    const int hy6 = p0 >> 1, hx6 = WG_TW + (p0 & 1);          // pass 6
+    const int xl = p0 * WG_PITCH + 4 * q, xl6 = (hy6 * WG_HW + hx6) * WG_PITCH + 4 * q;      // LDS element offsets (pass i: + i * WG_HW * WG_PITCH; dY: + i * WG_TW * WG_PITCH)
+    static_assert(WG_TW == 16 && WG_HW == 18 && 2 * WG_HH <= 16, "loader passes: 16 columns per row pass, the two right-most columns of all rows in one more");
+    // tile-invariant address parts (32-bit element offsets inside one sample: H * W * ld < 2^31)
+    const int xpl = sg.bcast ? 0 : sg.ld, xrow = a.W * xpl, yrow = a.W * a.dy_ld;
+    const long sgs = a.group_n > 0 ? a.src_gs[sg.idx] : 0L, sbgs = a.group_n > 0 ? a.src_bn_gs[sg.idx] : 0L;
+    const float inv_bn_gn = sg.bn_gn > 0 ? 1.f / (float)sg.bn_gn : 0.f;      // (n / bn_gn for n < 2^20: floor((n + 0.5) * inv))
     const bool xbn = sg.bn_scale != nullptr;
     const float xsl = sg.bn_act ? 0.2f : 1.f;
+    float4 rx[WG_HH + 1], ry[WG_TH];
+    float4 rxs, rxh;                                          // lazily applied BatchNorm of the X source (ConvSrc.bn_*): scale / shift of this thread's four channels, tile in flight
+    int fy0 = 0, fx0 = 0;                                     // origin of the tile in flight (set by WG_LOAD, consumed by WG_STORE one iteration later)
 
-#define WG_GEOM(tile_)                                                                                                              \
-        int n_ = (int)((tile_) / (tiles_x * tiles_y));                                                                             \
-        const int rem_ = (int)((tile_) - (long)n_ * tiles_x * tiles_y);                                                            \
-        const int ty_ = rem_ / tiles_x;                                                                                            \
-        const int y0_ = ty_ * WG_TH, x0_ = (rem_ - ty_ * tiles_x) * WG_TW;                                                         \
-        const bool cok_ = kok && cx < sg.C;                                                                                        \
-        const bool yok_ = yc < a.Cout;
     // loads only (clamped addresses): the zero-padding / tail selects are applied by WG_STORE one tile later, so that nothing waits for these
     // loads while the current tile's MFMAs run
 #define WG_LOAD(tile_)                                                                                                              \
     do {                                                                                                                            \
-        WG_GEOM(tile_)                                                                                                              \
+        int n_ = (tile_) / (tiles_x * tiles_y);                                                                                    \
+        const int rem_ = (tile_) - n_ * tiles_x * tiles_y;                                                                         \
+        const int ty_ = rem_ / tiles_x;                                                                                            \
+        fy0 = ty_ * WG_TH; fx0 = (rem_ - ty_ * tiles_x) * WG_TW;                                                                   \
+        const int xc_ = fx0 - 1 + p0, yx_ = fx0 + p0;           /* this thread's halo / tile column */                            \
+        const bool xv_ = cok && xc_ >= 0 && xc_ < a.W, yv_ = yok && yx_ < a.W;                                                     \
+        const int y6_ = fy0 - 1 + hy6, x6_ = fx0 - 1 + hx6;                                                                        \
+        const bool v6_ = cok && p0 < 2 * WG_HH && y6_ >= 0 && y6_ < a.H && x6_ < a.W;                                              \
         const float* xp_ = sg.p;                                                                                                   \
         const float* dyb_ = a.dy;                                                                                                  \
-        long bo_ = cok_ ? cx : 0;                                                                                                  \
-        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * a.src_gs[sg.idx]; dyb_ += grp_ * a.dy_gs; bo_ += grp_ * a.src_bn_gs[sg.idx]; } \
-        if (sg.bn_gn > 0) bo_ += (long)(n_ / sg.bn_gn) * sg.bn_gs;                                                                 \
+        long bo_ = cok ? cx : 0;                                                                                                   \
+        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * sgs; dyb_ += grp_ * a.dy_gs; bo_ += grp_ * sbgs; } \
+        bo_ += (long)(int)(((float)n_ + 0.5f) * inv_bn_gn) * sg.bn_gs;                                                             \
         rxs = *reinterpret_cast<const float4*>(xbn ? sg.bn_scale + bo_ : sg.p);      /* (clamped to a valid address without BatchNorm) */ \
         rxh = *reinterpret_cast<const float4*>(xbn ? sg.bn_shift + bo_ : sg.p);                                                    \
-        const float* xb_ = xp_ + (long)n_ * sg.sn + (cok_ ? cx : 0);                                                               \
-        const int pl_ = sg.bcast ? 0 : sg.ld;                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
-            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
-            const int hy_ = pix_ / WG_HW, hx_ = pix_ - hy_ * WG_HW;                                                                \
-            const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
-            const bool ok_ = cok_ && hy_ < WG_HH && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                    \
-            rx[i] = *reinterpret_cast<const float4*>(xb_ + (ok_ ? ((long)y_ * a.W + x_) * pl_ : 0L));                              \
+        const float* xb_ = xp_ + (long)n_ * sg.sn + (cok ? cx : 0);                                                                \
+        const int xo_ = (fy0 - 1) * xrow + (xv_ ? xc_ * xpl : 0);                                                                   \
+        _Pragma("unroll") for (int i = 0; i < WG_HH; i++) {                                                                        \
+            const int y_ = fy0 - 1 + i;                             /* scalar */                                                   \
+            rx[i] = *reinterpret_cast<const float4*>(xb_ + (unsigned)((y_ >= 0 && y_ < a.H) ? xo_ + i * xrow : 0));               \
         }                                                                                                                          \
-        const float* yb_ = dyb_ + (long)n_ * a.dy_sn + (yok_ ? yc : 0);                                                            \
-        _Pragma("unroll") for (int i = 0; i < WG_YLOADS; i++) {                                                                    \
-            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
-            const int y_ = y0_ + pix_ / WG_TW, x_ = x0_ + (pix_ & (WG_TW - 1));                                                    \
-            const bool ok_ = yok_ && y_ < a.H && x_ < a.W;                                                                         \
-            ry[i] = *reinterpret_cast<const float4*>(yb_ + (ok_ ? ((long)y_ * a.W + x_) * a.dy_ld : 0L));                          \
-        }                                                                                                                          \
+        rx[WG_HH] = *reinterpret_cast<const float4*>(xb_ + (unsigned)(v6_ ? y6_ * xrow + x6_ * xpl : 0));                         \
+        const float* yb_ = dyb_ + (long)n_ * a.dy_sn;               /* scalar */                                                   \
+        const int yo_ = fy0 * yrow + (yok ? yc : 0) + (yv_ ? yx_ * a.dy_ld : 0);                                                   \
+        _Pragma("unroll") for (int i = 0; i < WG_TH; i++)                                                                          \
+            ry[i] = *reinterpret_cast<const float4*>(yb_ + (unsigned)(fy0 + i < a.H ? yo_ + i * yrow : (yok ? yc : 0)));           \
     } while (0)
+    // value -> (hi, lo) halves of four channels, stored at dst_ / dst_ + 64.  bf16: one packed conversion per pair, the high halves re-expanded by shift / mask (16 VALU
+    // per float4 incl. the four selects; the generic form converts every high half twice)
 #define WG_SPLIT_STORE(dst_, v_)                                                                                                   \
     do {                                                                                                                            \
         v4 hi_, lo_;                                                                                                                \
-        hi_[0] = (T)(v_).x; hi_[1] = (T)(v_).y; hi_[2] = (T)(v_).z; hi_[3] = (T)(v_).w;                                            \
-        lo_[0] = (T)((v_).x - (float)hi_[0]); lo_[1] = (T)((v_).y - (float)hi_[1]);                                                \
-        lo_[2] = (T)((v_).z - (float)hi_[2]); lo_[3] = (T)((v_).w - (float)hi_[3]);                                                \
+        if (is_bf16<T>::value) {                                                                                                    \
+            typedef T t2_ __attribute__((ext_vector_type(2)));                                                                      \
+            t2_ h01_, h23_; h01_[0] = (T)(v_).x; h01_[1] = (T)(v_).y; h23_[0] = (T)(v_).z; h23_[1] = (T)(v_).w;                     \
+            const unsigned u01_ = __builtin_bit_cast(unsigned, h01_), u23_ = __builtin_bit_cast(unsigned, h23_);                   \
+            t2_ l01_, l23_;                                                                                                         \
+            l01_[0] = (T)((v_).x - __builtin_bit_cast(float, u01_ << 16)); l01_[1] = (T)((v_).y - __builtin_bit_cast(float, u01_ & 0xffff0000u)); \
+            l23_[0] = (T)((v_).z - __builtin_bit_cast(float, u23_ << 16)); l23_[1] = (T)((v_).w - __builtin_bit_cast(float, u23_ & 0xffff0000u)); \
+            hi_[0] = h01_[0]; hi_[1] = h01_[1]; hi_[2] = h23_[0]; hi_[3] = h23_[1];                                                 \
+            lo_[0] = l01_[0]; lo_[1] = l01_[1]; lo_[2] = l23_[0]; lo_[3] = l23_[1];                                                 \
+        } else {                                                                                                                    \
+            hi_[0] = (T)(v_).x; hi_[1] = (T)(v_).y; hi_[2] = (T)(v_).z; hi_[3] = (T)(v_).w;                                        \
+            lo_[0] = (T)((v_).x - (float)hi_[0]); lo_[1] = (T)((v_).y - (float)hi_[1]);                                            \
+            lo_[2] = (T)((v_).z - (float)hi_[2]); lo_[3] = (T)((v_).w - (float)hi_[3]);                                            \
+        }                                                                                                                          \
         *reinterpret_cast<v4*>(dst_) = hi_;                                                                                        \
         *reinterpret_cast<v4*>((dst_) + 64) = lo_;                                                                                 \
     } while (0)
-#define WG_STORE(tile_)                                                                                                             \
+#define WG_X_ELEM(i_, ok_, dst_)                                                                                                   \
     do {                                                                                                                            \
-        WG_GEOM(tile_)                                                                                                              \
-        (void)n_;                                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < WG_XLOADS; i++) {                                                                    \
-            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
-            const int hy_ = pix_ / WG_HW, hx_ = pix_ - hy_ * WG_HW;                                                                \
-            const int y_ = y0_ - 1 + hy_, x_ = x0_ - 1 + hx_;                                                                      \
-            const bool ok_ = cok_ && y_ >= 0 && y_ < a.H && x_ >= 0 && x_ < a.W;                                                   \
-            float4 v_ = rx[i];                                                                                                     \
-            if (xbn) {      /* act(x * scale + shift): what the forward conv consumed; zero padding applies to the normalised tensor */ \
-                v_.x = fmaf(v_.x, rxs.x, rxh.x); v_.y = fmaf(v_.y, rxs.y, rxh.y); v_.z = fmaf(v_.z, rxs.z, rxh.z); v_.w = fmaf(v_.w, rxs.w, rxh.w); \
-                v_.x = v_.x > 0.f ? v_.x : xsl * v_.x; v_.y = v_.y > 0.f ? v_.y : xsl * v_.y;                                      \
-                v_.z = v_.z > 0.f ? v_.z : xsl * v_.z; v_.w = v_.w > 0.f ? v_.w : xsl * v_.w;                                      \
-            }                                                                                                                      \
-            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && cx + 1 < sg.C) ? v_.y : 0.f;                                                   \
-            v_.z = (ok_ && cx + 2 < sg.C) ? v_.z : 0.f; v_.w = (ok_ && cx + 3 < sg.C) ? v_.w : 0.f;                                \
-            if (pix_ < WG_HH * WG_HW) WG_SPLIT_STORE(&Xh[pix_ * WG_PITCH + 4 * q], v_);                                           \
+        float4 v_ = rx[i_];                                                                                                        \
+        if (xbn) {      /* act(x * scale + shift): what the forward conv consumed; zero padding applies to the normalised tensor */ \
+            v_.x = fmaf(v_.x, rxs.x, rxh.x); v_.y = fmaf(v_.y, rxs.y, rxh.y); v_.z = fmaf(v_.z, rxs.z, rxh.z); v_.w = fmaf(v_.w, rxs.w, rxh.w); \
+            v_.x = v_.x > 0.f ? v_.x : xsl * v_.x; v_.y = v_.y > 0.f ? v_.y : xsl * v_.y;                                          \
+            v_.z = v_.z > 0.f ? v_.z : xsl * v_.z; v_.w = v_.w > 0.f ? v_.w : xsl * v_.w;                                          \
         }                                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < WG_YLOADS; i++) {                                                                    \
-            const int pix_ = (tid >> 4) + 16 * i;                                                                                  \
-            const int y_ = y0_ + pix_ / WG_TW, x_ = x0_ + (pix_ & (WG_TW - 1));                                                    \
-            const bool ok_ = yok_ && y_ < a.H && x_ < a.W;                                                                         \
+        v_.x = (ok_) ? v_.x : 0.f; v_.y = ((ok_) && xm1) ? v_.y : 0.f; v_.z = ((ok_) && xm2) ? v_.z : 0.f; v_.w = ((ok_) && xm3) ? v_.w : 0.f; \
+        WG_SPLIT_STORE(dst_, v_);                                                                                                  \
+    } while (0)
+#define WG_STORE()                                                                                                                  \
+    do {                                                                                                                            \
+        const int xc_ = fx0 - 1 + p0, yx_ = fx0 + p0;                                                                              \
+        const bool xv_ = cok && xc_ >= 0 && xc_ < a.W, yv_ = yok && yx_ < a.W;                                                     \
+        const int y6_ = fy0 - 1 + hy6, x6_ = fx0 - 1 + hx6;                                                                        \
+        const bool v6_ = cok && y6_ >= 0 && y6_ < a.H && x6_ < a.W;                                                                \
+        _Pragma("unroll") for (int i = 0; i < WG_HH; i++) {                                                                        \
+            const int y_ = fy0 - 1 + i;                                                                                            \
+            const bool ok_ = xv_ && y_ >= 0 && y_ < a.H;                                                                           \
+            WG_X_ELEM(i, ok_, &Xh[xl + i * (WG_HW * WG_PITCH)]);                                                                   \
+        }                                                                                                                          \
+        if (p0 < 2 * WG_HH) WG_X_ELEM(WG_HH, v6_, &Xh[xl6]);                                                                       \
+        _Pragma("unroll") for (int i = 0; i < WG_TH; i++) {                                                                        \
+            const bool ok_ = yv_ && fy0 + i < a.H;                                                                                 \
             float4 v_ = ry[i];                                                                                                     \
-            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && yc + 1 < a.Cout) ? v_.y : 0.f;                                                 \
-            v_.z = (ok_ && yc + 2 < a.Cout) ? v_.z : 0.f; v_.w = (ok_ && yc + 3 < a.Cout) ? v_.w : 0.f;                            \
-            WG_SPLIT_STORE(&Yt[pix_ * WG_PITCH + 4 * q], v_);                                                                     \
+            v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && ym1) ? v_.y : 0.f; v_.z = (ok_ && ym2) ? v_.z : 0.f; v_.w = (ok_ && ym3) ? v_.w : 0.f; \
+            WG_SPLIT_STORE(&Yt[xl + i * (WG_TW * WG_PITCH)], v_);                                                                  \
         }                                                                                                                          \
     } while (0)
 
@@ -505,17 +528,17 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
     // tr-read lane roles: group g = (lane >> 4) & 1 -> channel half; lane & 15 -> (pixel row (lane & 15) >> 2, column quad lane & 3); lane >> 5 -> pixel octet
     const int prow = (lane >> 5) * 8 + ((lane & 15) >> 2);            // + 4 rr
     const int ccol = ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
-    const int yoff = prow * WG_PITCH + wm * 32 + ccol;
+    const int yoff = prow * WG_PITCH + (RSPLIT ? 0 : wm * 32) + ccol;
     const int xoff = prow * WG_PITCH + wn * 32 + ccol;
 
-    long tile = blockIdx.z;
+    int tile = (int)blockIdx.z;
     if (tile < ntiles) WG_LOAD(tile);
-    for (; tile < ntiles; tile += gridDim.z) {
-        WG_STORE(tile);
+    for (; tile < ntiles; tile += (int)gridDim.z) {
+        WG_STORE();
         __syncthreads();
-        if (tile + gridDim.z < ntiles) WG_LOAD(tile + gridDim.z);
+        if (tile + (int)gridDim.z < ntiles) WG_LOAD(tile + (int)gridDim.z);
 #pragma unroll 1
-        for (int r = 0; r < WG_TH; r++) {
+        for (int r = RSPLIT ? wm * (WG_TH / 2) : 0; r < (RSPLIT ? (wm + 1) * (WG_TH / 2) : WG_TH); r++) {
             const T* yb = Yt + r * WG_TW * WG_PITCH + yoff;
             const v8 ah = tr_frag<T>(yb, 0, 4 * WG_PITCH), al = tr_frag<T>(yb, 64, 4 * WG_PITCH + 64);
 #pragma unroll
@@ -533,10 +556,10 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
         }
         __syncthreads();
     }
-#undef WG_GEOM
 #undef WG_LOAD
 #undef WG_STORE
 #undef WG_SPLIT_STORE
+#undef WG_X_ELEM
 
     const int k = k0 + wn * 32 + (lane & 31);
     if (k < a.Ktot) {
@@ -544,7 +567,7 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
         for (int t = 0; t < 9; t++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int o = o0 + (RSPLIT ? 0 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (o < a.Cout) atomicAdd(WGRAD_DST(a, blockIdx.z) + ((long)t * a.Cout_pad + o) * a.Ktot + k, acc[t][r]);
             }
         }
@@ -770,6 +793,7 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     if (dry) return 1;
     const int tx = cdiv(a.W, WG_TW), ty = cdiv(a.H, WG_TH);
     const long ntiles = (long)a.N * tx * ty;
+    if (ntiles >= (1L << 30)) return 0;
     const int kt = cdiv(a.Ktot, WG_KC), ot = cdiv(a.Cout, WG_OC);
     // Register bound 2 (256 per lane) with still ONE persistent workgroup per CU: the side stream's workgroup then leaves half of every SIMD's register file
     // to the BPTT chain on the main stream, which shares the CU with it (measured, E/R/A/D step: unbounded 89.0 ms; bound 2 with 256 / 384 / 512 workgroups
@@ -779,7 +803,8 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     if (g > ntiles) g = ntiles;
     WgradArgs b = a;
     if (b.det_slab) { g = wgrad_det_begin(b, g, st); if (g <= 0) return -1; }
-    hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    if (a.Cout <= 32) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, true>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, false>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
     if (b.det_slab) wgrad_det_end(b, g, st);
     return 1;
 }

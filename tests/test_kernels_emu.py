@@ -153,3 +153,6 @@ def test_wgrad_hx_split_bf16_small():
     """k_wgrad_hx on the simulator (ds_read_b64_tr_b16 transposing fragment reads): ragged tiles, three segments incl. a broadcast vector,
     output-channel tail; the forward / dgrad of the same case run on the exact kernels"""
     K.conv_case(load_emu(), "cpu", N=2, H=13, W=10, segs=[(64, 0), (9, 1), (40, 0)], Cout=72, KS=3, wgrad_precision=17, wgrad_tol=1e-4)
+    # <= 32 output channels: the two wave rows split the tile's pixel rows (round 4); ragged rows (H = 6, 7: the second half-tile partly / wholly outside)
+    K.conv_case(load_emu(), "cpu", N=2, H=7, W=18, segs=[(40, 0)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4)
+    K.conv_case(load_emu(), "cpu", N=1, H=6, W=16, segs=[(64, 0), (5, 1)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=3)

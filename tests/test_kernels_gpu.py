@@ -174,6 +174,7 @@ def test_conv_hx_dgrad(lib, kw):
     dict(N=2, H=64, W=64, segs=[(128, 0)], Cout=128, KS=3),                                         # D residual block
     dict(N=2, H=128, W=128, segs=[(64, 0)], Cout=32, KS=3),                                         # D last UpBlock conv
     dict(N=2, H=40, W=52, segs=[(33, 0)], Cout=65, KS=3),                                           # channel tails
+    dict(N=3, H=38, W=52, segs=[(32, 0)], Cout=32, KS=3),                                           # 32 -> 32 (row-split waves), ragged
 ])
 def test_wgrad_hx(lib, kw):
     K.conv_case(lib, "cuda", wgrad_precision=17, wgrad_tol=1e-4, **kw)
