@@ -510,7 +510,7 @@ def property_case(lib, dev, c, seed=3, perceptual=False):
     return eng
 
 
-def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False):
+def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False, reps=3):
     """caddy_set_deterministic: two backward passes over the same forward give BIT-IDENTICAL flat gradients (slabs + fixed-order reduces instead of fp32
     atomics in arrival order); the backward is then exactly linear in the loss weights for a power-of-two factor; and the deterministic gradient agrees with the default
     (atomic) one up to its run-to-run noise.  Returns the measured distances."""
@@ -533,10 +533,10 @@ def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False):
     g_atomic = eng.grads.clone()
     eng.set_deterministic(True)
     gs = []
-    for _ in range(3):
+    for _ in range(reps):
         eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
         gs.append(eng.grads.clone())
-    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2]), ("deterministic backward not bit-reproducible", rel(gs[1], gs[0]), rel(gs[2], gs[0]))
+    assert all(torch.equal(gs[0], g_) for g_ in gs[1:]), ("deterministic backward not bit-reproducible", [rel(g_, gs[0]) for g_ in gs[1:]])
     assert torch.isfinite(gs[0]).all() and gs[0].abs().max().item() > 0
     eng.loss_backward({k: 2 * v for k, v in w1.items() if k != "mi_entropy"}, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
     lin = rel(eng.grads, 2 * gs[0])
