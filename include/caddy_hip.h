@@ -251,6 +251,7 @@ long caddy_bn_calls(caddy_ctx* ctx, int i, char* name_out128);
 struct ConvArgs; struct WgradArgs; struct PackDesc; struct TV;
 int caddy_k_conv_fwd(const struct ConvArgs* a, void* stream);
 int caddy_k_conv_wgrad(const struct WgradArgs* a, void* stream);
+int caddy_k_conv_took_direct(void);      /* 1: this thread's last caddy_k_conv_fwd ran on the latency kernel (ConvArgs.direct_ok; model/main_model/model.py:570-607 batch-1 roll-out layers) */
 /* BatchNorm fused with the convolutions around it (reference: the conv -> BatchNorm2d -> LeakyReLU chains of model/layers/residual_block.py:51-68,
  * same_block.py:34-47, up_block.py:31-45): per-tile partial sums from the producing conv's epilogue (ConvArgs.stats) -> finalisation without a pass over
  * the tensor; backward of a BatchNorm whose output was never materialised (ConvSrc.bn_scale / bn_shift applied by the consumer while staging) */

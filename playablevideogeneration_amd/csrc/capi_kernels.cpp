@@ -7,6 +7,7 @@
 #define ST(s) ((hipStream_t)(s))
 extern "C" {
 int caddy_k_conv_fwd(const ConvArgs* a, void* s) { return conv_fwd_launch(*a, ST(s)); }
+int caddy_k_conv_took_direct(void) { return g_last_conv_direct; }      // 1: the last caddy_k_conv_fwd of this thread ran on the latency kernel (conv_direct.hip)
 int caddy_k_conv_stats_tiles(void) { return g_last_conv_stats_tiles; }      // pixel tiles whose BatchNorm partial sums the last caddy_k_conv_fwd of this thread wrote (ConvArgs.stats)
 int caddy_k_bn_finalize_tiles(const float* part, int ntiles, int ldp, long count, const float* gamma, const float* beta, float* rmean, float* rvar, int C,
                               float* mean, float* invstd, float* scale, float* shift, void* s) {

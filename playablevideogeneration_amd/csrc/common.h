@@ -104,6 +104,9 @@ struct ConvArgs {
     // Bit-reproducible mode (caddy_set_deterministic): the split-K of an under-filled ACCUMULATING launch (dgrad +=) goes through slabs of split_scratch and the
     // fixed-order reduce (which then adds the previous contents of `out`) instead of fp32 atomics in arrival order
     int deterministic;
+    // Small assigning split-f16 launches may run on the latency kernel (conv_direct.hip: one launch, no slabs) instead of the tile kernel's split-K launch + slab reduce.
+    // The driver sets it on every forward convolution; kernel tests choose the path explicitly.
+    int direct_ok;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
@@ -156,7 +159,8 @@ enum { CK_FWD_128x128 = 0, CK_FWD_128x64, CK_FWD_64x64, CK_FWD_128x32, CK_THIN_O
 extern thread_local int g_last_conv_kernel;
 // rows a caller must provide in ConvArgs.stats: the smallest pixel tile (8 x 16) of the epilogue path, at least the 512 workgroups of the slab-reduce path
 static inline long conv_stats_tiles_cap(int N, int H, int W) { long t = (long)N * cdiv(H, 8) * cdiv(W, 16); return t > 512 ? t : 512; }
-extern thread_local int g_last_conv_stats_tiles;      // pixel tiles of the last conv_fwd_launch that wrote ConvArgs.stats (0 = none written)
+extern thread_local int g_last_conv_stats_tiles;
+extern thread_local int g_last_conv_direct;      // pixel tiles of the last conv_fwd_launch that wrote ConvArgs.stats (0 = none written)
 bool conv_src_lazy_ok(const ConvArgs& a);             // will conv_fwd_launch run this launch on a kernel that applies ConvSrc.bn_* ?
 bool wgrad_src_lazy_ok(const WgradArgs& a);           // ... conv_wgrad_launch ?
 int conv_fwd_launch(const ConvArgs& a, hipStream_t st);
@@ -175,6 +179,7 @@ int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc,
                              const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
+int conv_direct_try(const ConvArgs& a, hipStream_t st);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA

@@ -1,0 +1,142 @@
+// Latency-bound 3x3 convolutions (batch-1 roll-out: model/main_model/model.py:570-607 -- E's residual blocks on a 32x32 map, R's small side branches, the 32-channel stages):
+// one launch of a few hundred workgroups instead of the tile kernel's split-K launch + slab reduce.
+//
+// Why: such a launch is ~75 MFLOP; on k_conv_hx it is a chain of prologue -> 9..18 (tap, chunk) steps with a barrier each -> slab store, followed by k_split_reduce: 14.7 + 5 us
+// per layer whatever the arithmetic (profiles/r04_rollout_kernels.txt: 18 + 17 of a frame's 66 launches).  Here a workgroup owns ONE 16-pixel x 16-channel output tile and its
+// four waves split the K steps; every operand fragment goes from global memory / L2 straight into registers (no LDS staging, no barrier inside the loop, all loads of a wave
+// in flight at once), the four partial tiles meet in LDS in a fixed order, and the epilogue (bias, residual, LeakyReLU / ReLU) is applied in place -- no slabs, no reduce launch.
+// Arithmetic = conv_hx.hip's: v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo, three products per fp32 product), weights from the same packed split-f16 buffer
+// ([tap][chunk][Cout_pad][hi 32 | lo 32]: a row's 16-byte pieces ARE the A fragments), activations converted in registers.
+//
+// It only pays where the activations are small enough to be re-read by every 16-channel block (no reuse through LDS): the launcher takes launches of
+// <= DIRECT_MAX_WORK workgroup-steps and leaves everything else to k_conv_hx.
+#include "common.h"
+
+namespace {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int DK = HX_KC;                                    // channels per K step (one instruction)
+constexpr int DIRECT_MAX_CHUNKS = 64;
+#define DR_F16_MAX 65504.f
+
+struct ChunkRef { const float* base; int pl; int C; int c0; };      // source of one 32-channel chunk: sample base pointer, pixel pitch (0: broadcast vector), channels, first channel
+
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo, unsigned& amax) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        amax = max(amax, __float_as_uint(v[e]) & 0x7fffffffu);
+        const float t = __builtin_amdgcn_fmed3f(v[e], -DR_F16_MAX, DR_F16_MAX);      // f16 range guard (ConvArgs.sat_flag, see conv_hx.hip)
+        hi[e] = (_Float16)t; lo[e] = (_Float16)(t - (float)hi[e]);
+    }
+}
+
+// grid: x = 16-pixel groups (sample, row, column group), y = 16-channel output blocks.  NW waves split the K steps; U steps of a wave are in flight together.
+template <int NW, int U>
+__global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_x) {
+    __shared__ ChunkRef tab[DIRECT_MAX_CHUNKS];
+    __shared__ __attribute__((aligned(16))) float red[NW * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int g = blockIdx.x;
+    const int n = g / (groups_x * a.H);
+    g -= n * groups_x * a.H;
+    const int y = g / groups_x, x0 = (g - y * groups_x) * 16;
+    const int co0 = blockIdx.y * 16;
+    const int nchunks = a.Kq / DK, nsteps = nchunks * 9;
+    // chunk -> source table (segments are padded to whole chunks in the packed weights)
+    if (tid < nchunks) {      // (nchunks <= DIRECT_MAX_CHUNKS <= the workgroup size)
+        int s = 0, c = tid * DK;
+        while (s + 1 < a.nsrc && c >= (a.src[s].C + DK - 1) / DK * DK) { c -= (a.src[s].C + DK - 1) / DK * DK; s++; }
+        ChunkRef r; r.base = a.src[s].p + (long)n * a.src[s].sn; r.pl = a.src[s].bcast ? 0 : a.src[s].ld; r.C = a.src[s].C; r.c0 = c;
+        tab[tid] = r;
+    }
+    __syncthreads();
+    const int px = lane & 15, kg = lane >> 4;                 // B fragment: pixel column, k-group (8 channels); A fragment: output channel row px, same k-group
+    const _Float16* wq = reinterpret_cast<const _Float16*>(a.wq) + ((long)co0 + px) * (2 * DK) + kg * 8;
+    const long wstep = (long)a.Cout_pad * (2 * DK);           // halves between consecutive (tap, chunk) tiles
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned amax = 0u;
+    for (int s0 = wave; s0 < nsteps; s0 += NW * U) {
+        h8 wh[U], wl[U];
+        float4 xa[U], xb[U];
+        bool ok[U]; int cc[U], CC[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                         // loads only (clamped addresses)
+            int s = s0 + NW * u; s = s < nsteps ? s : nsteps - 1;
+            const int chunk = s / 9, tap = s - 9 * chunk;
+            const ChunkRef r = tab[chunk];
+            const int yy = y + tap / 3 - 1, xx = x0 + px + tap % 3 - 1;
+            const int c = r.c0 + kg * 8;
+            ok[u] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W; cc[u] = c; CC[u] = r.C;
+            const float* p = r.base + (ok[u] ? ((long)yy * a.W + xx) * r.pl : 0L);
+            xa[u] = *reinterpret_cast<const float4*>(p + (c < r.C ? c : 0));
+            xb[u] = *reinterpret_cast<const float4*>(p + (c + 4 < r.C ? c + 4 : 0));
+            const _Float16* w = wq + ((long)tap * nchunks + chunk) * wstep;
+            wh[u] = *reinterpret_cast<const h8*>(w);
+            wl[u] = *reinterpret_cast<const h8*>(w + DK);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (s0 + NW * u >= nsteps) break;                 // (wave-uniform)
+            const float v4[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (ok[u] && cc[u] + e < CC[u]) ? v4[e] : 0.f;
+            h8 xh, xl;
+            split8(v, xh, xl, amax);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u], xh, acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], xh, acc, 0, 0, 0);
+        }
+    }
+    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);
+    // ---- the waves' partial tiles: fixed order (bit-reproducible), then the epilogue on wave 0: lane holds channels co0 + 4 (lane >> 4) .. + 3 of pixel lane & 15 ----
+    *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float t = red[lane * 4 + r];
+#pragma unroll
+        for (int w = 1; w < NW; w++) t += red[(w * 64 + lane) * 4 + r];
+        v[r] = t;
+    }
+    const int xx = x0 + px, co = co0 + 4 * kg;
+    if (xx >= a.W || co >= a.Cout) return;
+    const long pix = (long)y * a.W + xx;
+    float* o = a.out + (long)n * a.out_sn + pix * a.out_ld + co;
+    const float* rp = a.res ? a.res + (long)n * a.res_sn + pix * a.res_ld + co : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (co + r >= a.Cout) break;
+        float t = v[r] * a.out_scale + (a.bias ? a.bias[co + r] : 0.f);
+        if (rp) t += rp[r];
+        if (a.act == 2) t = fmaxf(t, 0.f);
+        else if (a.act == 3) t = t > 0.f ? t : 0.2f * t;
+        v[r] = t;
+    }
+    if (co + 4 <= a.Cout) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int r = 0; r < 4 && co + r < a.Cout; r++) o[r] = v[r];
+}
+}  // namespace
+
+// workgroup-steps up to which re-reading the activations per 16-channel block (no LDS reuse) is cheaper than the tile kernel's launch + slab reduce
+#define DIRECT_MAX_WORK 24576
+
+// 1 = handled.  Called by conv_hx_try for assigning split-f16 launches it would otherwise split over K (a.Kq, a.out_scale, a.Cout_pad set by the caller).
+int conv_direct_try(const ConvArgs& a, hipStream_t st) {
+    if (a.KS != 3 || !a.wq || a.precision != PREC_F16X3 || a.accumulate || a.mask || a.pool_out || a.skip_out || a.stats || a.seed_ref) return 0;
+    if (a.act != 0 && a.act != 2 && a.act != 3) return 0;
+    if ((a.out_ld & 3) || (a.out_sn & 3) || (a.res && ((a.res_ld & 3) || (a.res_sn & 3)))) return 0;
+    for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale || (a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0;
+    const int nchunks = a.Kq / DK;
+    if (nchunks < 1 || nchunks > DIRECT_MAX_CHUNKS) return 0;
+    const int gx = cdiv(a.W, 16);
+    const long groups = (long)a.N * a.H * gx, cob = cdiv(a.Cout, 16);
+    if (groups * cob * nchunks * 9 > DIRECT_MAX_WORK) return 0;
+    if ((long)cob * 16 > a.Cout_pad) return 0;
+    dim3 grid((unsigned)groups, (unsigned)cob);
+    // (eight waves on the long reductions of R's 16x16 side branch -- 81 steps, 128 workgroups -- measured SLOWER: 13.7 us against ~8, roll-out 2068 -> 2014 frames/s)
+    if (nchunks * 9 >= 36) hipLaunchKernelGGL((k_conv_direct<4, 3>), grid, dim3(256), 0, st, a, gx);
+    else hipLaunchKernelGGL((k_conv_direct<4, 2>), grid, dim3(256), 0, st, a, gx);
+    return 1;
+}

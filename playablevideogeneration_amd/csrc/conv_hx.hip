@@ -681,6 +681,7 @@ bool conv_src_lazy_ok(const ConvArgs& a) {
     return true;
 }
 thread_local int g_last_conv_stats_tiles = 0;
+thread_local int g_last_conv_direct = 0;
 
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
@@ -712,6 +713,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     const long blocks = (long)a.N * tx * ty * (a.Cout_pad / bn);
     // under-filled launches: split the channel chunks across blockIdx.z.  Accumulating launches (dgrad +=) combine with fp32 atomics; assigning
     // launches use the caller's slab scratch + the fixed-order k_split_reduce (bit-reproducible forward), as k_conv_fwd does.
+    // latency-bound assigning launches (batch-1 roll-out): one launch without slabs on conv_direct.hip
+    g_last_conv_direct = 0;
+    if (a.direct_ok && blocks < 200 && conv_direct_try(a, st) == 1) { g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1; return 1; }
     a.splitk = 1; a.split_stride = 0;
     bool det_accum = false;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;

@@ -517,8 +517,10 @@ PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
 
 
 def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
-                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False, pool=False, skip_out=False):
+                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False, pool=False, skip_out=False, direct=False):
     """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
+    direct = True: ConvArgs.direct_ok -- small assigning launches go to the latency kernel (conv_direct.hip); the case asserts that it was taken (the untouched pad columns of
+    the output and, with `split`, the untouched slab scratch tell).
     dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
     Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
     lib.caddy_k_hx_weight_bytes.restype = C.c_long
@@ -605,6 +607,11 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
         scr = torch.zeros(8 * N * H * W * round_up(out_c, 4), device=dev)
         a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
     a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
+    if direct:
+        a.direct_ok = 1
+        if not split:                      # the slab scratch stays untouched when the latency kernel takes the launch
+            scr = torch.full((8 * N * H * W * round_up(out_c, 4),), 3.25, device=dev)
+            a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
     if pool:                               # MaxPool2d(2, 2) of the activated output written by the conv epilogue (floor on odd sizes)
         pld = round_up(out_c, 4) + 4
         pout = torch.full((N, H // 2, W // 2, pld), 5.5, device=dev)
@@ -630,6 +637,8 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     err = (y - ref).abs().max().item() / scale
     assert err < tol, ("hx conv", err, tol)
     assert torch.equal(out[..., out_c:].cpu(), init[..., out_c:])           # pad channels untouched
+    if direct:
+        assert lib.caddy_k_conv_took_direct() == 1, "the latency kernel did not take this launch"
     return err
 
 

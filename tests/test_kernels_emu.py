@@ -104,6 +104,18 @@ def test_conv_hx_narrow_output_tiles_small():
     K.hx_conv_case(load_emu(), "cpu", N=1, H=8, W=16, segs=[(40, False)], Cout=64, precision=K.PREC_BF16X3, dgrad_seg=0)
 
 
+def test_conv_direct_latency_kernel_small():
+    """conv_direct.hip (round 4): small assigning split-f16 launches in ONE launch -- a workgroup per 16-pixel x 16-channel tile, four waves splitting the K steps, fragments
+    straight from global memory, fixed-order LDS fold, epilogue in place.  Ragged width (not a multiple of 16), channel tails on both sides, a broadcast segment, a single
+    32-channel chunk (nine steps over four waves), bias / LeakyReLU / ReLU / residual epilogues, BatchNorm-folded weights (PackDesc.oscale)"""
+    lib = load_emu()
+    K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True, direct=True)
+    K.hx_conv_case(lib, "cpu", N=2, H=8, W=18, segs=[(64, False), (9, True)], Cout=65, bias=True, act=3, res=True, direct=True, seed=1)
+    K.hx_conv_case(lib, "cpu", N=1, H=9, W=32, segs=[(32, False)], Cout=32, act=2, oscale=True, direct=True, seed=2)
+    K.hx_conv_case(lib, "cpu", N=1, H=6, W=16, segs=[(64, False), (5, True), (64, False)], Cout=128, bias=True, act=3, direct=True, seed=3)
+    K.hx_conv_case(lib, "cpu", N=1, H=4, W=16, segs=[(128, False), (9, True), (128, False)], Cout=40, bias=True, direct=True, seed=4)      # 81 steps
+
+
 def test_conv_hx_8wave_pipelined_variant_small():
     """the 16x16x128 tile on 8 waves with the 3-deep weight-tile register ring: ragged 20x18 map, K tail (2 chunks + segment padding), Cout tail"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=20, W=18, segs=[(40, False), (5, True)], Cout=130, bias=True, act=2, big=1)

@@ -116,6 +116,18 @@ def test_conv_hx_forward(lib, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(N=1, H=32, W=32, segs=[(64, False)], Cout=64, bias=True, act=3, res=True),                    # E residual block conv of a roll-out frame (BatchNorm folded)
+    dict(N=1, H=32, W=32, segs=[(64, False), (9, True)], Cout=65, bias=True),                          # channel tails + broadcast action input
+    dict(N=1, H=64, W=64, segs=[(32, False)], Cout=64, bias=True, act=3),                              # one 32-channel chunk: nine steps over four waves
+    dict(N=1, H=16, W=16, segs=[(128, False), (9, True), (128, False)], Cout=128, bias=True, act=3),   # R's side branch on the 16x16 map
+    dict(N=2, H=20, W=26, segs=[(40, False)], Cout=48, act=2, oscale=True, seed=3),                    # ragged width, tails
+])
+def test_conv_direct_latency_kernel(lib, kw):
+    """round 4: conv_direct.hip -- the one-launch form of small assigning split-f16 convolutions (batch-1 roll-out layers)"""
+    K.hx_conv_case(lib, "cuda", direct=True, **kw)
+
+
+@pytest.mark.parametrize("kw", [
     dict(N=8, H=64, W=64, Cin=128, Cout=128),                      # D residual block: conv1 -> bn1 -> LeakyReLU -> conv2, 8x16x128 tiles
     dict(N=8, H=128, W=128, Cin=64, Cout=64, seed=1),              # 16x16x64 tiles
     dict(N=8, H=32, W=32, Cin=128, Cout=256, aux_c=9, act=0),      # ConvLSTM 0's BatchNorm (no activation) -> SameBlock conv with the broadcast action input
