@@ -105,7 +105,7 @@ struct ConvArgs {
     // fixed-order reduce (which then adds the previous contents of `out`) instead of fp32 atomics in arrival order
     int deterministic;
     // Small assigning split-f16 launches may run on the latency kernel (conv_direct.hip: one launch, no slabs) instead of the tile kernel's split-K launch + slab reduce.
-    // The driver sets it on every forward convolution; kernel tests choose the path explicitly.
+    // The driver sets it on the forward convolutions of inference-mode passes (roll-out, evaluation); kernel tests choose the path explicitly.
     int direct_ok;
 };
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the

@@ -510,7 +510,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf; a.out = out.d;
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
-    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag; a.direct_ok = 1; }
+    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
     else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32) { a.precision = PREC_F16X3; a.sat_flag = sat_flag; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
     for (int s = 0; s < nseg; s++)
         if (segs[s].t.bn_scale && !conv_src_lazy_ok(a)) { fail = true; set_error("internal: lazily normalised input handed to a convolution that cannot apply it"); }
