@@ -116,6 +116,14 @@ def test_conv_direct_latency_kernel_small():
     K.hx_conv_case(lib, "cpu", N=1, H=4, W=16, segs=[(128, False), (9, True), (128, False)], Cout=40, bias=True, direct=True, seed=4)      # 81 steps
 
 
+def test_conv_hx_4x16_tiles_for_inference_small():
+    """round 4: inference launches (ConvArgs.direct_ok) too large for the latency kernel and under-filled on 8x16 tiles run on 4x16-pixel tiles: with and without the K split
+    into slabs, ragged rows, a channel tail"""
+    lib = load_emu()
+    K.hx_conv_case(lib, "cpu", N=1, H=14, W=64, segs=[(256, False)], Cout=128, bias=True, act=3, direct="tile4", split=True)
+    K.hx_conv_case(lib, "cpu", N=1, H=18, W=60, segs=[(200, False), (9, True)], Cout=100, bias=True, res=True, direct="tile4", seed=1)
+
+
 def test_conv_hx_8wave_pipelined_variant_small():
     """the 16x16x128 tile on 8 waves with the 3-deep weight-tile register ring: ragged 20x18 map, K tail (2 chunks + segment padding), Cout tail"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=20, W=18, segs=[(40, False), (5, True)], Cout=130, bias=True, act=2, big=1)

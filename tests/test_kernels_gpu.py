@@ -128,6 +128,16 @@ def test_conv_direct_latency_kernel(lib, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(N=1, H=128, W=128, segs=[(64, False)], Cout=64, bias=True, act=3),                  # D's 128x128 layers of a roll-out frame: 256 workgroups of 4x16 pixels, no K split
+    dict(N=1, H=126, W=120, segs=[(128, False)], Cout=64, bias=True, act=3, res=True, seed=1),      # ragged rows / columns, 36 steps
+    dict(N=1, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=3, split=True, seed=2),      # still under-filled on 4x16 tiles: K split into slabs + fixed-order reduce
+])
+def test_conv_hx_4x16_tiles_for_inference(lib, kw):
+    """round 4: inference launches too large for the latency kernel whose 8x16 grid would be split over K run on 4x16-pixel tiles instead (no slab reduce)"""
+    K.hx_conv_case(lib, "cuda", direct="tile4", **kw)
+
+
+@pytest.mark.parametrize("kw", [
     dict(N=8, H=64, W=64, Cin=128, Cout=128),                      # D residual block: conv1 -> bn1 -> LeakyReLU -> conv2, 8x16x128 tiles
     dict(N=8, H=128, W=128, Cin=64, Cout=64, seed=1),              # 16x16x64 tiles
     dict(N=8, H=32, W=32, Cin=128, Cout=256, aux_c=9, act=0),      # ConvLSTM 0's BatchNorm (no activation) -> SameBlock conv with the broadcast action input
