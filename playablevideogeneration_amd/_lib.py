@@ -28,7 +28,13 @@ class ConvArgs(C.Structure):
                 ("mask", C.c_void_p), ("seed_ref", C.c_void_p), ("seed_w", C.c_float), ("wq", C.c_void_p), ("Kq", C.c_int), ("out_scale", C.c_float),
                 ("res", C.c_void_p), ("res_sn", C.c_long), ("res_ld", C.c_int), ("xcd_map", C.c_int),
                 ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int),
-                ("stats", C.c_void_p), ("stats_ld", C.c_int), ("sat_flag", C.c_void_p), ("deterministic", C.c_int), ("direct_ok", C.c_int)]
+                ("stats", C.c_void_p), ("stats_ld", C.c_int), ("sat_flag", C.c_void_p), ("deterministic", C.c_int), ("direct_ok", C.c_int), ("lstm", C.c_void_p)]
+
+
+class LstmFuse(C.Structure):      # csrc/common.h: cell update applied by the slab reduce of a roll-out gate convolution (ConvArgs.lstm)
+    _fields_ = [("cprev", C.c_void_p), ("cprev_sn", C.c_long), ("cprev_ld", C.c_int), ("h", C.c_void_p), ("h_sn", C.c_long), ("h_ld", C.c_int),
+                ("c", C.c_void_p), ("c_sn", C.c_long), ("c_ld", C.c_int), ("hb", C.c_void_p), ("hb_sn", C.c_long), ("hb_ld", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("C", C.c_int)]
 
 
 class WgradArgs(C.Structure):

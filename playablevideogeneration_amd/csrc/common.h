@@ -107,7 +107,14 @@ struct ConvArgs {
     // Small assigning split-f16 launches may run on the latency kernel (conv_direct.hip: one launch, no slabs) instead of the tile kernel's split-K launch + slab reduce.
     // The driver sets it on the forward convolutions of inference-mode passes (roll-out, evaluation); kernel tests choose the path explicitly.
     int direct_ok;
+    // Roll-out ConvLSTM cells: when the launch is split over K, its slab reduce applies the cell update itself (LstmFuse, host pointer; null otherwise) and sets
+    // g_last_conv_lstm_fused -- the caller then skips its point-wise LSTM kernel.  Launch paths without a slab reduce ignore it.
+    const struct LstmFuse* lstm;
 };
+// gates = [i | f | o | g] x C pre-activations (convolutional_lstm_cell.py:92-101): c' = sigm(f) c + sigm(i) tanh(g), h' = sigm(o) tanh(c'), hb = h' * scale + shift (the cell's
+// eval-mode BatchNorm, conv_dynamics_network.py); all tensors NHWC with their own sample / pixel pitches
+struct LstmFuse { const float* cprev; long cprev_sn; int cprev_ld; float* h; long h_sn; int h_ld; float* c; long c_sn; int c_ld; float* hb; long hb_sn; int hb_ld; const float* scale; const float* shift; int C; };
+extern thread_local int g_last_conv_lstm_fused;
 // split-f16 weights are stored multiplied by HX_WSCALE (exact: a power of two) and the accumulator is multiplied by 1 / HX_WSCALE in the
 // epilogue: conv weights are O(1/sqrt(fan_in)) ~ 0.01-0.1, where the `lo` half (|lo| <= 2^-11 |w|) would fall into the f16 subnormal range and
 // keep only ~8 of its 11 bits.  Scaled by 64 the weights are O(1) and carry 22 bits; |w| < 1023 stays finite.
@@ -175,6 +182,7 @@ size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
 extern int g_hx_big_override;
+int conv_split_reduce_lstm_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, const float* bias, const LstmFuse& f, hipStream_t st);
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
                              const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin

@@ -783,7 +783,9 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     }
 #undef HX_LAUNCH
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
-    if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
+    if (a.split_stride && a.lstm && !det_accum && real_act == 0 && !real_res && !stats_req && a.Cout == 4 * a.lstm->C && (a.lstm->C & 3) == 0 && (a.out_ld & 3) == 0)
+        conv_split_reduce_lstm_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, real_bias, *a.lstm, st);      // roll-out ConvLSTM cell: the reduce applies the cell update
+    else if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
                                                  stats_req, stats_req_ld, stats_cap, det_accum ? 1 : 0);
     return 1;
 }

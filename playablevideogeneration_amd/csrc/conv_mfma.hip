@@ -353,6 +353,45 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long str
     }
 }
 
+// the same for the gate convolution of a roll-out ConvLSTM cell (ConvArgs.lstm): the four gate quads of (pixel, channel quad) are summed over the slabs in the same fixed
+// order, then the cell update of k_map<FLstmFwd> is applied in place -- same expressions (results within 2 ulp: fma contraction) -- and the gate tensor itself is never written (only a backward pass
+// would read it).  One launch instead of k_split_reduce + the point-wise kernel.
+__global__ __launch_bounds__(256) void k_split_reduce_lstm(const float* scr, long stride, int splits, int ldc, int HW, long P, const float* bias, LstmFuse f) {
+    // four consecutive lanes own one (pixel, channel quad): lane k sums gate k's quad over the slabs (as many threads in flight as k_split_reduce has), a 4 x 4 transpose
+    // through shuffles hands lane k the four gates of channel c + k, and every lane updates one channel
+    const int C = f.C, C4 = C >> 2, lane = threadIdx.x & 63, k = lane & 3;
+    const long items = P * C4;
+    // (wave-uniform trip count: a wave owns 16 consecutive items per trip and every lane takes part in the shuffles; lanes past the end are clamped and do not store)
+    for (long w0 = (blockIdx.x * 256L + (threadIdx.x & ~63)) >> 2; w0 < items; w0 += (long)gridDim.x * 64) {
+        const long i0 = w0 + (lane >> 2);
+        const long i = i0 < items ? i0 : items - 1;
+        const long p = i / C4; const int c = (int)(i - p * C4) * 4;
+        const float* q = scr + p * ldc + k * C + c;
+        float4 v = *reinterpret_cast<const float4*>(q);
+        for (int z = 1; z < splits; z++) { const float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + k * C + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        // lane k holds gate k of channels c .. c + 3 -> lane k gets gates 0 .. 3 of channel c + k
+        const int base = lane & ~3;
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a0 = __shfl(v.x, base + j), a1 = __shfl(v.y, base + j), a2 = __shfl(v.z, base + j), a3 = __shfl(v.w, base + j);
+            g[j] = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
+        }
+        if (i0 < items) {
+            const long n = p / HW, pp = p - n * HW;
+            const int ch = c + k;
+            const float cp = f.cprev[n * f.cprev_sn + pp * f.cprev_ld + ch];
+            auto sg = [](float t) { return 1.f / (1.f + expf(-t)); };      // (pointwise.hip: sigm)
+            const float cc = sg(g[1]) * cp + sg(g[0]) * tanhf(g[3]);
+            const float hh = sg(g[2]) * tanhf(cc);
+            f.c[n * f.c_sn + pp * f.c_ld + ch] = cc;
+            f.h[n * f.h_sn + pp * f.h_ld + ch] = hh;
+            if (f.hb) f.hb[n * f.hb_sn + pp * f.hb_ld + ch] = hh * f.scale[ch] + f.shift[ch];
+        }
+    }
+}
+
 // the same with the BatchNorm partial sums of the reduced tensor (ConvArgs.stats): a workgroup owns PPB consecutive pixels, thread = (pixel row tid / C4, channel quad
 // tid % C4) with C4 | 256, so that every thread keeps one channel quad; the pixel rows are folded through LDS and workgroup b writes stats[(b * stats_ld + c) * 2 + {0, 1}]
 // -- the layout k_bn_finalize_tiles reads, with "tiles" = workgroups.  (Split launches are exactly the under-filled ones -- R's 16x16 / 32x32 maps, E / A on one time
@@ -800,6 +839,13 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
 #undef LAUNCH_CONV
     if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
                                                  nullptr, 0, 0, det_accum ? 1 : 0);
+    return 0;
+}
+thread_local int g_last_conv_lstm_fused = 0;
+int conv_split_reduce_lstm_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, const float* bias, const LstmFuse& f, hipStream_t st) {
+    const long thr = P * f.C;      // four lanes per (pixel, channel quad)
+    hipLaunchKernelGGL(k_split_reduce_lstm, dim3((unsigned)(thr < 256L * 1024 ? cdiv(thr, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, bias, f);
+    g_last_conv_lstm_fused = 1;
     return 0;
 }
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,

@@ -510,6 +510,8 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf; a.out = out.d;
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
+    g_last_conv_lstm_fused = 0;
+    if (lstm_fuse) { a.lstm = lstm_fuse; lstm_fuse = nullptr; }      // (set by lstm_step for the gate convolution of a roll-out cell)
     if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
     else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32) { a.precision = PREC_F16X3; a.sat_flag = sat_flag; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
     for (int s = 0; s < nseg; s++)
@@ -790,17 +792,28 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     } else { hprev = L.h; cprev = L.c; }
     Seg sg[3] = {{x, 0, true}, {aux, 1, true}, {hprev, 0, true}};
     sg[2].off_chain = true;
-    T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     T4 hn, cn;
     if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
-    if (fold) {      // roll-out: the cell's eval-mode BatchNorm is a second output of the point-wise kernel
+    if (fold) {      // roll-out: the cell's eval-mode BatchNorm is a second output of the cell update; when the gate convolution is split over K its slab reduce applies
+                     // the update itself (ConvArgs.lstm: one launch instead of k_split_reduce + k_map<FLstmFwd>, and the gate tensor is never written)
         T4 hb = alloc(B, L.Hs, L.Ws, L.C);
         const int cp = round_up(L.bn.C, 4);
-        TV hbv = dv(hb);
-        RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream, &hbv, L.bn.eval_stash + 2 * cp, L.bn.eval_stash + 3 * cp));
+        LstmFuse lf{cprev.d, cprev.sn, cprev.ld, hn.d, hn.sn, hn.ld, cn.d, cn.sn, cn.ld, hb.d, hb.sn, hb.ld, L.bn.eval_stash + 2 * cp, L.bn.eval_stash + 3 * cp, L.C};
+        // (the persistent roll-out state is updated in place -- cn aliases cprev, hn the convolution's third input: every (pixel, channel quad) is read and written by one
+        //  thread of the reduce, which starts after the convolution's last read)
+        const bool fusable = (cprev.ld & 3) == 0 && (hn.ld & 3) == 0 && (cn.ld & 3) == 0 && (hb.ld & 3) == 0 &&
+                             (cprev.sn & 3) == 0 && (hn.sn & 3) == 0 && (cn.sn & 3) == 0 && (hb.sn & 3) == 0;
+        if (fusable) lstm_fuse = &lf;
+        T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);
+        lstm_fuse = nullptr;
+        if (!g_last_conv_lstm_fused || dry) {
+            TV hbv = dv(hb);
+            RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream, &hbv, L.bn.eval_stash + 2 * cp, L.bn.eval_stash + 3 * cp));
+        }
         L.h = hn; L.c = cn;
         return hb;
     }
+    T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
     if (recording) tp->push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
     L.h = hn; L.c = cn;

@@ -91,6 +91,7 @@ struct caddy_ctx {
     bool dry = false;
     bool fail = false;
     bool training = true;
+    const struct LstmFuse* lstm_fuse = nullptr;      // lstm_step -> conv(): the gate convolution of a roll-out ConvLSTM cell may apply the cell update in its slab reduce
     bool recording = false;
     hipStream_t stream = nullptr;
     float* P = nullptr; float* G = nullptr;

@@ -642,6 +642,58 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     return err
 
 
+def lstm_fused_reduce_case(lib, dev, N=1, H=16, W=16, Cin=64, Cc=32, seed=0):
+    """ConvArgs.lstm (round 4): the slab reduce of a K-split gate convolution applies the ConvLSTM cell update itself (roll-out frames: one launch instead of k_split_reduce +
+    k_map<FLstmFwd>).  Same sums in the same order, same expressions (up to the compiler's fma contraction: <= 2 ulp): h' and c' agree with the two-kernel path to 1e-6,
+    hb = h' * scale + shift, the gate tensor is not written, and the in-place form of the persistent roll-out state (c' over c) works."""
+    from playablevideogeneration_amd._lib import LstmFuse
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+    g = torch.Generator().manual_seed(seed)
+    Cout = 4 * Cc
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    cp = torch.randn(N, Cc, H, W, generator=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    st = stream(dev)
+    w_d = w.contiguous().to(dev)
+    d = make_pack([w], [(0, Cin)], 3, lib)
+    d.w[0] = w_d.data_ptr()
+    rows_pad = round_up(Cout, lib.caddy_k_hx_pick_bn(Cout))
+    wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), -1, rows_pad, 2), dtype=torch.uint8, device=dev)
+    assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, -1, PREC_F16X3, st) == 0
+    xb, b_d = nhwc(x, dev=dev), b.to(dev)
+    scr = torch.zeros(16 * N * H * W * Cout, device=dev)
+
+    def args(out):
+        a = ConvArgs()
+        a.src[0] = ConvSrc(xb.data_ptr(), H * W * xb.shape[3], xb.shape[3], Cin, round_up(Cin, CONV_BK), 0)
+        a.nsrc, a.N, a.H, a.W, a.KS = 1, N, H, W, 3
+        a.wp, a.Ktot, a.Cout, a.Cout_pad = None, round_up(Cin, CONV_BK), Cout, round_up(Cout, lib.caddy_k_conv_pick_bn(Cout))
+        a.wq, a.precision, a.bias = wq.data_ptr(), PREC_F16X3, b_d.data_ptr()
+        a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * Cout, Cout
+        a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
+        return a
+    gates = torch.full((N, H, W, Cout), 9.0, device=dev)
+    a = args(gates)
+    assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    cpb = nhwc(cp, dev=dev)
+    h1, c1 = torch.zeros_like(cpb), torch.zeros_like(cpb)
+    assert lib.caddy_k_lstm_fwd(C.byref(tv(gates, Cout)), C.byref(tv(cpb, Cc)), C.byref(tv(h1, Cc)), C.byref(tv(c1, Cc)), st) == 0
+    sync(dev)
+    gates2 = torch.full((N, H, W, Cout), 9.0, device=dev)
+    h2, c2, hb2 = torch.zeros_like(cpb), cpb.clone(), torch.zeros_like(cpb)      # c' written over c (the persistent roll-out state)
+    sc_d, sh_d = sc.to(dev), sh.to(dev)
+    lf = LstmFuse(c2.data_ptr(), H * W * Cc, Cc, h2.data_ptr(), H * W * Cc, Cc, c2.data_ptr(), H * W * Cc, Cc, hb2.data_ptr(), H * W * Cc, Cc, sc_d.data_ptr(), sh_d.data_ptr(), Cc)
+    a = args(gates2)
+    a.lstm = C.cast(C.pointer(lf), C.c_void_p)
+    assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
+    sync(dev)
+    assert torch.all(gates2 == 9.0), "the fused reduce was not taken (the gate tensor was written)"
+    assert (h1 - h2).abs().max().item() < 1e-6 and (c1 - c2).abs().max().item() < 1e-6, ((h1 - h2).abs().max().item(), (c1 - c2).abs().max().item())
+    assert (hb2.cpu() - (h2.cpu() * sc + sh)).abs().max().item() < 1e-6
+
+
 def hx_saturation_case(lib, dev, N=1, H=10, W=20, Cin=40, Cout=48, seed=0):
     """f16 range guard of the split-f16 forward (ConvArgs.sat_flag): inputs beyond +-65504 are clamped to the f16 range while they are staged (no inf - inf = NaN in the low
     half) and the launch sets the flag; in-range inputs leave the flag alone.  Reference: fp64 conv2d of the CLAMPED input."""

@@ -124,6 +124,10 @@ def test_conv_hx_4x16_tiles_for_inference_small():
     K.hx_conv_case(lib, "cpu", N=1, H=18, W=60, segs=[(200, False), (9, True)], Cout=100, bias=True, res=True, direct="tile4", seed=1)
 
 
+def test_lstm_cell_update_in_the_slab_reduce_small():
+    K.lstm_fused_reduce_case(load_emu(), "cpu", N=1, H=8, W=16, Cin=64, Cc=32)
+
+
 def test_conv_hx_8wave_pipelined_variant_small():
     """the 16x16x128 tile on 8 waves with the 3-deep weight-tile register ring: ragged 20x18 map, K tail (2 chunks + segment padding), Cout tail"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=20, W=18, segs=[(40, False), (5, True)], Cout=130, bias=True, act=2, big=1)

@@ -127,6 +127,12 @@ def test_conv_direct_latency_kernel(lib, kw):
     K.hx_conv_case(lib, "cuda", direct=True, **kw)
 
 
+def test_lstm_cell_update_in_the_slab_reduce(lib):
+    """round 4: roll-out ConvLSTM cells -- the K-split gate convolution's slab reduce applies the cell update (ConvArgs.lstm) like k_split_reduce + k_map<FLstmFwd>"""
+    K.lstm_fused_reduce_case(lib, "cuda", N=1, H=32, W=32, Cin=208, Cc=128)
+    K.lstm_fused_reduce_case(lib, "cuda", N=1, H=16, W=16, Cin=528, Cc=256, seed=1)
+
+
 @pytest.mark.parametrize("kw", [
     dict(N=1, H=128, W=128, segs=[(64, False)], Cout=64, bias=True, act=3),                  # D's 128x128 layers of a roll-out frame: 256 workgroups of 4x16 pixels, no K split
     dict(N=1, H=126, W=120, segs=[(128, False)], Cout=64, bias=True, act=3, res=True, seed=1),      # ragged rows / columns, 36 steps
