@@ -187,6 +187,7 @@ int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc,
                              const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
+int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st);    // conv_head.hip: dgrad of the 7x7 head (3 -> C channels) on the split-bf16 matrix pipe (ConvArgs.precision == PREC_BF16X3, no wq)
 int conv_direct_try(const ConvArgs& a, hipStream_t st);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

@@ -157,7 +157,113 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
         }
     }
 }
+
+// ---- dgrad of the 7x7 head (3 -> C channels as a convolution of dY with the flipped weights; model/layers/final_block.py:9-29 backward) on v_mfma_f32_16x16x32_bf16 ----
+// The 3-channel side is the REDUCTION here: K = 32 = one tap ROW of the 7x7 window = 4 tap pairs x 2 taps x (3 -> 4) channels (the eighth tap carries zero weights), so a
+// 16-pixel x 16-channel block takes 7 instructions per product instead of 49 v_mfma_f32_16x16x4_f32 (k_conv_c4<7>: 85 us per 8 frames of 256 x 256, half of it matrix-pipe
+// time).  B fragment = dY straight from the staged halo: lane (pixel p = lane & 15, pair j = lane >> 4) reads the 2 x 4 channels of the horizontally adjacent pixels
+// p + 2j, p + 2j + 1 of row y + u - 3 -- 16 contiguous bytes of the [row][column][4 channels] bf16 image (implicit im2col, no expansion in LDS).  A fragments (weights of tap
+// row u: [channel][pair, tap, ch]) are split once per workgroup and stay in registers (7 rows x NB blocks x hi / lo).  Operands split in bf16 as every gradient operand
+// (conv_hx.hip); fp32 accumulation; the result is stored / accumulated as 4 consecutive channels per lane.  Persistent over 8 x 32-pixel tiles.
+template <int NB>
+__global__ __launch_bounds__(256) void k_head_dgrad7(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 32, R = 3, HH = TH + 2 * R, HWD = TW + 2 * R + 2;      // 40 columns: 38 + the zero-weight eighth tap of the right-most pixel
+    __shared__ __attribute__((aligned(16))) bf16x4 Xh[HH * HWD];
+    __shared__ __attribute__((aligned(16))) bf16x4 Xl[HH * HWD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane & 15, pj = lane >> 4;
+    const ConvSrc s = a.src[0];
+    // ---- weights: wp[tap][Cout_pad][Ktot] (dgrad-packed, taps already flipped) -> A fragments ----
+    bf16x8 ah[7][NB], al[7][NB];
+#pragma unroll
+    for (int u = 0; u < 7; u++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const int co = nb * 16 + ci;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int v = 2 * pj + (e >> 2), ch = e & 3;
+                float w = 0.f;
+                if (v < 7 && ch < s.C && co < a.Cout) w = a.wp[((long)(u * 7 + v) * a.Cout_pad + co) * a.Ktot + ch];
+                const __bf16 h = (__bf16)w;
+                ah[u][nb][e] = h; al[u][nb][e] = (__bf16)(w - (float)h);
+            }
+        }
+    const long ntiles = (long)a.N * tiles_x * tiles_y;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = (int)(tile / (tiles_x * tiles_y));
+        const int rem = (int)(tile - (long)n * tiles_x * tiles_y);
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        const float* base = s.p + (long)n * s.sn;
+        // ---- halo of dY: one float4 (3 channels + pad) per pixel -> split bf16 ----
+        for (int p = tid; p < HH * HWD; p += 256) {
+            const int hy = p / HWD, hx = p - hy * HWD;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = *reinterpret_cast<const float4*>(base + ((long)y * a.W + x) * s.ld);
+            const float f[4] = {v.x, s.C > 1 ? v.y : 0.f, s.C > 2 ? v.z : 0.f, s.C > 3 ? v.w : 0.f};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { hi[e] = (__bf16)f[e]; lo[e] = (__bf16)(f[e] - (float)hi[e]); }
+            Xh[p] = hi; Xl[p] = lo;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int g = 0; g < 4; g++) {                          // this wave's four 16-pixel groups: tile row 2 wave + (g >> 1), column half g & 1
+            const int ry = 2 * wave + (g >> 1), cx = 16 * (g & 1);
+            f32x4 acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int o = (ry + u) * HWD + cx + ci + 2 * pj;
+                union { bf16x4 q[2]; bf16x8 v; } bh, bl;
+                bh.q[0] = Xh[o]; bh.q[1] = Xh[o + 1]; bl.q[0] = Xl[o]; bl.q[1] = Xl[o + 1];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][nb], bh.v, acc[nb], 0, 0, 0);      // small terms first
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][nb], bl.v, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][nb], bh.v, acc[nb], 0, 0, 0);
+            }
+            const int y = y0 + ry, x = x0 + cx + ci;            // D: column = pixel lane & 15, rows = channels 4 (lane >> 4) .. + 3
+            if (y < a.H && x < a.W) {
+                float* o_ = a.out + (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int c = nb * 16 + 4 * pj;
+                    if (c >= a.Cout) continue;
+                    float v[4] = {acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]};
+                    if (c + 4 <= a.Cout) {
+                        float4 r = make_float4(v[0], v[1], v[2], v[3]);
+                        if (a.accumulate) { const float4 q = *reinterpret_cast<const float4*>(o_ + c); r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+                        *reinterpret_cast<float4*>(o_ + c) = r;
+                    } else {
+                        for (int e = 0; e < 4 && c + e < a.Cout; e++) o_[c + e] = a.accumulate ? o_[c + e] + v[e] : v[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
 }  // namespace
+
+// 1 = handled: dgrad of the 7x7 FinalBlock head (a convolution of the 3-channel dY with the dgrad-packed weights) on the split-bf16 matrix pipe
+// (precision == PREC_BF16X3 without split weights marks the layer as eligible: the context runs exact fp32 otherwise)
+int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st) {
+    if (a.precision != PREC_BF16X3 || a.wq || a.KS != 7 || a.nsrc != 1 || a.src[0].bcast || a.src[0].bn_scale || a.src[0].C > 4 || a.src[0].ld != 4 || (a.src[0].sn & 3)) return 0;
+    if (a.bias || a.res || a.mask || a.pool_out || a.skip_out || a.stats || a.act != 0 || a.Cout < 8 || a.Cout > 32 || (a.out_ld & 3) || (a.out_sn & 3)) return 0;
+    const int nb = cdiv(a.Cout, 16);
+    if (a.Cout_pad < nb * 16) return 0;
+    const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 8);
+    const long ntiles = (long)a.N * tx * ty;
+    const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
+    if (nb == 2) hipLaunchKernelGGL((k_head_dgrad7<2>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((k_head_dgrad7<1>), dim3(grid), dim3(256), 0, st, a, tx, ty);
+    g_last_conv_kernel = CK_THIN_IN;
+    return 1;
+}
 
 // 1 = handled: forward of a FinalBlock head on the split-f16 matrix pipe (precision == PREC_F16X3 marks the layer as eligible: the context runs exact fp32 otherwise)
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st) {

@@ -790,6 +790,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     const bool fold_epilogue = a.act == 3 || a.res != nullptr;      // LeakyReLU / residual epilogues (BatchNorm-folded roll-out): k_conv_fwd, k_conv_hx, k_conv_narrow
     if (!generic_only) {
         if (!fold_epilogue && conv_head_fwd_try(a, st) == 1) return 0;      // FinalBlock heads (-> 3 channels) on the 16-bit matrix pipe (conv_head.hip)
+        if (!fold_epilogue && conv_head_dgrad_try(a, st) == 1) return 0;    // dgrad of the 7x7 FinalBlock head on the split-bf16 matrix pipe (conv_head.hip)
         if (!fold_epilogue && conv_c4_fwd_try(a, st) == 1) return 0;        // 3-channel input (stem, FinalBlock dgrad): 16x16x4 MFMA, K = one padded pixel
         if (!fold_epilogue && conv_thin_fwd_try(a, st) == 1) return 0;      // 3-channel heads / stem: vector-ALU kernels (conv_thin.hip)
         if (conv_narrow_fwd_try(a, st) == 1) return 0;    // 16/32-channel layers: halo-tile kernel on 16x16x4 MFMA (conv_narrow.hip)

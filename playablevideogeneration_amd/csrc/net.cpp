@@ -572,6 +572,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
                 d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux; d.deterministic = deterministic ? 1 : 0;
                 if (Lp->wqd[s] && prec_bwd != PREC_FP32) { d.wq = Lp->wqd[s]; d.precision = PREC_BF16X3; }
+                else if (Lp->pd.Cout <= 3 && Lp->pd.KS == 7 && prec_bwd != PREC_FP32) d.precision = PREC_BF16X3;      // 7x7 FinalBlock head: split bf16 on conv_head.hip (weights split in the kernel)
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
                 const int kind_save = prof_kind_override;
                 if (prof_kind_override < 0) prof_kind_override = 1;      // profiling: a dgrad launch, whether it assigns or accumulates

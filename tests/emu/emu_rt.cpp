@@ -155,6 +155,20 @@ f32x4 mfma_f32_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c, int, int, int) {
     return c;
 }
 
+f32x4 mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {      // same fragment maps as the f16 form
+    float mine[16], all[64 * 16];
+    for (int j = 0; j < 8; j++) { mine[j] = (float)a[j]; mine[8 + j] = (float)b[j]; }
+    wave_gather_n(mine, 16, all);
+    int l = t_cur->lin & 63, col = l & 15;
+    for (int r = 0; r < 4; r++) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; k++) acc = fmaf(all[(row + 16 * (k >> 3)) * 16 + (k & 7)], all[(col + 16 * (k >> 3)) * 16 + 8 + (k & 7)], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 // Fragment maps per /opt/skills/guides/cdna_hip_programming.md section 3:
 //  32x32x2: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 f32x16 mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {

@@ -74,6 +74,7 @@ f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int);
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c, int, int, int);
 f32x4 mfma_f32_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c, int, int, int);
+f32x4 mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c, int, int, int);
 void wave_gather_n(const float* mine, int n, float* all);   // all[lane*n + i]
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 s16x4_t ds_read_tr16_b64(const void* p);                    // gfx950 ds_read_b64_tr_b16 (lane map measured on the MI355X: tools/probes/tr_probe.hip)
@@ -97,6 +98,7 @@ inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t, hipStream_t, Arg
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu::mfma_f32_16x16x32_f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu::mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* scheduling hint only */
 static inline void __threadfence() {}      /* workgroups run one after the other on the simulator */

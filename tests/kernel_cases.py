@@ -60,8 +60,9 @@ def make_pack(ws, segs, KS, lib):
 
 
 def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True, wgrad_precision=0, wgrad_tol=None,
-              res=False, oscale=False):
-    """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd."""
+              res=False, oscale=False, dgrad_precision=None, dgrad_tol=None):
+    """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd.
+    dgrad_precision = 17: ConvArgs.precision of the dgrad launches (split bf16: conv_head.hip's 7x7 head dgrad)."""
     g = torch.Generator().manual_seed(seed)
     Cin = sum(c for c, _ in segs)
     xs = []
@@ -204,7 +205,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         da.src[0] = ConvSrc(dz_d.data_ptr(), H * W * dz_d.shape[3], dz_d.shape[3], Cout, kd, 0)
         da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, KS
         da.wp, da.Ktot, da.Cout, da.Cout_pad, da.bias, da.act = wpd.data_ptr(), kd, c, cd_pad, None, 0
-        da.precision = precision
+        da.precision = precision if dgrad_precision is None else dgrad_precision
         da.aux = aux.data_ptr() if use_aux else None
         gx = torch.ones((N, H, W, round_up(c, 4)), device=dev)      # accumulate on top of ones
         da.out, da.out_sn, da.out_ld, da.accumulate = gx.data_ptr(), H * W * gx.shape[3], gx.shape[3], 1
@@ -214,7 +215,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         if bc:
             got = got.sum(dim=(2, 3))
         e = (got - x_r.grad).abs().max().item()
-        assert e < tol * 8 * max(1.0, x_r.grad.abs().max().item()), ("dgrad", si, e)
+        assert e < (dgrad_tol or tol) * 8 * max(1.0, x_r.grad.abs().max().item()), ("dgrad", si, e)
         # deterministic split-K of the accumulating launch (ConvArgs.deterministic: slabs + fixed-order reduce that adds the old contents)
         scr = torch.zeros(9 * N * H * W * round_up(c, 4), device=dev)
         outs = []
@@ -229,7 +230,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
         if bc:
             got2 = got2.sum(dim=(2, 3))
         e = (got2 - x_r.grad).abs().max().item()
-        assert e < tol * 8 * max(1.0, x_r.grad.abs().max().item()), ("deterministic dgrad", si, e)
+        assert e < (dgrad_tol or tol) * 8 * max(1.0, x_r.grad.abs().max().item()), ("deterministic dgrad", si, e)
         assert torch.equal(outs[0], outs[1]), "deterministic dgrad not bit-reproducible"
 
 

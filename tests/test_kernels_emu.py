@@ -35,6 +35,8 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, precision=16),     # conv_head.hip <7>: ragged 8x16 tiles, tanh
     dict(N=1, H=17, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1, precision=16),   # conv_head.hip <3>: four 32-channel chunks, ragged 8x32 tiles
     dict(N=1, H=9, W=20, segs=[(16, 0)], Cout=3, KS=7, act=1, precision=16),                # conv_head.hip <7>: half-filled chunk (reduced model: 16 -> 3)
+    dict(N=2, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, precision=16, dgrad_precision=17, dgrad_tol=1e-4),      # ... + its dgrad on k_head_dgrad7<2> (split bf16, K = one tap row)
+    dict(N=1, H=9, W=20, segs=[(16, 0)], Cout=3, KS=7, act=1, precision=16, dgrad_precision=17, dgrad_tol=1e-4),                  # k_head_dgrad7<1>
 ])
 def test_conv(kw):
     K.conv_case(load_emu(), "cpu", **kw)

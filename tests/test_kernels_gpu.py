@@ -42,6 +42,8 @@ def lib():
     dict(N=2, H=33, W=75, segs=[(64, 0)], Cout=3, KS=3, bias=True, act=1, precision=16, tol=5e-5),      # conv_head.hip <3>, two chunks, ragged tiles
     dict(N=1, H=17, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1, precision=16, tol=5e-5),     # conv_head.hip <3>, four chunks
     dict(N=1, H=9, W=20, segs=[(16, 0)], Cout=3, KS=7, act=1, precision=16),                            # conv_head.hip <7>, half-filled chunk
+    dict(N=2, H=64, W=80, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, precision=16, tol=5e-5, dgrad_precision=17, dgrad_tol=1e-4),      # ... + dgrad on k_head_dgrad7<2> (split bf16)
+    dict(N=1, H=37, W=45, segs=[(16, 0)], Cout=3, KS=7, act=1, precision=16, dgrad_precision=17, dgrad_tol=1e-4),                            # k_head_dgrad7<1>, ragged tiles
     dict(N=8, H=128, W=160, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, precision=16, tol=5e-5),     # conv_head.hip <7>, eight frames of a training step
     dict(N=1, H=64, W=64, segs=[(20, 0)], Cout=16, KS=3),                      # narrow conv <2,1>; dgrad <1,2>; wgrad <2,1>
     dict(N=1, H=65, W=66, segs=[(16, 0)], Cout=29, KS=3),                      # narrow wgrad <1,2>, ragged tiles, channel tail
