@@ -708,11 +708,15 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     if (force_big >= 0) big = bn == 128 && force_big == 1;
     // narrower layers: 16x16-pixel tiles, or 8x16 when those would leave CUs idle (E / A on one time step's frames, R's side branches)
     const bool small_tiles = bn < 128 && force_big != 1 && (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 16) * (a.Cout_pad / bn) < 384;      // (tests force the well-filled variants with 1)
-    // inference launches (ConvArgs.direct_ok) whose 8x16 x 64-channel grid is under-filled (< 200 workgroups: it would be split over K): 4x16-pixel tiles -- twice the
+    // inference launches (ConvArgs.direct_ok) and gradient launches whose 8x16 x 64-channel grid is under-filled (< 200 workgroups: it would be split over K): 4x16-pixel tiles -- twice the
     // workgroups from the pixel side, half the K slices and slabs (D's 128x128 layers of a batch-1 roll-out frame run unsplit: 256 workgroups of 18 - 36 steps, no slab
     // reduce).  Measured, roll-out: only where 4x16 tiles reach 200 workgroups 2012 -> 2067 frames/s, for every under-filled launch 2144.
     const long blocks8 = (long)a.N * cdiv(a.W, 16) * cdiv(a.H, 8) * (a.Cout_pad / bn);
-    const bool th4 = a.direct_ok && bn == 64 && small_tiles && a.precision == PREC_F16X3 && !a.pool_out && !a.skip_out && !a.mask && !a.stats && !a.accumulate && blocks8 < 200;
+    // The same for the under-filled split-bf16 launches of a training step (dgrads of E / A / R's small maps: fewer K slices = fewer atomics / slabs): E/R/A/D step
+    // 66.73 / 66.79 -> 66.37 / 66.46 ms.  (Not the training FORWARD: a different K slicing changes its summation order, and the parity bounds of the closed-loop forward are
+    // calibrated on the 8x16 form.)
+    const bool th4 = bn == 64 && small_tiles && !a.pool_out && !a.skip_out && !a.mask && !a.stats && blocks8 < 200 &&
+                     ((a.direct_ok && a.precision == PREC_F16X3 && !a.accumulate) || a.precision == PREC_BF16X3);
     const int th = th4 ? 4 : ((bn == 128 && !big) || small_tiles) ? 8 : 16;
     const int tx = cdiv(a.W, 16), ty = cdiv(a.H, th);
     const long blocks = (long)a.N * tx * ty * (a.Cout_pad / bn);
@@ -756,7 +760,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         constexpr int D_ = NPL_ == 2 ? 3 : 1;                                                                                     \
         if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_>), grid, dim3(512), 0, st, a, tx, ty);    \
         else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (th4) hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 4, 16, 64, 2, 2, 3, 0>), grid, dim3(256), 0, st, a, tx, ty);       /* (split f16, plain epilogue only) */ \
+        else if (th4) hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0>), grid, dim3(256), 0, st, a, tx, ty);       /* (plain epilogue only) */ \
         else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
         else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);    \
         else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty); \

@@ -192,6 +192,7 @@ def test_folded_inference_epilogues(lib):
     dict(N=2, H=128, W=128, segs=[(64, False)], Cout=128, dgrad_seg=0, mask=True, seed_w=2e-7),                    # ... + L1 seed of a tapped map
     dict(N=2, H=64, W=64, segs=[(256, False)], Cout=256, dgrad_seg=0, mask=True, precision=19),
     dict(N=4, H=16, W=16, segs=[(256, False)], Cout=128, dgrad_seg=0, split=True),                                 # assigning dgrad, slab split-K
+    dict(N=8, H=64, W=64, segs=[(64, False)], Cout=64, dgrad_seg=0, accumulate=True),                              # 256 workgroups of 8x16 pixels (smaller grids take the 4x16 tiles since round 4)
 ])
 def test_conv_hx_dgrad(lib, kw):
     kw = dict(kw)
