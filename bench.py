@@ -209,7 +209,10 @@ def main():
     ap.add_argument("--no-perceptual", action="store_true", help="A/B aid: drop the VGG19 perceptual term (the reported step then says so)")
     ap.add_argument("--no-plugin", action="store_true", help="skip the leg that times the plugin path (model / trainer factories + train_epoch)")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the contract's timed region (+ profiled steps): no erad_only / exact-fp32 / plugin legs")
+    ap.add_argument("--quick", action="store_true", help="A/B aid: the timed region + the erad_only leg; no exact-fp32 / deterministic / plugin / roll-out legs")
     a = ap.parse_args()
+    if a.quick:
+        a.no_plugin = a.no_rollout = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
@@ -402,7 +405,8 @@ def run(a, dev, lib=None, backend="nccl"):
 
     # ---- the same full step on the exact-fp32 kernels (what `dtype: f32` would cost without the split-operand scheme) ----
     ms_exact = None
-    if extra and world == 1 and on_gpu:
+    quick = getattr(a, "quick", False)
+    if extra and world == 1 and on_gpu and not quick:
         eng.set_precision(0, 0)
         if perc:
             eng.set_vgg_precision(0, 0)
@@ -413,7 +417,7 @@ def run(a, dev, lib=None, backend="nccl"):
             eng.set_vgg_precision(16, 17)
         log(f"exact-fp32 kernels: {ms_exact:.1f} ms/step")
     ms_det = ms_det_erad = None      # the bit-reproducible backward (caddy_set_deterministic): what it costs, full step and E/R/A/D-only step
-    if extra and world == 1 and on_gpu:
+    if extra and world == 1 and on_gpu and not quick:
         eng.set_deterministic(True)
         step()
         ms_det, _ = timed(max(2, a.steps // 4))

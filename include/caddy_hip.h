@@ -239,6 +239,9 @@ int caddy_debug_count(caddy_ctx* ctx);
 int caddy_debug_fusion_counts(caddy_ctx* ctx, long* out3);
 /* tests / A-B: which BatchNorm paths the driver may pick (all default to 1): the one-launch kernel for tiny maps, the lazily applied form, statistics from the conv epilogue */
 int caddy_debug_set_bn_paths(caddy_ctx* ctx, int small, int lazy, int epilogue_stats);
+/* tests / A-B runs: 0 keeps every VGG19 feature map of the perceptual loss (training/losses.py:379-491, model/layers/vgg.py:20-36) as an fp32 tensor; 1 (default) lets well-filled
+ * layers exchange them pre-split for the 16-bit matrix pipe ("S16" tensors, csrc/common.h).  Same convolution results bit for bit; the feature L1 sees hi + lo (2^-22 relative). */
+int caddy_debug_set_vgg_s16(caddy_ctx* ctx, int on);
 int caddy_debug_set_pack_merged(caddy_ctx* ctx, int on);      /* tests: 0 = one (un)packing launch per layer and form instead of the job-table launch */
 int caddy_debug_dims(caddy_ctx* ctx, int i, int* nhwc4);
 int caddy_debug_get(caddy_ctx* ctx, int i, int grad, float* dst_nchw);

@@ -110,6 +110,14 @@ struct ConvArgs {
     // Roll-out ConvLSTM cells: when the launch is split over K, its slab reduce applies the cell update itself (LstmFuse, host pointer; null otherwise) and sets
     // g_last_conv_lstm_fused -- the caller then skips its point-wise LSTM kernel.  Launch paths without a slab reduce ignore it.
     const struct LstmFuse* lstm;
+    // "S16" tensors (round 5): an activation stored PRE-SPLIT for the 16-bit matrix pipe.  Same geometry and footprint as the fp32 NHWC tensor (4 bytes per element, C a
+    // multiple of 32), but every pixel's 32-channel chunk holds [hi x 32 | lo x 32] 16-bit halves (hi = round16(x), lo = round16(x - hi); f16 for forward activations, bf16 for
+    // gradients) -- exactly the LDS row k_conv_hx stages, so that a consumer copies it instead of converting every halo element in every output-channel block.  Understood by the
+    // k_conv_hx instances conv_hx_s16_ok() selects and by the VGG19 point-wise kernels (perceptual.hip); the caller asks conv_hx_s16_ok() before it sets any of these.
+    int in_s16;             // src[0] (the only segment, no lazy BatchNorm) is S16 of the launch's operand type
+    int out_s16;            // `out` is written as S16 (no accumulate, no split-K)
+    int pool_s16;           // `pool_out` is written as S16 (requires out_s16 semantics of the epilogue: set together with or without out_s16)
+    int mask_s16, seed_s16; // `mask` / `seed_ref` are S16-f16 tensors
 };
 // gates = [i | f | o | g] x C pre-activations (convolutional_lstm_cell.py:92-101): c' = sigm(f) c + sigm(i) tanh(g), h' = sigm(o) tanh(c'), hb = h' * scale + shift (the cell's
 // eval-mode BatchNorm, conv_dynamics_network.py); all tensors NHWC with their own sample / pixel pitches
@@ -176,6 +184,7 @@ int conv_pick_bn(int cout);
 struct PackDesc;
 int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_hx_try(const ConvArgs& a, hipStream_t st);
+bool conv_hx_s16_ok(int N, int H, int W, int Cout);       // ... on a tile variant that reads / writes S16 tensors (ConvArgs.in_s16 / out_s16)?  (the same two well-filled variants)
 bool conv_hx_pool_ok(int N, int H, int W, int Cout);      // will conv_hx_try run this geometry on a tile variant with the fused max-pool epilogue?           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
 int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward form, else dgrad form of that input segment */, int precision, hipStream_t st);
 size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);

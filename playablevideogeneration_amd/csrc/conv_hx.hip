@@ -43,6 +43,26 @@ struct SegRefH { const float* p; long sn; int ld; int C; int bcast; int c0; int 
 template <typename T> struct is_bf16 { static constexpr bool value = false; };
 template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 
+// ---- S16 activation format (common.h): helpers of the SO epilogue / S16 mask reads ----
+template <typename T> __device__ __forceinline__ unsigned s16_bits(T h) { unsigned short s; __builtin_memcpy(&s, &h, 2); return s; }
+// value -> dword to store by this lane: the lanes (c, c + 1) of a channel pair exchange halves, the even lane stores [hi(c) | hi(c + 1)] into the chunk's hi block, the odd
+// lane [lo(c - 1) | lo(c)] into its lo block -- one dword store per lane, as for fp32 output.  Must be executed by both lanes of a pair.
+template <typename T> __device__ __forceinline__ unsigned s16_pair(float v, int lane) {
+    const T hi = (T)v;
+    const T lo = (T)(v - (float)hi);
+    const unsigned u = s16_bits(hi) | (s16_bits(lo) << 16);
+    const unsigned w = (unsigned)__builtin_amdgcn_mov_dpp((int)u, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xF, 0xF, true);
+    return (lane & 1) ? ((w >> 16) | (u & 0xffff0000u)) : ((u & 0xffffu) | (w << 16));
+}
+// dword slot of channel `col` inside its pixel row for the store above: chunk base + (c >> 1), odd lanes 16 dwords further (the lo block)
+__device__ __forceinline__ int s16_slot(int col) { return (col & ~31) | ((col & 31) >> 1) | ((col & 1) << 4); }
+// reads of an S16-f16 tensor at (pixel row base in floats, channel): the high half alone (sign / zero test: hi == 0 implies lo == 0) or the value hi + lo
+__device__ __forceinline__ float s16_hi(const float* row, int col) { return (float)reinterpret_cast<const _Float16*>(row + (col & ~31))[col & 31]; }
+__device__ __forceinline__ float s16_val(const float* row, int col) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(row + (col & ~31));
+    return (float)h[col & 31] + (float)h[32 + (col & 31)];
+}
+
 // T: _Float16 / __bf16.  NPL planes staged (2: hi + lo, 3 products; 1: hi only).  Tile TH x TW pixels x BN output channels, WM x WN waves
 // (4 or 8), each owning a (BM / WM) x (BN / WN) sub-tile.  D = depth of the register ring of weight tiles: the tile of step s + D is
 // requested while step s computes (D = 1: next step only; D = 3: ~1.9 us of latency tolerance at 8 waves -- the weights of a 512-channel
@@ -54,12 +74,17 @@ template <> struct is_bf16<__bf16> { static constexpr bool value = true; };
 // instance the batch-1 roll-out ran 7 % slower).  0: bias / residual / ReLU / LeakyReLU / accumulate / split-K -- everything the model's layers need;
 // 1: + fused 2x2 max-pool (ConvArgs.pool_out) and write-less mode (skip_out) of the VGG19 layers in front of a pool; 2: + ReLU mask / L1 seed of the
 // VGG19 dgrad chain (ConvArgs.mask, seed_ref); 3: both (single-product study variants).  tanh (FinalBlocks) is not an hx epilogue at all.
-template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, int EP = 0>
+// IO (round 5): operand formats at the kernel boundary.  bit 0 (PS): the input segment is PRE-SPLIT ("S16", common.h) -- the staging is a plain 16-byte copy per lane, no
+// conversion, no range guard (the producer applied it).  bit 1 (SO): the epilogue writes `out` / `pool_out` as S16 of T -- split once per OUTPUT element instead of once
+// per staged halo element in every output-channel block of every consumer (the 512-channel VGG19 layers staged and converted each halo tile four times).
+template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, int EP = 0, int IO = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
     constexpr int NT = 64 * WM * WN;                         // threads
     constexpr bool E_POOL = EP == 1 || EP == 3, E_MASK = EP == 2 || EP == 3;
+    constexpr bool PS = (IO & 1) != 0, SO = (IO & 2) != 0;
+    static_assert(!(PS || SO) || NPL == 2, "S16 tensors carry both halves");
     constexpr int BM = TH * TW;
     constexpr int HW_ = TW + 2, HH_ = TH + 2, HPX = HW_ * HH_;
     constexpr int PITCH = NPL * KC + 8;                      // LDS row pitch in 16-bit elements: 72 (144 B) or 40 (80 B)
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         const int hy = p / HW_, hx = p - hy * HW_;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         pixoff[i] = (p < HPX && y >= 0 && y < a.H && x >= 0 && x < a.W) ? y * a.W + x : -1;
-        aoff[i] = hy * AROW + hx * PITCH + 4 * q;
+        aoff[i] = hy * AROW + hx * PITCH + (PS ? 8 : 4) * q;      // (PS: lane q carries 16 bytes = 8 halves of the pixel's [hi 32 | lo 32] row)
     }
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
@@ -129,6 +154,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // later, so that nothing waits for these loads while the taps of the current chunk run)
 #define HX_LOAD_A(chunk_)                                                                                                          \
     do {                                                                                                                           \
+        if (PS) {       /* pre-split input (one segment, C a multiple of 32): pixel row of the chunk = 128 contiguous bytes [hi 32 | lo 32] */ \
+            const float* base_ = a.src[0].p + (long)n * a.src[0].sn + (chunk_) * KC + 4 * q;                                      \
+            const int pl_ = a.src[0].ld;                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < NA; i++)                                                                        \
+                ra[i] = *reinterpret_cast<const float4*>(base_ + (long)(pixoff[i] >= 0 ? pixoff[i] : 0) * pl_);                   \
+            break;                                                                                                                 \
+        }                                                                                                                          \
         HX_SEG_OF(chunk_)                                                                                                          \
         const float* base_ = sg_.p + (long)n * sg_.sn + (cok_ ? c_ : 0);                                                          \
         const int pl_ = sg_.bcast ? 0 : sg_.ld;                                                                                   \
@@ -141,6 +173,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     } while (0)
 #define HX_STORE_A(chunk_)                                                                                                          \
     do {                                                                                                                           \
+        if (PS) {       /* 16-byte copy (zero padding outside the image) */                                                        \
+            _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                                      \
+                const int p_ = tp + APP * i;                                                                                      \
+                if (HPX % APP == 0 || p_ < HPX) {                                                                                  \
+                    float4 v_ = ra[i];                                                                                             \
+                    if (pixoff[i] < 0) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+                    *reinterpret_cast<float4*>(&As[aoff[i]]) = v_;                                                                 \
+                }                                                                                                                  \
+            }                                                                                                                      \
+            break;                                                                                                                 \
+        }                                                                                                                          \
         HX_SEG_OF(chunk_)                                                                                                          \
         const bool m1_ = c_ + 1 < sg_.C, m2_ = c_ + 2 < sg_.C, m3_ = c_ + 3 < sg_.C;                                              \
         const bool bn_ = sg_.bn_scale != nullptr;               /* wave-uniform */                                                \
@@ -270,10 +313,99 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     }
 
     if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);      // (rare: one atomic per saturating thread)
+    unsigned amax_o = 0u;                                     // SO, split f16: the same guard on what this launch stores
     // ---- epilogue: D fragment map col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile) ----
     float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
 #pragma unroll
     for (int j = 0; j < TNt; j++) { st1[j] = 0.f; st2[j] = 0.f; }
+    // ---- fast epilogues (round 5).  The general loop below tests the launch-uniform modes (split-K, residual, accumulate, mask, tile clipping) per VALUE inside fully unrolled
+    // loops with 64-bit addresses: ~10 000 instructions with ~1000 branches per instance, and the mask reads of the VGG19 dgrads were one dependent load + wait per value -- all of it
+    // exposed (one workgroup per CU: nothing overlaps an epilogue).  Whole-K, assigning, residual-free launches on tiles that lie inside the image -- every well-filled launch of the
+    // step -- take straight-line code instead: wave-uniform base pointers + 32-bit byte offsets (one add per value), activation as a slope select, the 16 mask / seed values of a
+    // 32 x 32 block requested back to back before the first one is used.
+    const int wm_u = __builtin_amdgcn_readfirstlane(wave) / WN;      // (wave-uniform copy: keeps the row arithmetic on the scalar unit)
+    constexpr int RW = BM / WM / TW;                          // tile rows per wave
+    const bool whole = a.splitk == 1 && a.res == nullptr && !a.accumulate && y0 + TH <= a.H && x0 + TW <= a.W && (long)a.H * a.W * a.out_ld < (1L << 30);      // workgroup-uniform
+    bool fast_done = false;
+    if (whole) {
+        fast_done = true;
+        const bool masked = E_MASK && a.mask != nullptr;
+        char* const op = reinterpret_cast<char*>(a.out + (long)n * a.out_sn);
+        const char* const mp = masked ? reinterpret_cast<const char*>(a.mask + (long)n * a.out_sn) : nullptr;
+        const char* const sp = (masked && a.seed_ref) ? reinterpret_cast<const char*>(a.seed_ref + (long)n * a.out_sn) : nullptr;
+        const unsigned ldb = (unsigned)a.out_ld * 4u, wldb = (unsigned)a.W * ldb;
+        const unsigned pbase = (unsigned)((y0 + wm_u * RW) * a.W + x0 + 4 * (lane >> 5)) * ldb;      // this lane's first pixel (bytes; one sample stays below 4 GB: the launcher checks)
+        const float osc = a.out_scale, slope = a.act == 2 ? 0.f : (a.act == 3 ? 0.2f : 1.f), sw = a.seed_w;
+        const bool store_full = !E_POOL || !a.skip_out;
+        const int ms16 = a.mask_s16, ss16 = a.seed_s16;
+#pragma unroll
+        for (int j = 0; j < TNt; j++) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (col < a.Cout) {                              // (lane-divergent only on the padded tail of a layer whose width is no multiple of 32; never with S16 tensors)
+                const float bv = a.bias ? a.bias[col] : 0.f;
+                const unsigned cb = pbase + (SO ? (unsigned)s16_slot(col) : (unsigned)col) * 4u;
+                const unsigned mb = pbase + (ms16 ? (unsigned)(col & ~31) * 4u + (unsigned)(col & 31) * 2u : (unsigned)col * 4u);      // S16 tensors: the high half of channel col
+                const unsigned sb = pbase + (ss16 ? (unsigned)(col & ~31) * 4u + (unsigned)(col & 31) * 2u : (unsigned)col * 4u);
+#pragma unroll
+                for (int i = 0; i < TMt; i++) {
+                    float mk[16], sd[16];
+                    if (masked) {                             // requested back to back, consumed below
+                        if (!ms16) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) mk[r] = *reinterpret_cast<const float*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
+                        } else if (sp == nullptr) {           // sign / zero test only: the high half decides (hi == 0 implies lo == 0)
+#pragma unroll
+                            for (int r = 0; r < 16; r++) mk[r] = (float)*reinterpret_cast<const _Float16*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
+                                                           mk[r] = (float)h_[0] + (float)h_[32]; }
+                        }
+                        if (sp != nullptr) {
+                            if (!ss16) {
+#pragma unroll
+                                for (int r = 0; r < 16; r++) sd[r] = *reinterpret_cast<const float*>(sp + (sb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(sp + (sb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
+                                                               sd[r] = (float)h_[0] + (float)h_[32]; }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float v = acc[i][j][r] * osc + bv;
+                        v = v > 0.f ? v : slope * v;
+                        if (masked) {
+                            if (sp != nullptr) { const float d_ = mk[r] - sd[r]; v += d_ > 0.f ? sw : (d_ < 0.f ? -sw : 0.f); }
+                            v = mk[r] > 0.f ? v : 0.f;
+                        }
+                        if (EP == 0) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
+                        const unsigned o_ = cb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb;
+                        if (SO) {
+                            if (!is_bf16<T>::value) { amax_o = max(amax_o, __float_as_uint(v) & 0x7fffffffu); v = __builtin_amdgcn_fmed3f(v, -HX_F16_MAX, HX_F16_MAX); }
+                            const unsigned w_ = s16_pair<T>(v, lane);
+                            if (store_full) *reinterpret_cast<unsigned*>(op + o_) = w_;
+                        } else if (store_full) *reinterpret_cast<float*>(op + o_) = v;
+                        if (E_POOL) acc[i][j][r] = v;
+                    }
+                    if (E_POOL && a.pool_out) {      // 2x2 max of the activated values (see the general loop); an interior tile has no clipped windows
+                        char* const pp = reinterpret_cast<char*>(a.pool_out + (long)n * a.pool_sn);
+                        const unsigned plb = (unsigned)a.pool_ld * 4u;
+                        const unsigned pb0 = (unsigned)(((y0 + wm_u * RW + i * 2) >> 1) * (a.W >> 1) + ((x0 + 4 * (lane >> 5)) >> 1)) * plb + ((SO && a.pool_s16) ? (unsigned)s16_slot(col) : (unsigned)col) * 4u;
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) {
+                            const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
+                            const unsigned po_ = pb0 + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) >> 1) * plb;
+                            if (SO && a.pool_s16) *reinterpret_cast<unsigned*>(pp + po_) = s16_pair<T>(mx, lane);
+                            else *reinterpret_cast<float*>(pp + po_) = mx;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!fast_done)
 #pragma unroll
     for (int j = 0; j < TNt; j++) {
         const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -296,14 +428,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 if (a.res) v += a.res[(long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + col];
                 if (a.act == 2) v = fmaxf(v, 0.f);
                 else if (a.act == 3) v = v > 0.f ? v : 0.2f * v;
-                if (E_MASK && a.mask) {
-                    const float mk = a.mask[off];
-                    if (a.seed_ref) { const float d = mk - a.seed_ref[off]; v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
+                if (E_MASK && a.mask) {      // (mask / seed_ref: geometry of `out`; S16-f16 tensors of the forward pass when ConvArgs.mask_s16 / seed_s16)
+                    const float* mrow = a.mask + (off - col);
+                    const bool need_val = a.seed_ref != nullptr;
+                    const float mk = a.mask_s16 ? (need_val ? s16_val(mrow, col) : s16_hi(mrow, col)) : mrow[col];
+                    if (a.seed_ref) { const float* srow = a.seed_ref + (off - col);
+                                      const float d = mk - (a.seed_s16 ? s16_val(srow, col) : srow[col]); v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
                     v = mk > 0.f ? v : 0.f;
                 }
                 if (a.accumulate) v += a.out[off];
                 if (EP == 0) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
-                if (!E_POOL || !a.skip_out) a.out[off] = v;
+                if (SO) {       // S16 output: range guard (f16) + split here, once per output element
+                    if (!is_bf16<T>::value) { amax_o = max(amax_o, __float_as_uint(v) & 0x7fffffffu); v = __builtin_amdgcn_fmed3f(v, -HX_F16_MAX, HX_F16_MAX); }
+                    const unsigned o_ = s16_pair<T>(v, lane);
+                    if (!E_POOL || !a.skip_out) reinterpret_cast<unsigned*>(a.out)[off - col + s16_slot(col)] = o_;
+                } else if (!E_POOL || !a.skip_out) a.out[off] = v;
                 if (E_POOL) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
             }
             if (E_POOL && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
@@ -313,11 +452,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                     const int py = (y0 + m / TW) >> 1, px = (x0 + m % TW) >> 1;
                     if (py >= (a.H >> 1) || px >= (a.W >> 1)) continue;      // floor semantics: the last row / column of an odd map belongs to no window
                     const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
-                    a.pool_out[(long)n * a.pool_sn + ((long)py * (a.W >> 1) + px) * a.pool_ld + col] = mx;
+                    const long prow = (long)n * a.pool_sn + ((long)py * (a.W >> 1) + px) * a.pool_ld;
+                    if (SO && a.pool_s16) reinterpret_cast<unsigned*>(a.pool_out)[prow + s16_slot(col)] = s16_pair<T>(mx, lane);      // (already clamped above)
+                    else a.pool_out[prow + col] = mx;
                 }
             }
         }
     }
+    if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag, 1u);
     // ---- BatchNorm partial sums of this tile: the two 32-lane halves of a wave hold different pixel rows of one channel, the WM waves of a column
     // block different rows too -> shuffle, then LDS (the staging tiles are dead), one plain store per (tile, channel): no atomics, fixed order ----
     if (EP == 0 && a.stats != nullptr) {                      // (grid-uniform; the launcher only passes it with splitk == 1)
@@ -674,6 +816,8 @@ bool conv_hx_pool_ok(int N, int H, int W, int Cout) {
     return false;
 }
 
+bool conv_hx_s16_ok(int N, int H, int W, int Cout) { return (Cout & 31) == 0 && conv_hx_pool_ok(N, H, W, Cout); }
+
 // will conv_fwd_launch hand this launch to k_conv_hx (the only forward kernel that applies ConvSrc.bn_* while staging its input)?
 bool conv_src_lazy_ok(const ConvArgs& a) {
     if (a.KS != 3 || !a.wq || a.precision < PREC_F16X3 || a.precision > PREC_BF16X1 || a.act == 1) return false;
@@ -767,6 +911,35 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);                  \
     } while (0)
     const bool vgg_bwd = a.mask != nullptr;      // ReLU mask / L1 seed epilogue (VGG19 dgrad chain): split-bf16 instances with EP = 2
+    const int io = (a.in_s16 ? 1 : 0) | ((a.out_s16 || a.pool_s16) ? 2 : 0);
+    if (io) {      // S16 tensors at the boundary: the two well-filled tile variants only (conv_hx_s16_ok), whole-K workgroups, plain or VGG19 epilogues
+        const bool wide = big || (bn == 64 && !small_tiles);
+        if (!wide || a.splitk != 1 || a.accumulate || a.res || a.stats || (a.precision != PREC_F16X3 && a.precision != PREC_BF16X3)) return -1;
+        if (a.in_s16 && (a.nsrc != 1 || (a.src[0].C & 31) || a.src[0].bcast || a.src[0].bn_scale)) return -1;
+        if ((a.out_s16 || a.pool_s16) && (a.Cout & 31)) return -1;
+        if (a.pool_out && !a.skip_out && (a.out_s16 != 0) != (a.pool_s16 != 0)) return -1;      // one epilogue format per launch
+        if (a.precision == PREC_BF16X3 && (a.pool_out || a.skip_out)) return -1;
+        if (a.precision == PREC_F16X3 && vgg_bwd) return -1;
+#define HX_IO_LAUNCH(T_, EP_)                                                                                                       \
+        do {                                                                                                                       \
+            if (big) { if (io == 1) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 128, 4, 2, 3, EP_, 1>), grid, dim3(512), 0, st, a, tx, ty);      \
+                       else if (io == 2) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 128, 4, 2, 3, EP_, 2>), grid, dim3(512), 0, st, a, tx, ty); \
+                       else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 128, 4, 2, 3, EP_, 3>), grid, dim3(512), 0, st, a, tx, ty); }            \
+            else { constexpr int D_ = EP_ == 1 ? 1 : 3;      /* (ring depths of the plain instances) */                                  \
+                   if (io == 1) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, D_, EP_, 1>), grid, dim3(256), 0, st, a, tx, ty);          \
+                   else if (io == 2) hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, D_, EP_, 2>), grid, dim3(256), 0, st, a, tx, ty);     \
+                   else hipLaunchKernelGGL((k_conv_hx<T_, 2, 16, 16, 64, 4, 1, D_, EP_, 3>), grid, dim3(256), 0, st, a, tx, ty); }                \
+        } while (0)
+        if (a.precision == PREC_F16X3) { if (a.pool_out || a.skip_out) HX_IO_LAUNCH(_Float16, 1); else HX_IO_LAUNCH(_Float16, 0); }
+        else if (vgg_bwd) HX_IO_LAUNCH(__bf16, 2);
+        else { if (io != 1) return -1;      // (dgrad of a layer behind a max-pool: its output is the fp32 gradient of the pooled map)
+               if (big) hipLaunchKernelGGL((k_conv_hx<__bf16, 2, 16, 16, 128, 4, 2, 3, 0, 1>), grid, dim3(512), 0, st, a, tx, ty);
+               else hipLaunchKernelGGL((k_conv_hx<__bf16, 2, 16, 16, 64, 4, 1, 3, 0, 1>), grid, dim3(256), 0, st, a, tx, ty); }
+#undef HX_IO_LAUNCH
+        g_last_conv_kernel = big ? CK_HX_128_8W : CK_HX_64;
+        return 1;
+    }
+    if (a.mask_s16 || a.seed_s16) { if (!vgg_bwd) return -1; }
     if (a.pool_out || a.skip_out) {      // VGG19 layers in front of a max-pool: the two tile variants those layers run on (perceptual.hip asks only when this holds)
         if (a.precision != PREC_F16X3 || !(big || (bn == 64 && !small_tiles))) return -1;
         if (big) hipLaunchKernelGGL((k_conv_hx<_Float16, 2, 16, 16, 128, 4, 2, 3, 1>), grid, dim3(512), 0, st, a, tx, ty);

@@ -1474,6 +1474,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (caddy_serial_streams()) c->use_dstream = false;
+    if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
         else if (!strcmp(e, "fwd")) { c->prec_bwd = PREC_FP32; c->vgg_precision_bwd = PREC_FP32; }
@@ -1492,6 +1493,7 @@ void caddy_ctx_destroy(caddy_ctx* c) {
 int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
 int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
 int caddy_debug_set_bn_paths(caddy_ctx* c, int small, int lazy, int epilogue_stats) { c->bn_small = small != 0; c->lazy_bn = lazy != 0; c->epi_stats = epilogue_stats != 0; return 0; }
+int caddy_debug_set_vgg_s16(caddy_ctx* c, int on) { c->vgg_s16 = on != 0; return 0; }
 int caddy_debug_set_pack_merged(caddy_ctx* c, int on) { c->merged_pack = on != 0; c->pack_jobs.key = -1; for (auto& j : c->unpack_jobs) j.key = -1; return 0; }
 int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }

@@ -22,6 +22,7 @@ struct T4 {            // activation + gradient views with identical geometry
     // lazily normalised tensor: `d` holds the RAW conv output x, the logical value is act(x * bn_scale[c] + bn_shift[c]) and is only ever formed inside the
     // consuming convolution's staging (ConvSrc.bn_*); `g` is the gradient w.r.t. the logical (normalised) value
     const float* bn_scale = nullptr; const float* bn_shift = nullptr; int bn_act = 0;
+    int fmt = 0;       // 1: `d` is an S16 tensor (common.h: pre-split 16-bit halves, same geometry / footprint) -- VGG19 feature maps only (perceptual.hip)
 };
 static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
 static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
@@ -159,6 +160,7 @@ struct caddy_ctx {
     double* red_scratch = nullptr;   // per-block partial sums of the BatchNorm reductions (RED_MAX_BLOCKS x 2 x 1024 doubles)
     VggState vgg;                    // VGG19 perceptual loss (perceptual.hip); enabled by caddy_config.perceptual
     int vgg_precision = PREC_F16X3, vgg_precision_bwd = PREC_BF16X3;   // ConvArgs.precision of the VGG convolutions (forward / dgrad); PREC_FP32 = exact
+    bool vgg_s16 = true;             // VGG19 feature maps / feature gradients of well-filled layers as S16 tensors (caddy_debug_set_vgg_s16; CADDY_VGG_S16=0)
     int prec_fwd = PREC_F16X3, prec_bwd = PREC_BF16X3;                 // ... of the model's wide 3x3 convolutions (caddy_set_precision; CADDY_PRECISION=exact)
     // ground-truth VGG19 branch overlapped with the forward pass on the side stream (perceptual.hip: vgg_gt_prefetch)
     T4 gt_img[3]{}, gt_taps[3][5]{}; size_t gt_scratch_off = 0, gt_scratch_end = 0; bool gt_prefetched = false, perc_prefetch = true; hipEvent_t gt_done = nullptr;

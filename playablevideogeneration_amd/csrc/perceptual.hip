@@ -42,6 +42,25 @@ __global__ __launch_bounds__(256) void k_maxpool2(const float* in, float* out, l
         reinterpret_cast<float4*>(out)[i] = m;
     }
 }
+// ---- S16 tensors (common.h): four consecutive channels at flat float index i4 (a multiple of 4) of a DENSE map (ld == C, C a multiple of 32) ----
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 s16_load4_f16(const float* p, long i4) {      // value = hi + lo
+    const _Float16* h = reinterpret_cast<const _Float16*>(p + (i4 & ~31L)) + (i4 & 31);
+    const f16x4_t hi = *reinterpret_cast<const f16x4_t*>(h), lo = *reinterpret_cast<const f16x4_t*>(h + 32);
+    return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+}
+__device__ __forceinline__ void s16_store4_bf16(float* p, long i4, float4 v) {      // the split of conv_hx.hip's loaders: hi = bf16(x), lo = bf16(x - hi)
+    __bf16* h = reinterpret_cast<__bf16*>(p + (i4 & ~31L)) + (i4 & 31);
+    bf16x4_t hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]); lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    *reinterpret_cast<bf16x4_t*>(h) = hi;
+    *reinterpret_cast<bf16x4_t*>(h + 32) = lo;
+}
+template <bool S> __device__ __forceinline__ float4 ld4(const float* p, long i) { return S ? s16_load4_f16(p, 4 * i) : reinterpret_cast<const float4*>(p)[i]; }
+template <bool S> __device__ __forceinline__ void st4_grad(float* p, long i, float4 v) { if (S) s16_store4_bf16(p, 4 * i, v); else reinterpret_cast<float4*>(p)[i] = v; }
+
 // gradient of [ReLU -> MaxPool2d(2,2)] in one pass: gz[pos] = g_pooled[window] if pos is the window's first maximum (torch's tie rule: strict >,
 // scan order (0,0),(0,1),(1,0),(1,1)) and a[pos] > 0, else 0.  Every position of gz is ASSIGNED (no zero-fill needed), including the
 // uncovered last row / column of odd-sized maps (zero).
@@ -53,37 +72,39 @@ __device__ __forceinline__ void route4(float a0, float a1, float a2, float a3, f
     const float v = m > 0.f ? g : 0.f;
     z0 = k == 0 ? v : 0.f; z1 = k == 1 ? v : 0.f; z2 = k == 2 ? v : 0.f; z3 = k == 3 ? v : 0.f;
 }
+// AS: `a` (the forward activation) is an S16-f16 tensor; ZS: gz is written as S16-bf16 (the operand format of the dgrad that consumes it)
+template <bool AS, bool ZS>
 __global__ __launch_bounds__(256) void k_maxpool2_bwd_relu(const float* a, const float* gp, float* gz, long n_win4, int Hi, int Wi, int C4) {
     const int Ho = Hi >> 1, Wo = Wi >> 1, Hc = (Hi + 1) >> 1, Wc = (Wi + 1) >> 1;      // windows incl. the partial ones of odd sizes
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n_win4; i += (long)gridDim.x * 256) {
         int c = (int)(i % C4); long q = i / C4; int x = (int)(q % Wc); q /= Wc; int y = (int)(q % Hc); long n = q / Hc;
         const long base = ((n * Hi + 2 * y) * (long)Wi + 2 * x) * C4 + c;
         const long o1 = C4, o2 = (long)Wi * C4, o3 = o2 + C4;
-        float4* z = reinterpret_cast<float4*>(gz) + base;
         if (y >= Ho || x >= Wo) {      // partial window: no pooled output reads these positions
             const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            z[0] = zero;
-            if (2 * x + 1 < Wi) z[o1] = zero;
-            if (2 * y + 1 < Hi) { z[o2] = zero; if (2 * x + 1 < Wi) z[o3] = zero; }
+            st4_grad<ZS>(gz, base, zero);
+            if (2 * x + 1 < Wi) st4_grad<ZS>(gz, base + o1, zero);
+            if (2 * y + 1 < Hi) { st4_grad<ZS>(gz, base + o2, zero); if (2 * x + 1 < Wi) st4_grad<ZS>(gz, base + o3, zero); }
             continue;
         }
-        const float4* p = reinterpret_cast<const float4*>(a) + base;
-        const float4 A = p[0], B = p[o1], D = p[o2], E = p[o3], G = reinterpret_cast<const float4*>(gp)[((n * Ho + y) * (long)Wo + x) * C4 + c];
+        const float4 A = ld4<AS>(a, base), B = ld4<AS>(a, base + o1), D = ld4<AS>(a, base + o2), E = ld4<AS>(a, base + o3);
+        const float4 G = reinterpret_cast<const float4*>(gp)[((n * Ho + y) * (long)Wo + x) * C4 + c];
         float4 zA, zB, zD, zE;
         route4(A.x, B.x, D.x, E.x, G.x, zA.x, zB.x, zD.x, zE.x);
         route4(A.y, B.y, D.y, E.y, G.y, zA.y, zB.y, zD.y, zE.y);
         route4(A.z, B.z, D.z, E.z, G.z, zA.z, zB.z, zD.z, zE.z);
         route4(A.w, B.w, D.w, E.w, G.w, zA.w, zB.w, zD.w, zE.w);
-        z[0] = zA; z[o1] = zB; z[o2] = zD; z[o3] = zE;
+        st4_grad<ZS>(gz, base, zA); st4_grad<ZS>(gz, base + o1, zB); st4_grad<ZS>(gz, base + o2, zD); st4_grad<ZS>(gz, base + o3, zE);
     }
 }
 // sum |f_rec - f_gt| over a dense feature map (double atomics per block); optionally the masked L1 seed of the top level:
-// gz = seed_w * sign(f_rec - f_gt) where f_rec > 0 (the ReLU that produced f_rec), else 0
+// gz = seed_w * sign(f_rec - f_gt) where f_rec > 0 (the ReLU that produced f_rec), else 0.  RS / GS: rec / gt are S16-f16 tensors; ZS: gz is written as S16-bf16
+template <bool RS, bool GS, bool ZS>
 __global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* gt, long n4, float seed_w, float* gz, double* acc) {
     __shared__ double sh[4];
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const float4 r = reinterpret_cast<const float4*>(rec)[i], g = reinterpret_cast<const float4*>(gt)[i];
+        const float4 r = ld4<RS>(rec, i), g = ld4<GS>(gt, i);
         const float d[4] = {r.x - g.x, r.y - g.y, r.z - g.z, r.w - g.w};
         const float rv[4] = {r.x, r.y, r.z, r.w};
         float z[4];
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* 
             s += (double)fabsf(d[e]);
             z[e] = rv[e] > 0.f ? (d[e] > 0.f ? seed_w : (d[e] < 0.f ? -seed_w : 0.f)) : 0.f;
         }
-        if (gz) reinterpret_cast<float4*>(gz)[i] = make_float4(z[0], z[1], z[2], z[3]);
+        if (gz) st4_grad<ZS>(gz, i, make_float4(z[0], z[1], z[2], z[3]));
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -100,13 +121,14 @@ __global__ __launch_bounds__(256) void k_feat_l1(const float* rec, const float* 
     if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 // per IMAGE: acc[n] += sum |f_rec - f_gt| over image n's feature map (blockIdx.y = image); the evaluator's per-position perceptual loss (evaluation/evaluator.py:193)
+template <bool RS, bool GS>
 __global__ __launch_bounds__(256) void k_feat_l1_img(const float* rec, const float* gt, long n4_img, double* acc) {
     __shared__ double sh[4];
-    const float4* r4 = reinterpret_cast<const float4*>(rec) + (long)blockIdx.y * n4_img;
-    const float4* g4 = reinterpret_cast<const float4*>(gt) + (long)blockIdx.y * n4_img;
+    const float* r4 = rec + 4 * (long)blockIdx.y * n4_img;
+    const float* g4 = gt + 4 * (long)blockIdx.y * n4_img;
     double s = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4_img; i += (long)gridDim.x * 256) {
-        const float4 r = r4[i], g = g4[i];
+        const float4 r = ld4<RS>(r4, i), g = ld4<GS>(g4, i);
         s += (double)fabsf(r.x - g.x) + (double)fabsf(r.y - g.y) + (double)fabsf(r.z - g.z) + (double)fabsf(r.w - g.w);
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -143,6 +165,42 @@ T4 valloc(caddy_ctx* c, int N, int H, int W, int C) {      // bottom-up allocati
     const int ld = round_up(C, 4);
     float* d = (float*)c->act.alloc((size_t)N * H * W * ld * 4);
     return T4{d, (float*)((char*)d + c->grad_delta), N, H, W, C, (long)H * W * ld, ld, true};
+}
+// format dispatch of the point-wise kernels (S16 flags -> template instances)
+void launch_feat_l1(hipStream_t st, const T4& rec, const T4& gt, float seed_w, float* gz, bool gz_s16, double* acc) {
+    const long n4 = (long)rec.N * rec.H * rec.W * (rec.C / 4);
+    const dim3 g(grid_for(n4)), b(256);
+    const int k = (rec.fmt ? 4 : 0) | (gt.fmt ? 2 : 0) | ((gz && gz_s16) ? 1 : 0);
+    const float* r = rec.d; const float* t = gt.d;
+    switch (k) {
+        case 0: hipLaunchKernelGGL((k_feat_l1<false, false, false>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 1: hipLaunchKernelGGL((k_feat_l1<false, false, true>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 2: hipLaunchKernelGGL((k_feat_l1<false, true, false>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 3: hipLaunchKernelGGL((k_feat_l1<false, true, true>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 4: hipLaunchKernelGGL((k_feat_l1<true, false, false>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 5: hipLaunchKernelGGL((k_feat_l1<true, false, true>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        case 6: hipLaunchKernelGGL((k_feat_l1<true, true, false>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+        default: hipLaunchKernelGGL((k_feat_l1<true, true, true>), g, b, 0, st, r, t, n4, seed_w, gz, acc); break;
+    }
+}
+void launch_feat_l1_img(hipStream_t st, const T4& rec, const T4& gt, double* acc) {
+    const long n4 = (long)rec.H * rec.W * (rec.C / 4);
+    const unsigned bx = (unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 64 ? 64 : n4 / 1024));
+    const dim3 g(bx, rec.N), b(256);
+    const float* r = rec.d; const float* t = gt.d;
+    if (rec.fmt && gt.fmt) hipLaunchKernelGGL((k_feat_l1_img<true, true>), g, b, 0, st, r, t, n4, acc);
+    else if (rec.fmt) hipLaunchKernelGGL((k_feat_l1_img<true, false>), g, b, 0, st, r, t, n4, acc);
+    else if (gt.fmt) hipLaunchKernelGGL((k_feat_l1_img<false, true>), g, b, 0, st, r, t, n4, acc);
+    else hipLaunchKernelGGL((k_feat_l1_img<false, false>), g, b, 0, st, r, t, n4, acc);
+}
+void launch_maxpool_bwd(hipStream_t st, const T4& pre, const float* gp, bool gz_s16) {
+    const long n4 = (long)pre.N * ((pre.H + 1) / 2) * ((pre.W + 1) / 2) * (pre.C / 4);
+    const dim3 g(grid_for(n4)), b(256);
+    const float* a = pre.d;
+    if (pre.fmt && gz_s16) hipLaunchKernelGGL((k_maxpool2_bwd_relu<true, true>), g, b, 0, st, a, gp, pre.g, n4, pre.H, pre.W, pre.C / 4);
+    else if (pre.fmt) hipLaunchKernelGGL((k_maxpool2_bwd_relu<true, false>), g, b, 0, st, a, gp, pre.g, n4, pre.H, pre.W, pre.C / 4);
+    else if (gz_s16) hipLaunchKernelGGL((k_maxpool2_bwd_relu<false, true>), g, b, 0, st, a, gp, pre.g, n4, pre.H, pre.W, pre.C / 4);
+    else hipLaunchKernelGGL((k_maxpool2_bwd_relu<false, false>), g, b, 0, st, a, gp, pre.g, n4, pre.H, pre.W, pre.C / 4);
 }
 }  // namespace
 
@@ -230,7 +288,16 @@ int conv_call(caddy_ctx* c, const ConvArgs& a, double flops, int kind) {
     c->prof_kind_override = save;
     return rc;
 }
-// 13 x (conv3x3 + bias + ReLU) with the 2x2 max-pools; taps[] (if given) receive the five tapped feature maps in place
+// does the context keep VGG19 feature maps / feature gradients of well-filled layers as S16 tensors?  (both passes on the split-operand kernels: an exact-fp32 pass would have to
+// read them)
+bool vgg_use_s16(const caddy_ctx* c) { return c->vgg_s16 && c->vgg_precision == PREC_F16X3 && c->vgg_precision_bwd == PREC_BF16X3; }
+// is conv i's launch on an N x H x W input one of the k_conv_hx variants that read / write S16 tensors?
+bool vgg_io_ok(const caddy_ctx* c, int i, int N, int H, int W) { return vgg_use_s16(c) && VGG[i].cin >= 32 && conv_hx_s16_ok(N, H, W, VGG[i].cout); }
+
+// 13 x (conv3x3 + bias + ReLU) with the 2x2 max-pools; taps[] (if given) receive the five tapped feature maps in place.
+// Formats (round 5): a feature map is written PRE-SPLIT (S16-f16, T4::fmt) by the epilogue of its producer when that launch and the launch of the convolution that consumes it
+// are both on the S16-capable tile variants (conv_hx_s16_ok: the well-filled ones) -- the consumer then copies operand rows instead of converting every halo element in every
+// one of its output-channel blocks; the point-wise consumers (feature L1, max-pool backward, ReLU masks) read either format.
 void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool keep_all) {
     bool dry = c->dry;
     VggState& V = c->vgg;
@@ -244,11 +311,13 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
             else {
                 T4 p = valloc(c, x.N, x.H / 2, x.W / 2, x.C);
                 const long n4 = (long)p.N * p.H * p.W * (p.C / 4);
+                if (x.fmt) { c->fail = true; set_error("internal: S16 feature map handed to the stand-alone max-pool"); }
                 if (!dry) hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(n4)), dim3(256), 0, c->stream, (const float*)x.d, p.d, n4, x.H, x.W, p.C / 4);
                 B.p[i] = p; x = p;
             }
         }
         T4 out = (taps && VGG[i].tap >= 0) ? taps[VGG[i].tap] : valloc(c, x.N, x.H, x.W, VGG[i].cout);
+        out.fmt = 0;
         ConvArgs a{};
         a.src[0] = ConvSrc{x.d, x.sn, x.ld, x.C, round_up(x.C, CONV_BK), 0};
         a.nsrc = 1; a.N = x.N; a.H = x.H; a.W = x.W; a.KS = 3; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
@@ -256,14 +325,23 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
         a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : (c->vgg_precision == PREC_BF16X3 ? PREC_BF16X3 : PREC_F16X3));
         if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : (a.precision == PREC_BF16X3 ? 2 : 0)];
         a.sat_flag = c->sat_flag;      // f16 range guard: real VGG19 weights on un-normalised inputs are where a forward activation could leave the f16 range
+        const bool io_here = vgg_io_ok(c, i, x.N, x.H, x.W);
+        const bool pool_next = i + 1 < VGG_NCONV && VGG[i + 1].pool_before;
+        a.in_s16 = x.fmt;
+        if (x.fmt && !io_here) { c->fail = true; set_error("internal: S16 input for a VGG19 launch that cannot read it"); }
         // MaxPool2d(2, 2) in front of the next conv: written by THIS conv's epilogue on the split-operand kernel (the window's four pixels sit in
         // one lane) -- no separate pass over the full-resolution map; a branch that is never back-propagated (keep_all = false: the ground truth)
         // does not even store the full-resolution map of such a layer (it is no tap: the taps are the first convs AFTER a pool)
-        if (i + 1 < VGG_NCONV && VGG[i + 1].pool_before && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && conv_hx_pool_ok(x.N, x.H, x.W, VGG[i].cout)) {
+        if (pool_next && a.wq && a.precision == PREC_F16X3 && VGG[i].cin >= 32 && conv_hx_pool_ok(x.N, x.H, x.W, VGG[i].cout)) {
             pooled = valloc(c, x.N, x.H / 2, x.W / 2, VGG[i].cout);
             a.pool_out = pooled.d; a.pool_sn = pooled.sn; a.pool_ld = pooled.ld;
             a.skip_out = (!keep_all && VGG[i].tap < 0) ? 1 : 0;
             have_pooled = true;
+            // the pooled map as S16 when its consumer (conv i + 1 on the pooled geometry) reads S16; the full-resolution map (read by the max-pool backward only) in the same format
+            if (io_here && vgg_io_ok(c, i + 1, x.N, x.H / 2, x.W / 2)) { a.pool_s16 = 1; pooled.fmt = 1; if (!a.skip_out) { a.out_s16 = 1; out.fmt = 1; } }
+        } else if (io_here && !pool_next) {
+            // consumed by conv i + 1 on the same geometry (or, for relu5_1, by the feature L1 alone)
+            if (i + 1 == VGG_NCONV || vgg_io_ok(c, i + 1, x.N, x.H, x.W)) { a.out_s16 = 1; out.fmt = 1; }
         }
         if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
         B.a[i] = out; x = out;
@@ -312,6 +390,7 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
         c->act.off = c->gt_scratch_off;                        // (host-side bump pointer only: the region is private to the side stream)
         Branch G{};
         vgg_forward(c, gi, G, c->gt_taps[r], false);
+        for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) c->gt_taps[r][VGG[i].tap].fmt = G.a[i].fmt;      // (a tapped map may be an S16 tensor)
         c->act.off = keep;
     }
     c->stream = main_st;
@@ -355,6 +434,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
             for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; }      // MaxPool2d floors odd sizes
             const size_t mark2 = c->act.off;
             vgg_forward(c, gt_img[r], G, taps, false);
+            for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) taps[VGG[i].tap].fmt = G.a[i].fmt;
             c->act.off = mark2;                  // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
         }
         vgg_forward(c, rec, R, nullptr, true);
@@ -362,17 +442,24 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
         float wl[5];
         int li[5];
         for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) li[VGG[i].tap] = i;
+        // formats of the feature gradients gz_i = d/d(pre-ReLU output of conv i), stored at the gradient mirror of a[i]: S16-bf16 when the dgrad of conv i that consumes it runs on an
+        // S16-capable launch AND its producer can write it -- the point-wise producers (feature L1 seed of relu5_1, max-pool backward) always can, the dgrad of conv i + 1 when it is
+        // such a launch itself
+        bool io_d[VGG_NCONV], gzs[VGG_NCONV];
+        for (int i = 0; i < VGG_NCONV; i++) {
+            const T4& in = VGG[i].pool_before ? R.p[i] : (i > 0 ? R.a[i - 1] : rec);
+            io_d[i] = vgg_use_s16(c) && i > 0 && V.conv[i].wqd[0] != nullptr && conv_hx_s16_ok(in.N, in.H, in.W, VGG[i].cin);
+        }
+        for (int i = 0; i < VGG_NCONV; i++) gzs[i] = io_d[i] && (i + 1 == VGG_NCONV || VGG[i + 1].pool_before || io_d[i + 1]);
         for (int l = 0; l < 5; l++) {
             const T4& f = R.a[li[l]];
             const double numel = (double)f.N * f.H * f.W * f.C;
             lv->numel[r][l] = numel;
             wl[l] = (float)(lambda * (l == 0 ? 1.0 : 2.0) / 3.0 / numel);
-            const long n4 = (long)f.N * f.H * f.W * (f.C / 4);
-            if (!dry) hipLaunchKernelGGL(k_feat_l1, dim3(grid_for(n4)), dim3(256), 0, st, (const float*)f.d, (const float*)taps[l].d, n4, wl[l],
-                                         l == 4 ? f.g : (float*)nullptr, c->loss_acc + LOSS_PERC_R0 + 6 * r + 1 + l);
+            if (!dry) launch_feat_l1(st, f, taps[l], wl[l], l == 4 ? f.g : (float*)nullptr, gzs[li[4]], c->loss_acc + LOSS_PERC_R0 + 6 * r + 1 + l);
         }
         if (lambda != 0.0) {
-            // backward of the reconstruction branch: gz_i = d/d(pre-ReLU output of conv i), stored at the gradient mirror of a[i]
+            // backward of the reconstruction branch
             for (int i = VGG_NCONV - 1; i >= 0; i--) {
                 VggLayer& L = V.conv[i];
                 const T4& gz = R.a[i];
@@ -384,16 +471,16 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 d.precision = c->vgg_precision_bwd == PREC_BF16X1 ? PREC_BF16X1 : (c->vgg_precision_bwd == PREC_FP32 ? PREC_FP32 : PREC_BF16X3);
                 if (d.precision != PREC_FP32 && L.wqd[0]) d.wq = L.wqd[d.precision == PREC_BF16X1 ? 1 : 0];
                 d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
+                d.in_s16 = gzs[i] ? 1 : 0;
                 if (i == 0) d.accumulate = 1;                                 // += into d(rec_r), next to the L1 seed
-                else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue
-                    d.mask = in.d;
-                    if (VGG[i - 1].tap >= 0) { d.seed_ref = taps[VGG[i - 1].tap].d; d.seed_w = wl[VGG[i - 1].tap]; }
+                else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue; the output IS gz_{i-1}
+                    d.mask = in.d; d.mask_s16 = in.fmt;
+                    if (VGG[i - 1].tap >= 0) { const T4& tp = taps[VGG[i - 1].tap]; d.seed_ref = tp.d; d.seed_w = wl[VGG[i - 1].tap]; d.seed_s16 = tp.fmt; }
+                    d.out_s16 = gzs[i - 1] ? 1 : 0;
                 }
                 if (!dry) c->ck(conv_call(c, d, 2.0 * in.N * in.H * in.W * 9.0 * VGG[i].cin * VGG[i].cout, 4), "vgg dgrad");
-                if (VGG[i].pool_before) {                                     // pooled input: route through the max-pool and the ReLU of a[i-1]
-                    const T4& pre = R.a[i - 1];
-                    const long n4 = (long)pre.N * ((pre.H + 1) / 2) * ((pre.W + 1) / 2) * (pre.C / 4);
-                    if (!dry) hipLaunchKernelGGL(k_maxpool2_bwd_relu, dim3(grid_for(n4)), dim3(256), 0, st, (const float*)pre.d, (const float*)in.g, pre.g, n4, pre.H, pre.W, pre.C / 4);
+                if (VGG[i].pool_before) {                                     // pooled input: route through the max-pool and the ReLU of a[i-1] (fp32 gradient of the pooled map -> gz_{i-1})
+                    if (!dry) launch_maxpool_bwd(st, R.a[i - 1], (const float*)in.g, gzs[i - 1]);
                 }
             }
         }
@@ -432,15 +519,11 @@ int vgg_eval_per_frame(caddy_ctx* c, double* out_host) {
     double* acc = c->dalloc(5 * (size_t)N);
     hipMemsetAsync(acc, 0, sizeof(double) * 5 * (size_t)N, st);
     const size_t mark2 = c->act.off;
-    { Branch G{}; vgg_forward(c, gi, G, tg, false); }
+    { Branch G{}; vgg_forward(c, gi, G, tg, false); for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) tg[VGG[i].tap].fmt = G.a[i].fmt; }
     c->act.off = mark2;
-    { Branch R{}; vgg_forward(c, rec, R, tr, false); }
+    { Branch R{}; vgg_forward(c, rec, R, tr, false); for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) tr[VGG[i].tap].fmt = R.a[i].fmt; }
     if (c->act.overflow()) { c->act.off = mark; set_error("caddy_perceptual_per_frame: workspace too small"); return -1; }
-    for (int l = 0; l < 5; l++) {
-        const long n4 = (long)tr[l].H * tr[l].W * (tr[l].C / 4);
-        const unsigned bx = (unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 64 ? 64 : n4 / 1024));
-        hipLaunchKernelGGL(k_feat_l1_img, dim3(bx, N), dim3(256), 0, st, (const float*)tr[l].d, (const float*)tg[l].d, n4, acc + (size_t)l * N);
-    }
+    for (int l = 0; l < 5; l++) launch_feat_l1_img(st, tr[l], tg[l], acc + (size_t)l * N);
     hipMemcpyAsync(out_host, acc, sizeof(double) * 5 * (size_t)N, hipMemcpyDeviceToHost, st);
     hipStreamSynchronize(st);
     for (int l = 0; l < 5; l++) { const double numel = (double)tr[l].H * tr[l].W * tr[l].C; for (int n = 0; n < N; n++) out_host[(size_t)l * N + n] /= numel; }

@@ -42,7 +42,8 @@ thread_local dim3 t_bdim, t_gdim;
 static constexpr size_t STACK = 256 * 1024;
 static constexpr int MAXT = 1024;
 
-struct WaveState { uint64_t slot[64]; float A[64], B[64]; float big[64 * 16]; int arrived; unsigned gen; int nlanes; };
+struct WaveState { uint64_t slot[64]; float A[64], B[64]; float big[64 * 16]; int arrived; unsigned gen; int nlanes;
+                   uint32_t dppv[64][2]; unsigned long dppseq[64]; };      // DPP mailboxes: pairwise, usable under divergence (only the lanes of a quad must agree)
 struct BlockState { int nthreads; int arrived; unsigned gen; WaveState waves[MAXT / 64]; };
 static thread_local BlockState t_blk;
 static thread_local void* t_sched_sp;
@@ -81,6 +82,19 @@ uint64_t wave_exchange(uint64_t v, int src_lane) {
     uint64_t r = (src_lane >= 0 && src_lane < w.nlanes) ? w.slot[src_lane] : v;
     wave_sync();
     return r;
+}
+// v_mov_b32_dpp quad_perm: every lane posts its value and reads the post of `src_lane` with the same sequence number.  NOT a wave-wide collective: lanes outside the
+// quad may have left the code path (the hardware's EXEC mask); the lanes that exchange must execute the same sequence of calls.
+uint32_t dpp_exchange(uint32_t v, int src_lane) {
+    WaveState& w = t_blk.waves[t_cur->lin >> 6];
+    const int me = t_cur->lin & 63;
+    const unsigned long s = w.dppseq[me];
+    w.dppv[me][s & 1] = v;
+    w.dppseq[me] = s + 1;
+    t_progress++;
+    if (src_lane == me || src_lane < 0 || src_lane >= w.nlanes) return v;
+    while (w.dppseq[src_lane] <= s) yield();
+    return w.dppv[src_lane][s & 1];
 }
 void wave_gather2(float a, float b, float* A64, float* B64) {
     WaveState& w = t_blk.waves[t_cur->lin >> 6];
@@ -209,7 +223,8 @@ static void run_block(unsigned bx, unsigned by, unsigned bz, dim3 grid, dim3 blo
     BlockState& b = t_blk;
     b.nthreads = n; b.arrived = 0; b.gen = 0;
     int nw = (n + 63) / 64;
-    for (int w = 0; w < nw; w++) { b.waves[w].arrived = 0; b.waves[w].gen = 0; b.waves[w].nlanes = std::min(64, n - 64 * w); }
+    for (int w = 0; w < nw; w++) { b.waves[w].arrived = 0; b.waves[w].gen = 0; b.waves[w].nlanes = std::min(64, n - 64 * w);
+                                   for (int l = 0; l < 64; l++) b.waves[w].dppseq[l] = 0; }
     for (int i = 0; i < n; i++) {
         Fiber& f = t_fibers[i];
         f.lin = i; f.tid.x = i % block.x; f.tid.y = (i / block.x) % block.y; f.tid.z = i / (block.x * block.y); f.done = false;

@@ -63,6 +63,7 @@ void syncthreads();
 void wave_sync();
 uint64_t wave_exchange(uint64_t v, int src_lane);           // returns value deposited by src_lane
 void wave_gather2(float a, float b, float* A64, float* B64); // all lanes' (a,b) -> arrays
+uint32_t dpp_exchange(uint32_t v, int src_lane);            // pairwise mailbox exchange (v_mov_b32_dpp): legal under divergence
 void run(dim3 grid, dim3 block, const std::function<void()>& body);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -141,6 +142,12 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
+// v_mov_b32_dpp, quad_perm controls only (ctrl < 0x100): lane l reads lane (l & ~3) | ((ctrl >> 2 (l & 3)) & 3) of its quad
+static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    const int self = emu::t_cur->lin & 63;
+    return (int)emu::dpp_exchange((uint32_t)v, (self & ~3) | ((ctrl >> (2 * (self & 3))) & 3));
+}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only ever applied to wave-uniform values */
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }      /* v_med3_f32 (a NaN drops out) */
 using std::max;

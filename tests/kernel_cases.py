@@ -899,3 +899,114 @@ def hx_lazy_bn_case(lib, dev, *, N, H, W, Cin, Cout, aux_c=0, act=1, seed=0, big
     assert e < 5e-4, ("d(x0) through the lazily applied BatchNorm", e)
     assert (dgam.cpu().double() - gr.grad).abs().max().item() < 5e-4 * gr.grad.abs().max().item() and (dbet.cpu().double() - br.grad).abs().max().item() < 5e-4 * br.grad.abs().max().item()
     return err
+
+
+# ---- S16 tensors (csrc/common.h): activations stored pre-split for the 16-bit matrix pipe ----
+def s16_decode(buf, Cc, dtype=torch.float16):
+    """(N,H,W,ld) fp32-typed raw buffer holding an S16 tensor -> (hi, lo) as (N,H,W,C) tensors of `dtype` (cpu)."""
+    raw = buf.cpu().contiguous().view(dtype)                                 # (N,H,W,2*ld) halves
+    N, H, W, _ = raw.shape
+    ch = raw[..., :2 * Cc].reshape(N, H, W, Cc // 32, 2, 32)
+    return ch[..., 0, :].reshape(N, H, W, Cc), ch[..., 1, :].reshape(N, H, W, Cc)
+
+
+def s16_encode(x_nhwc, dtype=torch.float16, dev="cpu"):
+    """(N,H,W,C) fp32 cpu tensor -> raw fp32-typed (N,H,W,C) buffer holding the S16 tensor: per 32-channel chunk [hi x 32 | lo x 32], hi = round16(x), lo = round16(x - hi)."""
+    N, H, W, Cc = x_nhwc.shape
+    hi = x_nhwc.to(dtype)
+    lo = (x_nhwc - hi.float()).to(dtype)
+    ch = torch.stack([hi.reshape(N, H, W, Cc // 32, 32), lo.reshape(N, H, W, Cc // 32, 32)], dim=4)      # (N,H,W,chunks,2,32)
+    return ch.reshape(N, H, W, 2 * Cc).contiguous().view(torch.float32).to(dev)
+
+
+def hx_s16_chain_case(lib, dev, *, N, H, W, C0, C1, C2, pool=False, seed=0):
+    """Two stacked 3x3 conv + bias + ReLU layers on k_conv_hx, once with an fp32 intermediate and once with the intermediate (and, with `pool`, its fused 2x2 max-pool) exchanged as
+    an S16-f16 tensor (ConvArgs.out_s16 / pool_s16 -> in_s16): the second layer's output must be BIT-IDENTICAL, the S16 tensor must hold exactly round16(x) | round16(x - hi).
+    Then the same for a dgrad pair in split bf16 with the ReLU-mask / L1-seed epilogue reading S16-f16 masks.  Well-filled tile variants forced (caddy_k_hx_force_big(1))."""
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+
+    def layer(cin, cout, prec, dgrad=False):
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        w_d = w.contiguous().to(dev)
+        d = make_pack([w], [(0, cin)], 3, lib)
+        d.w[0] = w_d.data_ptr()
+        rows = cin if dgrad else cout
+        rows_pad = round_up(rows, lib.caddy_k_hx_pick_bn(rows))
+        wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), 0 if dgrad else -1, rows_pad, 2), dtype=torch.uint8, device=dev)
+        assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, 0 if dgrad else -1, prec, st) == 0
+        b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+        return dict(w=w, w_d=w_d, d=d, wq=wq, b=b, cin=cin, cout=cout)
+
+    def run(L, x_buf, cin, cout_eff, Hh, Ww, prec, *, in_s16=0, out_s16=0, bias=True, act=2, pool_buf=None, pool_s16=0, mask=None, mask_s16=0, seedref=None, seed_s16=0, seed_w=0.0):
+        a = ConvArgs()
+        a.src[0] = ConvSrc(x_buf.data_ptr(), Hh * Ww * x_buf.shape[3], x_buf.shape[3], cin, round_up(cin, CONV_BK), 0)
+        a.nsrc, a.N, a.H, a.W, a.KS = 1, N, Hh, Ww, 3
+        a.wp, a.Ktot, a.Cout, a.Cout_pad = None, round_up(cin, CONV_BK), cout_eff, round_up(cout_eff, lib.caddy_k_conv_pick_bn(cout_eff))
+        a.wq, a.precision = L["wq"].data_ptr(), prec
+        a.bias, a.act = (L["b"].data_ptr() if bias else None), act
+        out = torch.full((N, Hh, Ww, cout_eff), 9.25, device=dev)
+        a.out, a.out_sn, a.out_ld = out.data_ptr(), Hh * Ww * cout_eff, cout_eff
+        a.in_s16, a.out_s16, a.pool_s16 = in_s16, out_s16, pool_s16
+        if pool_buf is not None:
+            a.pool_out, a.pool_sn, a.pool_ld = pool_buf.data_ptr(), (Hh // 2) * (Ww // 2) * cout_eff, cout_eff
+        if mask is not None:
+            a.mask, a.mask_s16 = mask.data_ptr(), mask_s16
+        if seedref is not None:
+            a.seed_ref, a.seed_s16, a.seed_w = seedref.data_ptr(), seed_s16, seed_w
+        lib.caddy_k_hx_force_big(1)
+        try:
+            rc = lib.caddy_k_conv_fwd(C.byref(a), st)
+        finally:
+            lib.caddy_k_hx_force_big(-1)
+        assert rc == 0, rc
+        sync(dev)
+        return out
+
+    # ---- forward pair, split f16 ----
+    x = torch.randn(N, C0, H, W, generator=g)
+    xb = nhwc(x, dev=dev)
+    A, Bl = layer(C0, C1, PREC_F16X3), layer(C1, C2, PREC_F16X3)
+    Hp, Wp = (H // 2, W // 2) if pool else (H, W)
+    p32 = torch.full((N, Hp, Wp, C1), 1.5, device=dev) if pool else None
+    p16 = torch.full((N, Hp, Wp, C1), 1.5, device=dev) if pool else None
+    y32 = run(A, xb, C0, C1, H, W, PREC_F16X3, pool_buf=p32)
+    y16 = run(A, xb, C0, C1, H, W, PREC_F16X3, out_s16=1, pool_buf=p16, pool_s16=1 if pool else 0)
+    for f32, s16 in ((y32, y16),) + (((p32, p16),) if pool else ()):
+        hi, lo = s16_decode(s16, C1)
+        v = f32.cpu()
+        assert torch.equal(hi, v.half()), "S16 high halves"
+        assert torch.equal(lo, (v - v.half().float()).half()), "S16 low halves"
+    z32 = run(Bl, p32 if pool else y32, C1, C2, Hp, Wp, PREC_F16X3)
+    z16 = run(Bl, p16 if pool else y16, C1, C2, Hp, Wp, PREC_F16X3, in_s16=1)
+    assert torch.equal(z32.cpu(), z16.cpu()), ("S16 input vs fp32 input", (z32.cpu() - z16.cpu()).abs().max().item())
+    z16b = run(Bl, p16 if pool else y16, C1, C2, Hp, Wp, PREC_F16X3, in_s16=1, out_s16=1)      # both at once
+    hi, lo = s16_decode(z16b, C2)
+    assert torch.equal(hi, z32.cpu().half()) and torch.equal(lo, (z32.cpu() - z32.cpu().half().float()).half())
+    ref = F.relu(F.conv2d(x.double(), A["w"].double(), A["b"].cpu().double(), padding=1))
+    err = (to_nchw(y32, C1).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+    # ---- dgrad pair, split bf16: gz2 (C2 channels) -> [dgrad of layer B, masked by the forward activation of layer A, + L1 seed] -> gz1 (C1) -> [dgrad of layer A] -> (C0) ----
+    DB, DA = layer(C1, C2, PREC_BF16X3, dgrad=True), layer(C0, C1, PREC_BF16X3, dgrad=True)
+    gz2 = torch.randn(N, Hp, Wp, C2, generator=g) * 1e-4
+    gz2_32 = gz2.to(dev)
+    gz2_16 = s16_encode(gz2, torch.bfloat16, dev)
+    act1 = (p32 if pool else y32)                              # ReLU output of layer A (mask: > 0), fp32 and S16 forms
+    act1_s = (p16 if pool else y16)
+    tap = torch.relu(torch.randn(N, Hp, Wp, C1, generator=g))
+    tap32, tap16 = tap.to(dev), s16_encode(tap, torch.float16, dev)
+    g1_32 = run(DB, gz2_32, C2, C1, Hp, Wp, PREC_BF16X3, bias=False, act=0, mask=act1, seedref=tap32, seed_w=1e-5)
+    g1_m16 = run(DB, gz2_32, C2, C1, Hp, Wp, PREC_BF16X3, bias=False, act=0, mask=act1_s, mask_s16=1, seedref=tap16, seed_s16=1, seed_w=1e-5)      # S16 masks on the plain launch
+    g1_16 = run(DB, gz2_16, C2, C1, Hp, Wp, PREC_BF16X3, bias=False, act=0, in_s16=1, out_s16=1, mask=act1_s, mask_s16=1, seedref=tap16, seed_s16=1, seed_w=1e-5)
+    # (the S16 forms see hi + lo of the activations: identical signs unless |mask - tap| is below 2^-22 relative -- never for these random values)
+    assert torch.equal(g1_32.cpu(), g1_m16.cpu()), (g1_32.cpu() - g1_m16.cpu()).abs().max().item()
+    hi, lo = s16_decode(g1_16, C1, torch.bfloat16)
+    v = g1_32.cpu()
+    assert torch.equal(hi, v.bfloat16()) and torch.equal(lo, (v - v.bfloat16().float()).bfloat16()), "S16-bf16 gradient"
+    if not pool:
+        g0_32 = run(DA, g1_32, C1, C0, H, W, PREC_BF16X3, bias=False, act=0)
+        g0_16 = run(DA, g1_16, C1, C0, H, W, PREC_BF16X3, bias=False, act=0, in_s16=1)
+        assert torch.equal(g0_32.cpu(), g0_16.cpu())
+    return err

@@ -679,3 +679,56 @@ def random_config_sweep(lib, dev, n, seed):
             oracle_case(lib, dev, c)
         except AssertionError as e:
             raise AssertionError((i, c, e))
+
+
+def vgg_s16_ab_case(lib, dev, c, lam=1.0, force_big=False):
+    """Round 5: VGG19 feature maps / feature gradients exchanged as S16 tensors (pre-split 16-bit operand pairs, csrc/common.h) against the fp32 form of the same library
+    (caddy_debug_set_vgg_s16).  The convolutions see bit-identical operands either way; the feature L1, its sign() seeds and the ReLU / max-pool routing see hi + lo instead of
+    the fp32 value (2^-22 relative): losses agree to 1e-6, the gradient w.r.t. the reconstructions up to a handful of flipped sign / arg-max decisions.
+    force_big: caddy_k_hx_force_big(1) puts every launch on the well-filled tile variants, so that small frames exercise the S16 path of every layer."""
+    d, P, obs = H.inputs_of(c)
+    V = O.make_vgg_params()
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+    nd = noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"])
+    w = dict(H.LOSS_W, perceptual=lam)
+    lib.caddy_debug_set_vgg_s16.argtypes = [C.c_void_p, C.c_int]
+    res = []
+    if force_big:
+        lib.caddy_k_hx_force_big(1)
+    try:
+        for s16 in (0, 1):
+            eng = make_engine(c, lib, dev, perceptual=True)
+            eng.load_state_dict(P)
+            eng.load_vgg(V)
+            lib.caddy_debug_set_vgg_s16(eng.ctx, s16)
+            out = eng.forward_full(obs, c["gt"], c["tau"], nd, training=True)
+            losses = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+            grads = eng.grads.clone().cpu()
+            lib.caddy_debug_set_seeds_only.argtypes = [C.c_void_p, C.c_int]
+            lib.caddy_debug_set_seeds_only(eng.ctx, 1)
+            eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+            seeds = [eng.output_grad(100 + r, out[1][r]).cpu() for r in range(3)]
+            lib.caddy_debug_set_seeds_only(eng.ctx, 0)
+            res.append((out[0].cpu(), losses, grads, seeds))
+            del eng
+    finally:
+        if force_big:
+            lib.caddy_k_hx_force_big(-1)
+    (f0, l0, g0, s0), (f1, l1, g1, s1) = res
+    assert torch.equal(f0, f1)
+    for k in l0:
+        if k.startswith("perceptual") or k == "total":
+            assert abs(l0[k] - l1[k]) <= 1e-6 * abs(l0[k]) + 1e-12, (k, l0[k], l1[k])
+    info = {}
+    for r in range(3):
+        a, b = s0[r].flatten(0, 1).double(), s1[r].flatten(0, 1).double()
+        per = torch.tensor([((a[i] - b[i]).norm() / a[i].norm()).item() for i in range(a.shape[0])])
+        info[f"seed_r{r}_median"], info[f"seed_r{r}_worst"] = per.median().item(), per.max().item()
+        assert per.median().item() < 1e-3 and per.max().item() < 5e-2, (r, per.tolist())
+    rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
+    info["param_grad_rel_l2"] = rel
+    assert rel < 2e-2, rel      # (BPTT amplifies the few flipped decisions; the two forms are two fp32-class evaluations of the same function)
+    return info

@@ -182,3 +182,9 @@ def test_wgrad_hx_split_bf16_small():
     # <= 32 output channels: the two wave rows split the tile's pixel rows (round 4); ragged rows (H = 6, 7: the second half-tile partly / wholly outside)
     K.conv_case(load_emu(), "cpu", N=2, H=7, W=18, segs=[(40, 0)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4)
     K.conv_case(load_emu(), "cpu", N=1, H=6, W=16, segs=[(64, 0), (5, 1)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=3)
+
+
+def test_conv_hx_s16_tensors_small():
+    """round 5: activations exchanged pre-split between k_conv_hx launches (ConvArgs.out_s16 / pool_s16 -> in_s16): bit-identical to the fp32 exchange, forward and dgrad chain"""
+    K.hx_s16_chain_case(load_emu(), "cpu", N=1, H=16, W=16, C0=64, C1=128, C2=64)
+    K.hx_s16_chain_case(load_emu(), "cpu", N=1, H=18, W=20, C0=64, C1=64, C2=128, pool=True)

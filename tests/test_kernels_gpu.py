@@ -210,3 +210,14 @@ def test_conv_hx_dgrad(lib, kw):
 ])
 def test_wgrad_hx(lib, kw):
     K.conv_case(lib, "cuda", wgrad_precision=17, wgrad_tol=1e-4, **kw)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=1, H=16, W=16, C0=64, C1=128, C2=64),                 # 8-wave 16x16x128 producer, 16x16x64 consumer
+    dict(N=2, H=32, W=48, C0=64, C1=64, C2=128, pool=True),      # fused 2x2 max-pool written as S16
+    dict(N=2, H=40, W=36, C0=128, C1=256, C2=256),               # several output-channel blocks, ragged tiles
+    dict(N=3, H=34, W=30, C0=64, C1=128, C2=128, pool=True),
+])
+def test_conv_hx_s16_tensors(lib, kw):
+    """round 5: activations exchanged pre-split between k_conv_hx launches (ConvArgs.out_s16 / pool_s16 -> in_s16): bit-identical to the fp32 exchange, forward and dgrad chain"""
+    K.hx_s16_chain_case(lib, "cuda", **kw)

@@ -76,6 +76,19 @@ def test_perceptual_loss_small_split_operands():
         M.SIM_SPLIT = False
 
 
+def test_perceptual_loss_small_s16_feature_maps():
+    """round 5: the split-operand VGG19 path with every launch forced onto the well-filled tile variants: feature maps and feature gradients travel as S16 tensors (pre-split operand
+    pairs written by the producing epilogue), the point-wise kernels (feature L1, max-pool backward, ReLU masks) read them -- against the oracle"""
+    lib = load_emu()
+    M.SIM_SPLIT = True
+    lib.caddy_k_hx_force_big(1)
+    try:
+        M.perceptual_oracle_case(lib, "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=2, H=64, W=64, gt=1, tau=0.8), lam=0.7)
+    finally:
+        lib.caddy_k_hx_force_big(-1)
+        M.SIM_SPLIT = False
+
+
 def test_full_reduced_s1_split_operand_kernels():
     """the default arithmetic of the MI355X runs (split-f16 forward, split-bf16 backward on conv_hx.hip) through the whole driver"""
     M.SIM_SPLIT = True

@@ -56,6 +56,24 @@ def test_perceptual_loss_parity(lib, name):
     print(info)
 
 
+def test_perceptual_loss_parity_s16_every_layer(lib):
+    """round 5: the same golden with every VGG19 launch forced onto the well-filled tile variants, i.e. every feature map / feature gradient exchanged as an S16 tensor"""
+    lib.caddy_k_hx_force_big(1)
+    try:
+        eng, info = M.perceptual_case("perc_main_s1", lib, "cuda")
+    finally:
+        lib.caddy_k_hx_force_big(-1)
+    print(info)
+
+
+def test_vgg_s16_feature_maps_vs_fp32_feature_maps(lib):
+    """round 5: S16 feature maps (pre-split operand pairs written by the producing epilogue) vs fp32 feature maps, same library, same inputs: small frames with every launch
+    forced well-filled, and 256x256 frames where the launcher picks"""
+    print(M.vgg_s16_ab_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=80, gt=1, tau=0.6), force_big=True))
+    print(M.vgg_s16_ab_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=4, H=256, W=256, gt=2, tau=0.6)))
+    torch.cuda.empty_cache()
+
+
 def test_perceptual_loss_odd_pooling_sizes(lib):
     """Breakout's 208x160 frames: the quarter resolution 52x40 goes 26x20 -> 13x10 -> 6x5 -> 3x2 through the VGG max-pools (floor)"""
     M.perceptual_oracle_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=208, W=160, gt=1, tau=0.6), lam=1.0)

@@ -12,9 +12,19 @@ c = sqlite3.connect(argv[1])
 rows = c.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x from kernels order by start").fetchall()
 ad = [i for i, r in enumerate(rows) if "k_adam" in r[0]]
 seg = rows[ad[1] + 1:ad[2] + 1]
+def short(n):
+    """mangled k_conv_hx / k_wgrad_hx instances (their _Float16 / __bf16 template argument keeps rocprof from demangling them) -> k_conv_hx<f16, 2, 16, 16, 128, 4, 2, 3, EP, IO>"""
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+(k_\w+?)I(DF16_|DF16b)((?:L[ib]\d+E)*)E", n)
+    if m:
+        args = re.findall(r"L[ib](\d+)E", m.group(3))
+        return f"{m.group(1)}<{'f16' if m.group(2) == 'DF16_' else 'bf16'}, {', '.join(args)}>"
+    n = re.sub(r"\(anonymous namespace\)::", "", n).split("(")[0]
+    return n[:70]
+
+
 agg = collections.defaultdict(lambda: [0, 0.0])
 for n, s, e, gx, gy, gz, wx in seg:
-    n = re.sub(r"\(anonymous namespace\)::", "", n).split("(")[0][:60]
+    n = short(n)
     if by_grid:
         n = f"{n[:48]:48s} g=({gx // max(wx, 1)},{gy},{gz}) wg={wx}"
     a = agg[n]; a[0] += 1; a[1] += (e - s) / 1e3
