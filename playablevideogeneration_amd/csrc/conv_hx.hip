@@ -63,6 +63,125 @@ __device__ __forceinline__ float s16_val(const float* row, int col) {
     return (float)h[col & 31] + (float)h[32 + (col & 31)];
 }
 
+// ---- epilogue of k_conv_hx (round 5: rewritten).  D fragment map: col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile).
+// The first form tested the launch-uniform modes (split-K, residual, accumulate, mask, tile clipping) per VALUE inside fully unrolled loops with 64-bit addresses: ~10 000
+// instructions and ~1000 branches per instance, and the mask reads of the VGG19 dgrads were one dependent load + wait per value -- all of it exposed (one workgroup per CU: nothing
+// overlaps an epilogue).  Now: wave-uniform base pointers + 32-bit byte offsets (one add per value), the row test on the scalar unit, column tests only in workgroups that straddle
+// the image border (INTR = false), the activation as a slope select, everything a 32 x 32 block READS (mask / seed / residual / old value) requested back to back before the first
+// use, and one straight-line instance per workgroup-uniform case: MODE 0 plain assigning store, 1 + ReLU mask / L1 seed (VGG19 dgrads), 2 everything (split-K atomics / slabs,
+// residual, accumulate).  Measured: full step 141.9 -> 127.5 ms, E/R/A/D step 66.1 -> 63.1 ms (profiles/r05_experiments.md).
+template <typename T, int TH, int TW, int BN, int WM, int WN, int EP, bool SO, bool INTR, int MODE, int TMt, int TNt>
+__device__ __forceinline__ void hx_epilogue(f32x16 (&acc)[TMt][TNt], float (&st1)[TNt], float (&st2)[TNt], unsigned& amax_o, const ConvArgs& a,
+                                            int n, int n0, int y0, int x0, int lane, int wave) {
+    constexpr bool E_POOL = EP == 1 || EP == 3, E_MASK = EP == 2 || EP == 3;
+    constexpr int BM = TH * TW, RW = BM / WM / TW;           // tile rows per wave
+    const int wm_u = __builtin_amdgcn_readfirstlane(wave) / WN, wn = wave % WN;      // (wave-uniform copy: keeps the row arithmetic on the scalar unit)
+    const int yw = y0 + wm_u * RW, xl = x0 + 4 * (lane >> 5);      // first image row of this wave's rows (uniform) / this lane's first column
+    const int nx = a.W - xl;                                  // columns of this lane's row segment that lie inside the image
+    const bool masked = MODE == 1 || (MODE == 2 && E_MASK && a.mask != nullptr);
+    const bool split = MODE == 2 && a.splitk > 1, slabs = split && a.split_stride != 0, atomics = split && !slabs;
+    const bool with_res = MODE == 2 && !split && a.res != nullptr, accum = MODE == 2 && !split && a.accumulate != 0;
+    char* const op = reinterpret_cast<char*>(a.out + (long)n * a.out_sn + (slabs ? (long)blockIdx.z * a.split_stride : 0L));
+    const char* const mp = masked ? reinterpret_cast<const char*>(a.mask + (long)n * a.out_sn) : nullptr;
+    const char* const sp = (masked && a.seed_ref) ? reinterpret_cast<const char*>(a.seed_ref + (long)n * a.out_sn) : nullptr;
+    const char* const rp = with_res ? reinterpret_cast<const char*>(a.res + (long)n * a.res_sn) : nullptr;
+    const unsigned ldb = (unsigned)a.out_ld * 4u, wldb = (unsigned)a.W * ldb;
+    const unsigned rldb = (unsigned)a.res_ld * 4u, rwldb = (unsigned)a.W * rldb;
+    const unsigned pix0 = (unsigned)(yw * a.W + xl);          // this lane's first pixel (one sample stays below 4 GB: the launcher checks)
+    const float osc = a.out_scale, slope = split ? 1.f : (a.act == 2 ? 0.f : (a.act == 3 ? 0.2f : 1.f)), sw = a.seed_w;
+    const bool store_full = !E_POOL || !a.skip_out;
+    const int ms16 = a.mask_s16, ss16 = a.seed_s16;
+    // byte offset of value r of row block i relative to the lane's first pixel, for a pixel pitch of ldb_ / row pitch of wldb_
+#define HX_EOFF(i_, r_, wldb_, ldb_) ((unsigned)((i_) * 2 + ((r_) >> 3)) * (wldb_) + (unsigned)(((r_) & 3) + 8 * (((r_) >> 2) & 1)) * (ldb_))
+    // is value r of row block i inside the image?  (rows: wave-uniform; columns: only evaluated by border workgroups)
+#define HX_EOK(i_, r_) (INTR || (yw + (i_) * 2 + ((r_) >> 3) < a.H && ((r_) & 3) + 8 * (((r_) >> 2) & 1) < nx))
+#pragma unroll
+    for (int j = 0; j < TNt; j++) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        if (col < a.Cout) {                                  // (lane-divergent only on the padded tail of a layer whose width is no multiple of 32; never with S16 tensors)
+            const float bv = (a.bias && blockIdx.z == 0) ? a.bias[col] : 0.f;
+            // channel part of the byte offsets (= a valid address by itself: pixel 0 of the sample, where clipped values send their loads) and the lane's first pixel added
+            const unsigned f0 = (unsigned)col * 4u, h0 = (unsigned)(col & ~31) * 4u + (unsigned)(col & 31) * 2u;      // fp32 tensors / high half of channel col in an S16 tensor
+            const unsigned m0 = ms16 ? h0 : f0, s0 = ss16 ? h0 : f0;
+            const unsigned cb = pix0 * ldb + (SO ? (unsigned)s16_slot(col) * 4u : f0);
+            const unsigned fb = pix0 * ldb + f0, mb = pix0 * ldb + m0, sb = pix0 * ldb + s0, rb = pix0 * rldb + f0;
+#pragma unroll
+            for (int i = 0; i < TMt; i++) {
+                float mk[16], sd[16], ex[16];                 // mask / seed reference / (residual | old value): requested back to back, consumed below
+                if (masked) {
+                    if (!ms16) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) mk[r] = *reinterpret_cast<const float*>(mp + (HX_EOK(i, r) ? mb + HX_EOFF(i, r, wldb, ldb) : m0));
+                    } else if (sp == nullptr) {               // sign / zero test only: the high half decides (hi == 0 implies lo == 0)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) mk[r] = (float)*reinterpret_cast<const _Float16*>(mp + (HX_EOK(i, r) ? mb + HX_EOFF(i, r, wldb, ldb) : m0));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(mp + (HX_EOK(i, r) ? mb + HX_EOFF(i, r, wldb, ldb) : m0));
+                                                       mk[r] = (float)h_[0] + (float)h_[32]; }
+                    }
+                    if (sp != nullptr) {
+                        if (!ss16) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) sd[r] = *reinterpret_cast<const float*>(sp + (HX_EOK(i, r) ? sb + HX_EOFF(i, r, wldb, ldb) : s0));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(sp + (HX_EOK(i, r) ? sb + HX_EOFF(i, r, wldb, ldb) : s0));
+                                                           sd[r] = (float)h_[0] + (float)h_[32]; }
+                        }
+                    }
+                }
+                if (with_res) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) ex[r] = *reinterpret_cast<const float*>(rp + (HX_EOK(i, r) ? rb + HX_EOFF(i, r, rwldb, rldb) : f0));
+                } else if (accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) ex[r] = *reinterpret_cast<const float*>(op + (HX_EOK(i, r) ? fb + HX_EOFF(i, r, wldb, ldb) : f0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float v = acc[i][j][r] * osc + bv;
+                    if (with_res) v += ex[r];
+                    v = v > 0.f ? v : slope * v;
+                    if (masked) {
+                        if (sp != nullptr) { const float d_ = mk[r] - sd[r]; v += d_ > 0.f ? sw : (d_ < 0.f ? -sw : 0.f); }
+                        v = mk[r] > 0.f ? v : 0.f;
+                    }
+                    if (accum) v += ex[r];
+                    if (E_POOL) acc[i][j][r] = v;             // (kept for the fused max-pool below; clamped by the range guard when the launch writes S16 tensors)
+                    if (HX_EOK(i, r)) {
+                        if (EP == 0 && !split) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
+                        const unsigned o_ = cb + HX_EOFF(i, r, wldb, ldb);
+                        if (SO) {       // S16 output: range guard (f16) + split here, once per output element (both lanes of a channel pair are inside or outside together)
+                            if (!is_bf16<T>::value) { amax_o = max(amax_o, __float_as_uint(v) & 0x7fffffffu); v = __builtin_amdgcn_fmed3f(v, -HX_F16_MAX, HX_F16_MAX); if (E_POOL) acc[i][j][r] = v; }
+                            const unsigned w_ = s16_pair<T>(v, lane);
+                            if (store_full) *reinterpret_cast<unsigned*>(op + o_) = w_;
+                        } else if (atomics) atomicAdd(reinterpret_cast<float*>(op + o_), v);
+                        else if (store_full) *reinterpret_cast<float*>(op + o_) = v;
+                    }
+                }
+                if (E_POOL && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
+                    char* const pp = reinterpret_cast<char*>(a.pool_out + (long)n * a.pool_sn);
+                    const unsigned plb = (unsigned)a.pool_ld * 4u;
+                    const int py = (yw + i * 2) >> 1;
+                    const unsigned pb0 = (unsigned)(py * (a.W >> 1) + (xl >> 1)) * plb + ((SO && a.pool_s16) ? (unsigned)s16_slot(col) : (unsigned)col) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const int pdx = ((r & 3) + 8 * ((r >> 2) & 1)) >> 1;
+                        if (!INTR && (py >= (a.H >> 1) || (xl >> 1) + pdx >= (a.W >> 1))) continue;      // floor semantics: the last row / column of an odd map belongs to no window
+                        const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
+                        const unsigned po_ = pb0 + (unsigned)pdx * plb;
+                        if (SO && a.pool_s16) *reinterpret_cast<unsigned*>(pp + po_) = s16_pair<T>(mx, lane);
+                        else *reinterpret_cast<float*>(pp + po_) = mx;
+                    }
+                }
+            }
+        }
+    }
+#undef HX_EOFF
+#undef HX_EOK
+}
+
 // T: _Float16 / __bf16.  NPL planes staged (2: hi + lo, 3 products; 1: hi only).  Tile TH x TW pixels x BN output channels, WM x WN waves
 // (4 or 8), each owning a (BM / WM) x (BN / WN) sub-tile.  D = depth of the register ring of weight tiles: the tile of step s + D is
 // requested while step s computes (D = 1: next step only; D = 3: ~1.9 us of latency tolerance at 8 waves -- the weights of a 512-channel
@@ -318,146 +437,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
 #pragma unroll
     for (int j = 0; j < TNt; j++) { st1[j] = 0.f; st2[j] = 0.f; }
-    // ---- fast epilogues (round 5).  The general loop below tests the launch-uniform modes (split-K, residual, accumulate, mask, tile clipping) per VALUE inside fully unrolled
-    // loops with 64-bit addresses: ~10 000 instructions with ~1000 branches per instance, and the mask reads of the VGG19 dgrads were one dependent load + wait per value -- all of it
-    // exposed (one workgroup per CU: nothing overlaps an epilogue).  Whole-K, assigning, residual-free launches on tiles that lie inside the image -- every well-filled launch of the
-    // step -- take straight-line code instead: wave-uniform base pointers + 32-bit byte offsets (one add per value), activation as a slope select, the 16 mask / seed values of a
-    // 32 x 32 block requested back to back before the first one is used.
-    const int wm_u = __builtin_amdgcn_readfirstlane(wave) / WN;      // (wave-uniform copy: keeps the row arithmetic on the scalar unit)
-    constexpr int RW = BM / WM / TW;                          // tile rows per wave
-    const bool whole = a.splitk == 1 && a.res == nullptr && !a.accumulate && y0 + TH <= a.H && x0 + TW <= a.W && (long)a.H * a.W * a.out_ld < (1L << 30);      // workgroup-uniform
-    bool fast_done = false;
-    if (whole) {
-        fast_done = true;
+    // ---- epilogue (hx_epilogue above): the workgroup-uniform cases are separate straight-line instances ----
+    {
+        const bool interior = y0 + TH <= a.H && x0 + TW <= a.W;
+        const bool general = a.splitk > 1 || a.res != nullptr || a.accumulate != 0;
         const bool masked = E_MASK && a.mask != nullptr;
-        char* const op = reinterpret_cast<char*>(a.out + (long)n * a.out_sn);
-        const char* const mp = masked ? reinterpret_cast<const char*>(a.mask + (long)n * a.out_sn) : nullptr;
-        const char* const sp = (masked && a.seed_ref) ? reinterpret_cast<const char*>(a.seed_ref + (long)n * a.out_sn) : nullptr;
-        const unsigned ldb = (unsigned)a.out_ld * 4u, wldb = (unsigned)a.W * ldb;
-        const unsigned pbase = (unsigned)((y0 + wm_u * RW) * a.W + x0 + 4 * (lane >> 5)) * ldb;      // this lane's first pixel (bytes; one sample stays below 4 GB: the launcher checks)
-        const float osc = a.out_scale, slope = a.act == 2 ? 0.f : (a.act == 3 ? 0.2f : 1.f), sw = a.seed_w;
-        const bool store_full = !E_POOL || !a.skip_out;
-        const int ms16 = a.mask_s16, ss16 = a.seed_s16;
-#pragma unroll
-        for (int j = 0; j < TNt; j++) {
-            const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-            if (col < a.Cout) {                              // (lane-divergent only on the padded tail of a layer whose width is no multiple of 32; never with S16 tensors)
-                const float bv = a.bias ? a.bias[col] : 0.f;
-                const unsigned cb = pbase + (SO ? (unsigned)s16_slot(col) : (unsigned)col) * 4u;
-                const unsigned mb = pbase + (ms16 ? (unsigned)(col & ~31) * 4u + (unsigned)(col & 31) * 2u : (unsigned)col * 4u);      // S16 tensors: the high half of channel col
-                const unsigned sb = pbase + (ss16 ? (unsigned)(col & ~31) * 4u + (unsigned)(col & 31) * 2u : (unsigned)col * 4u);
-#pragma unroll
-                for (int i = 0; i < TMt; i++) {
-                    float mk[16], sd[16];
-                    if (masked) {                             // requested back to back, consumed below
-                        if (!ms16) {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) mk[r] = *reinterpret_cast<const float*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
-                        } else if (sp == nullptr) {           // sign / zero test only: the high half decides (hi == 0 implies lo == 0)
-#pragma unroll
-                            for (int r = 0; r < 16; r++) mk[r] = (float)*reinterpret_cast<const _Float16*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(mp + (mb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
-                                                           mk[r] = (float)h_[0] + (float)h_[32]; }
-                        }
-                        if (sp != nullptr) {
-                            if (!ss16) {
-#pragma unroll
-                                for (int r = 0; r < 16; r++) sd[r] = *reinterpret_cast<const float*>(sp + (sb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 16; r++) { const _Float16* h_ = reinterpret_cast<const _Float16*>(sp + (sb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb));
-                                                               sd[r] = (float)h_[0] + (float)h_[32]; }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float v = acc[i][j][r] * osc + bv;
-                        v = v > 0.f ? v : slope * v;
-                        if (masked) {
-                            if (sp != nullptr) { const float d_ = mk[r] - sd[r]; v += d_ > 0.f ? sw : (d_ < 0.f ? -sw : 0.f); }
-                            v = mk[r] > 0.f ? v : 0.f;
-                        }
-                        if (EP == 0) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
-                        const unsigned o_ = cb + (unsigned)(i * 2 + (r >> 3)) * wldb + (unsigned)((r & 3) + 8 * ((r >> 2) & 1)) * ldb;
-                        if (SO) {
-                            if (!is_bf16<T>::value) { amax_o = max(amax_o, __float_as_uint(v) & 0x7fffffffu); v = __builtin_amdgcn_fmed3f(v, -HX_F16_MAX, HX_F16_MAX); }
-                            const unsigned w_ = s16_pair<T>(v, lane);
-                            if (store_full) *reinterpret_cast<unsigned*>(op + o_) = w_;
-                        } else if (store_full) *reinterpret_cast<float*>(op + o_) = v;
-                        if (E_POOL) acc[i][j][r] = v;
-                    }
-                    if (E_POOL && a.pool_out) {      // 2x2 max of the activated values (see the general loop); an interior tile has no clipped windows
-                        char* const pp = reinterpret_cast<char*>(a.pool_out + (long)n * a.pool_sn);
-                        const unsigned plb = (unsigned)a.pool_ld * 4u;
-                        const unsigned pb0 = (unsigned)(((y0 + wm_u * RW + i * 2) >> 1) * (a.W >> 1) + ((x0 + 4 * (lane >> 5)) >> 1)) * plb + ((SO && a.pool_s16) ? (unsigned)s16_slot(col) : (unsigned)col) * 4u;
-#pragma unroll
-                        for (int r = 0; r < 8; r += 2) {
-                            const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
-                            const unsigned po_ = pb0 + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) >> 1) * plb;
-                            if (SO && a.pool_s16) *reinterpret_cast<unsigned*>(pp + po_) = s16_pair<T>(mx, lane);
-                            else *reinterpret_cast<float*>(pp + po_) = mx;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (!fast_done)
-#pragma unroll
-    for (int j = 0; j < TNt; j++) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-        if (col >= a.Cout) continue;
-        const float bv = (a.bias && blockIdx.z == 0) ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TMt; i++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int y = y0 + m / TW, x = x0 + m % TW;
-                if (y >= a.H || x >= a.W) continue;
-                const long off = (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld + col;
-                float v = acc[i][j][r] * a.out_scale + bv;
-                if (a.splitk > 1) {
-                    if (a.split_stride) a.out[blockIdx.z * a.split_stride + off] = v;      // slabs: bias / activation applied by the reduce
-                    else atomicAdd(a.out + off, v);
-                    continue;
-                }
-                if (a.res) v += a.res[(long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + col];
-                if (a.act == 2) v = fmaxf(v, 0.f);
-                else if (a.act == 3) v = v > 0.f ? v : 0.2f * v;
-                if (E_MASK && a.mask) {      // (mask / seed_ref: geometry of `out`; S16-f16 tensors of the forward pass when ConvArgs.mask_s16 / seed_s16)
-                    const float* mrow = a.mask + (off - col);
-                    const bool need_val = a.seed_ref != nullptr;
-                    const float mk = a.mask_s16 ? (need_val ? s16_val(mrow, col) : s16_hi(mrow, col)) : mrow[col];
-                    if (a.seed_ref) { const float* srow = a.seed_ref + (off - col);
-                                      const float d = mk - (a.seed_s16 ? s16_val(srow, col) : srow[col]); v += d > 0.f ? a.seed_w : (d < 0.f ? -a.seed_w : 0.f); }
-                    v = mk > 0.f ? v : 0.f;
-                }
-                if (a.accumulate) v += a.out[off];
-                if (EP == 0) { st1[j] += v; st2[j] = fmaf(v, v, st2[j]); }
-                if (SO) {       // S16 output: range guard (f16) + split here, once per output element
-                    if (!is_bf16<T>::value) { amax_o = max(amax_o, __float_as_uint(v) & 0x7fffffffu); v = __builtin_amdgcn_fmed3f(v, -HX_F16_MAX, HX_F16_MAX); }
-                    const unsigned o_ = s16_pair<T>(v, lane);
-                    if (!E_POOL || !a.skip_out) reinterpret_cast<unsigned*>(a.out)[off - col + s16_slot(col)] = o_;
-                } else if (!E_POOL || !a.skip_out) a.out[off] = v;
-                if (E_POOL) acc[i][j][r] = v;                     // (kept for the fused max-pool below)
-            }
-            if (E_POOL && a.pool_out) {      // 2x2 max of the activated values: window = accumulators {r, r + 1, r + 8, r + 9}, r in {0, 2, 4, 6} (rows 2i / 2i + 1 of the tile, columns x, x + 1)
-#pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    const int m = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int py = (y0 + m / TW) >> 1, px = (x0 + m % TW) >> 1;
-                    if (py >= (a.H >> 1) || px >= (a.W >> 1)) continue;      // floor semantics: the last row / column of an odd map belongs to no window
-                    const float mx = fmaxf(fmaxf(acc[i][j][r], acc[i][j][r + 1]), fmaxf(acc[i][j][r + 8], acc[i][j][r + 9]));
-                    const long prow = (long)n * a.pool_sn + ((long)py * (a.W >> 1) + px) * a.pool_ld;
-                    if (SO && a.pool_s16) reinterpret_cast<unsigned*>(a.pool_out)[prow + s16_slot(col)] = s16_pair<T>(mx, lane);      // (already clamped above)
-                    else a.pool_out[prow + col] = mx;
-                }
-            }
-        }
+#define HX_EPI(INTR_, MODE_) hx_epilogue<T, TH, TW, BN, WM, WN, EP, SO, INTR_, MODE_>(acc, st1, st2, amax_o, a, n, n0, y0, x0, lane, wave)
+        if (interior) { if (general) HX_EPI(true, 2); else if (masked) HX_EPI(true, (E_MASK ? 1 : 0)); else HX_EPI(true, 0); }
+        else { if (general) HX_EPI(false, 2); else if (masked) HX_EPI(false, (E_MASK ? 1 : 0)); else HX_EPI(false, 0); }
+#undef HX_EPI
     }
     if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag, 1u);
     // ---- BatchNorm partial sums of this tile: the two 32-lane halves of a wave hold different pixel rows of one channel, the WM waves of a column
@@ -839,6 +827,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     a.Cout_pad = round_up(a.Cout, bn);      // (row padding of the packed weights: independent of the tile width chosen below)
     if (a.mask && a.accumulate) return -1;
     if (a.pool_out && (a.accumulate || a.mask)) return -1;
+    if ((long)a.H * a.W * a.out_ld >= (1L << 30) || (a.res && (long)a.H * a.W * a.res_ld >= (1L << 30))) return 0;      // (the epilogue addresses one sample with 32-bit byte offsets)
     const int nchunks = kq / HX_KC;
     // under-filled wide layers (R's gate / SameBlock convolutions on 16x16 .. 32x32 maps, A, D's first stage at batch 8): 64-channel tiles on the same
     // 128-row packed weights -> twice the workgroups, two co-resident per CU hiding each other's barrier / LDS latencies (one 4-wave workgroup per CU
