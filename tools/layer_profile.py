@@ -30,5 +30,11 @@ for kind, P, Kc, Cout, KS, fl, ms in recs:
 tot = sum(a[2] for a in agg.values())
 print(f"total conv ms (sum of launches, side stream overlaps not subtracted): {tot:.1f}")
 names = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "vggf", 4: "vggd"}
-for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
-    print(f"{names[k[0]]:5s} P={k[1]:8d} K={k[2]:5d} Cout={k[3]:5d} k{k[4]}  n={a[0]:4d}  {a[2]:7.2f} ms  {a[2]/a[0]*1e3:8.1f} us/launch  {a[1]/a[2]/1e9 if a[2] else 0:6.1f} TF")
+# EVERY row (the tail is where the HBM-bound narrow layers live).  hbm_us: algorithmic bytes of the launch (inputs + outputs + weights, fp32, each once) at the 8 TB/s peak;
+# frac: that bound / the measured time -- the roofline fraction of a layer too narrow for the matrix pipe to matter
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+    kind, P, Kc, Cout, KS = k
+    byt = 4.0 * (P * Kc + P * Cout + KS * KS * Kc * Cout)
+    us = a[2] / a[0] * 1e3
+    hbm_us = byt / 8e12 * 1e6
+    print(f"{names[kind]:5s} P={P:8d} K={Kc:5d} Cout={Cout:5d} k{KS}  n={a[0]:4d}  {a[2]:7.2f} ms  {us:8.1f} us/launch  {a[1]/a[2]/1e9 if a[2] else 0:6.1f} TF  hbm {hbm_us:7.1f} us  frac {hbm_us / us if us else 0:5.2f}")
