@@ -33,7 +33,10 @@ typedef struct caddy_config {
     int perceptual;     /* != 0: the context also holds the VGG19 perceptual loss (training/losses.py:379-491): the workspace grows by the
                            packed VGG19 weights and feature maps, caddy_load_vgg must be called before a caddy_loss_backward with
                            caddy_loss_cfg.perceptual != 0 */
+    int ensemble;       /* model.action_network.ensamble_size (model/main_model/model.py:28,47): N action networks `action_network.{0..N-1}.*` in the parameter table; 0 or 1 = one.
+                           The caller draws the member of a forward pass (model.py:152 / :358: random.choice) and names it with caddy_set_action_member.  At most CADDY_MAX_ENSEMBLE. */
 } caddy_config;
+#define CADDY_MAX_ENSEMBLE 8
 
 typedef struct caddy_param_info {
     char name[128];   /* reference state_dict key */
@@ -76,8 +79,8 @@ typedef struct caddy_loss_cfg {
 enum { CADDY_LOSS_TOTAL = 0, CADDY_LOSS_REC, CADDY_LOSS_STATES, CADDY_LOSS_ENTROPY, CADDY_LOSS_DIRKL, CADDY_LOSS_MI,
        CADDY_LOSS_STATEKL, CADDY_LOSS_HIDDEN, CADDY_LOSS_L1_R0, CADDY_LOSS_L1_R1, CADDY_LOSS_L1_R2,
        CADDY_LOSS_PERCEPTUAL = 11, CADDY_LOSS_PERCEPTUAL_TERM = 12,
-       CADDY_LOSS_F16_SATURATED = 13,      /* 1.0: a split-f16 forward convolution (model or VGG19) staged |x| > 65504 since the forward began; it was clamped to the f16 range -- switch
-                                              the context to the exact-fp32 forward: caddy_set_precision(ctx, 0, 17) / caddy_set_vgg_precision(ctx, 0, 17) */
+       CADDY_LOSS_F16_SATURATED = 13,      /* 1.0: a split-f16 forward convolution (model or VGG19) staged |x| > 65504 since the last caddy_f16_saturated poll; it was clamped to the f16
+                                              range -- call caddy_f16_saturated(ctx): the reporting layers move to a forward without a range limit */
        CADDY_LOSS_PERC_R0 = 16,
        /* caddy_loss_cfg.diagnostics: samples_entropy, action_distribution_entropy, states_magnitude, hidden_states_magnitude, action_directions_{mean,variance}_magnitude,
         * reconstructed_action_directions_{mean,variance}_magnitude, action_directions_reconstruction_error, reconstructed_action_directions_kl_loss,
@@ -202,14 +205,25 @@ int caddy_loss_backward(caddy_ctx* ctx, const caddy_loss_cfg* cfg, double* losse
 /* --- optimizer.step(): torch.optim.Adam with L2 weight decay (training/trainer.py:36,586); m, v: trainable floats --- */
 int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int step, float grad_scale);
+/* Ensemble of action networks (caddy_config.ensemble > 1; model/main_model/model.py:152,274 / :358,456: both A calls of a forward pass use the member drawn with random.choice).
+ * caddy_set_action_member names the member of the NEXT forward pass.  The members that were not drawn receive no gradient (`.grad is None` in the reference): caddy_adam_step leaves
+ * their moments and weights untouched, as torch.optim.Adam does, and applies the drawn member's range with ITS OWN step count `member_step` (torch keeps `step` per parameter: a member
+ * drawn k times has been stepped k times); every other parameter uses `step`. */
+int caddy_set_action_member(caddy_ctx* ctx, int member);
+int caddy_adam_step_member(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int member_step, float grad_scale);
 
 /* --- play.py roll-out: Model.start_inference (model.py:561-568) / Model.generate_next (model.py:570-607), eval mode.
  *     observation: (3S,H,W); variation: (Da) or NULL (= zeros, noise=False); frame_out: (3,H,W); obs_out: (3S,H,W) or NULL.
  *     observation, frame_out and obs_out must NOT overlap (obs_out = cat[frame, observation[:-3]] is written while observation is read):
  *     an overlapping call is rejected with -2. --- */
 int caddy_start_inference(caddy_ctx* ctx);
-/* 1 if a split-f16 forward convolution met an input beyond the f16 range (|x| > 65504, clamped) since the last forward / caddy_start_inference began; waits for the stream */
+/* Poll of the f16 range guards (one flag word per convolution layer, sticky on the device until this call reads and clears them; waits for the stream).  Return value: bit 0 -- a
+ * split-f16 forward convolution of the model (model/layers/) or of VGG19 (model/layers/vgg.py:20-36) met an input beyond the f16 range (|x| > 65504) since the last poll and clamped
+ * it; bit 1 -- a NaN was among them (the clamp made it finite: the loss call of that pass reported a NaN total, as the reference's fp32 arithmetic would have).  The layers that
+ * reported -- and only those -- run without a range limit from the next forward pass on (exact fp32 for model layers, split bf16 for VGG19 layers), for the lifetime of the context;
+ * caddy_fallback_layers returns how many have moved so far. */
 int caddy_f16_saturated(caddy_ctx* ctx);
+int caddy_fallback_layers(caddy_ctx* ctx);
 int caddy_generate_next(caddy_ctx* ctx, const float* observation, int action, const float* variation, float* frame_out, float* obs_out);
 
 /* --- live kernel timing: HIP events recorded on the launch stream around every conv launch between begin and end.

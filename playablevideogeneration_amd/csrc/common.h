@@ -97,9 +97,10 @@ struct ConvArgs {
     float* stats;
     int stats_ld;
     // Split-f16 forward only: |x| > 65504 does not fit the high half.  The staging clamps such a value (also an inf or a NaN) to the f16 range (instead of producing
-    // inf - inf = NaN in the low half) and the launch ORs 1 into *sat_flag (nullable): the context reports it with the losses (CADDY_LOSS_F16_SATURATED) / caddy_f16_saturated(), and the
-    // caller switches that context to the exact-fp32 forward (caddy_set_precision(0, ...)).  Not reachable with BatchNorm-normalised activations; it is the guard
-    // for externally supplied networks and inputs (VGG19 with real weights on un-normalised frames).
+    // inf - inf = NaN in the low half) and the launch ORs 1 into *sat_flag (nullable; | 2 when a NaN was among them: v_med3 turns it into a finite number, the reference would
+    // propagate it).  The driver gives every layer its own word (round 5): caddy_f16_saturated() reads them, moves exactly the layers that reported onto a forward without a range
+    // limit (exact fp32 for the model, split bf16 for VGG19) and the loss call reports CADDY_LOSS_F16_SATURATED / a NaN total.  Not reachable with BatchNorm-normalised activations;
+    // it is the guard for externally supplied networks and inputs (VGG19 with real weights on un-normalised frames).
     unsigned* sat_flag;
     // Bit-reproducible mode (caddy_set_deterministic): the split-K of an under-filled ACCUMULATING launch (dgrad +=) goes through slabs of split_scratch and the
     // fixed-order reduce (which then adds the previous contents of `out`) instead of fp32 atomics in arrival order

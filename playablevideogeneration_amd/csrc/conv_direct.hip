@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u], xh, acc, 0, 0, 0);
         }
     }
-    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);
+    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, amax > 0x7f800000u ? 3u : 1u);      // bit 1: a NaN among them
     // ---- the waves' partial tiles: fixed order (bit-reproducible), then the epilogue on wave 0: lane holds channels co0 + 4 (lane >> 4) .. + 3 of pixel lane & 15 ----
     *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc;
     __syncthreads();
@@ -127,7 +127,8 @@ int conv_direct_try(const ConvArgs& a, hipStream_t st) {
     if (a.KS != 3 || !a.wq || a.precision != PREC_F16X3 || a.accumulate || a.mask || a.pool_out || a.skip_out || a.stats || a.seed_ref) return 0;
     if (a.act != 0 && a.act != 2 && a.act != 3) return 0;
     if ((a.out_ld & 3) || (a.out_sn & 3) || (a.res && ((a.res_ld & 3) || (a.res_sn & 3)))) return 0;
-    for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale || (a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0;
+    for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale || (a.src[s].ld & 3) || (a.src[s].sn & 3) || ((uintptr_t)a.src[s].p & 15)) return 0;
+    if (((uintptr_t)a.out | (uintptr_t)a.res) & 15) return 0;      // (float4 accesses: a channel-offset view with c0 % 4 != 0 stays on the tile kernel)
     const int nchunks = a.Kq / DK;
     if (nchunks < 1 || nchunks > DIRECT_MAX_CHUNKS) return 0;
     const int gx = cdiv(a.W, 16);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[g], acc[g], 0, 0, 0);
         }
     }
-    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);
+    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, amax > 0x7f800000u ? 3u : 1u);      // bit 1: a NaN among them
     // ---- epilogue: lanes 0..15 hold rows (= output channels) 0..3 of their pixel column ----
     if (lane < 16) {
 #pragma unroll

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         }
     }
 
-    if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, 1u);      // (rare: one atomic per saturating thread)
+    if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, amax > 0x7f800000u ? 3u : 1u);      // bit 1: a NaN among them      // (rare: one atomic per saturating thread)
     unsigned amax_o = 0u;                                     // SO, split f16: the same guard on what this launch stores
     // ---- epilogue: D fragment map col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile) ----
     float st1[TNt], st2[TNt];                                 // per-channel sums of the stored values (ConvArgs.stats: BatchNorm statistics of the consumer)
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         else { if (general) HX_EPI(false, 2); else if (masked) HX_EPI(false, (E_MASK ? 1 : 0)); else HX_EPI(false, 0); }
 #undef HX_EPI
     }
-    if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag, 1u);
+    if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag, amax_o > 0x7f800000u ? 3u : 1u);
     // ---- BatchNorm partial sums of this tile: the two 32-lane halves of a wave hold different pixel rows of one channel, the WM waves of a column
     // block different rows too -> shuffle, then LDS (the staging tiles are dead), one plain store per (tile, channel): no atomics, fixed order ----
     if (EP == 0 && a.stats != nullptr) {                      // (grid-uniform; the launcher only passes it with splitk == 1)

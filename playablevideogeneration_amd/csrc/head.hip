@@ -396,7 +396,14 @@ __global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1
         acc[LOSS_TOTAL] += term / 3.0;
     }
 }
-__global__ void k_report_flag(const unsigned* flag, double* slot) { *slot = *flag != 0 ? 1.0 : 0.0; }
+// f16 range guards of the forward pass (one word per layer, common.h: ConvArgs.sat_flag): slot = 1 if any layer clamped a value; a NaN among the clamped values makes the total NaN --
+// v_med3 turned it into a finite operand, the reference would have propagated it into every loss
+__global__ void k_report_flag(const unsigned* flags, int n, double* slot, double* total) {
+    unsigned any = 0;
+    for (int i = threadIdx.x; i < n; i += 64) any |= flags[i];
+    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
+    if (threadIdx.x == 0) { *slot = (any & 1u) ? 1.0 : 0.0; if (any & 2u) *total = __builtin_nan(""); }
+}
 // Evaluation, per frame (evaluation/evaluator.py:192,194: SequenceLossEvaluator over ObservationsLoss / StatesLoss): acc[n] += sum over image n of |a - b| (sq = 0) or
 // (a - b)^2 (sq = 1) over the first C channels; image n of `a` is frame (n / Tb) * Ta + n % Tb + a_off of the (B, Ta) sequence, image n of `b` is n.  blockIdx.y = n.
 __global__ __launch_bounds__(256) void k_diff_per_frame(TV a, int Ta, int a_off, TV b, int Tb, int C, int sq, double* acc) {
@@ -587,8 +594,8 @@ int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, doubl
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden, l, lv ? 1 : 0);
     return 0;
 }
-int loss_report_flag(const unsigned* flag, double* slot, hipStream_t st) {
-    hipLaunchKernelGGL(k_report_flag, dim3(1), dim3(1), 0, st, flag, slot);
+int loss_report_flag(const unsigned* flags, int n, double* slot, double* total, hipStream_t st) {
+    hipLaunchKernelGGL(k_report_flag, dim3(1), dim3(64), 0, st, flags, n, slot, total);
     return 0;
 }
 int loss_diff_per_frame(const TV& a, int Ta, int a_off, const TV& b, int Tb, int C, int sq, double* acc, hipStream_t st) {

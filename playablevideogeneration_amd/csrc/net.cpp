@@ -55,11 +55,13 @@ void build_param_table(const caddy_config& c, std::vector<ParamEntry>& t, long* 
     TB b{t};
     const int Cs = 64, aux = c.actions + c.action_dim, Ch = c.hidden, hs = c.height / 8, ws = c.width / 8;
     b.add("state_to_hidden_state_layer.0.weight", {Ch, Cs, 3, 3}, 0); b.add("state_to_hidden_state_layer.0.bias", {Ch}, 0);
-    std::string p = "action_network.0";
-    b.res(p + ".residuals.0", Cs, 2 * Cs, 2); b.res(p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
-    b.add(p + ".mean_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".mean_fc.bias", {c.action_dim}, 0);
-    b.add(p + ".variance_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".variance_fc.bias", {c.action_dim}, 0);
-    b.add(p + ".final_fc.weight", {c.actions, c.action_dim}, 0); b.add(p + ".final_fc.bias", {c.actions}, 0);
+    for (int m = 0; m < (c.ensemble > 1 ? c.ensemble : 1); m++) {      // nn.ModuleList of ensamble_size ActionNetworks (model.py:47)
+        std::string p = "action_network." + std::to_string(m);
+        b.res(p + ".residuals.0", Cs, 2 * Cs, 2); b.res(p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
+        b.add(p + ".mean_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".mean_fc.bias", {c.action_dim}, 0);
+        b.add(p + ".variance_fc.weight", {c.action_dim, 2 * Cs}, 0); b.add(p + ".variance_fc.bias", {c.action_dim}, 0);
+        b.add(p + ".final_fc.weight", {c.actions, c.action_dim}, 0); b.add(p + ".final_fc.bias", {c.actions}, 0);
+    }
     const int lc[3][2] = {{Cs + aux, Ch}, {2 * Ch + aux, 2 * Ch}, {Ch + aux, Ch}};
     for (int i = 0; i < 3; i++) {
         std::string q = "dynamics_network.recurrent_layers_blocks." + std::to_string(i);
@@ -132,6 +134,8 @@ void make_conv(caddy_ctx* c, ConvL& L, const std::vector<std::string>& wn, const
     if (KS == 3 && d.Cin >= 32 && d.Cout >= 32) L.wq = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2));
     for (int s = 0; s < d.nseg; s++)
         if (KS == 3 && segC[s] >= 32 && d.Cout >= 32) L.wqd[s] = c->persist.alloc(hx_weight_bytes(d, s, round_up(segC[s], hx_pick_bn(segC[s])), 2));
+    L.flag_idx = (int)c->convs.size();
+    if (L.flag_idx >= CADDY_VGG_FLAG0) { set_error("internal: too many convolution layers for the range-guard flag table"); c->fail = true; L.flag_idx = 0; }
     c->convs.push_back(&L);
 }
 void make_bn(caddy_ctx* c, BNL& b, const std::string& p) {
@@ -161,14 +165,20 @@ void build_layers(caddy_ctx* c) {
     const int Cs = 64, aux = g.actions + g.action_dim, Ch = g.hidden;
     c->hs = g.height / 8; c->ws = g.width / 8;
     make_conv(c, c->s2h, {"state_to_hidden_state_layer.0.weight"}, "state_to_hidden_state_layer.0.bias", 3, {Cs});
-    std::string p = "action_network.0";
-    make_res(c, c->a_res[0], p + ".residuals.0", Cs, 2 * Cs, 2); make_res(c, c->a_res[1], p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
-    HeadParams& h = c->hp;
-    h.F = 2 * Cs; h.Da = g.action_dim; h.K = g.actions;
-    h.Wm = PP(c, p + ".mean_fc.weight"); h.bm = PP(c, p + ".mean_fc.bias"); h.Wv = PP(c, p + ".variance_fc.weight"); h.bv = PP(c, p + ".variance_fc.bias");
-    h.Wf = PP(c, p + ".final_fc.weight"); h.bf = PP(c, p + ".final_fc.bias");
-    h.dWm = GP(c, p + ".mean_fc.weight"); h.dbm = GP(c, p + ".mean_fc.bias"); h.dWv = GP(c, p + ".variance_fc.weight"); h.dbv = GP(c, p + ".variance_fc.bias");
-    h.dWf = GP(c, p + ".final_fc.weight"); h.dbf = GP(c, p + ".final_fc.bias");
+    c->n_members = g.ensemble > 1 ? g.ensemble : 1;
+    for (int m = 0; m < c->n_members; m++) {
+        std::string p = "action_network." + std::to_string(m);
+        make_res(c, c->a_res[m][0], p + ".residuals.0", Cs, 2 * Cs, 2); make_res(c, c->a_res[m][1], p + ".residuals.1", 2 * Cs, 2 * Cs, 1);
+        HeadParams& h = c->hp[m];
+        h.F = 2 * Cs; h.Da = g.action_dim; h.K = g.actions;
+        h.Wm = PP(c, p + ".mean_fc.weight"); h.bm = PP(c, p + ".mean_fc.bias"); h.Wv = PP(c, p + ".variance_fc.weight"); h.bv = PP(c, p + ".variance_fc.bias");
+        h.Wf = PP(c, p + ".final_fc.weight"); h.bf = PP(c, p + ".final_fc.bias");
+        h.dWm = GP(c, p + ".mean_fc.weight"); h.dbm = GP(c, p + ".mean_fc.bias"); h.dWv = GP(c, p + ".variance_fc.weight"); h.dbv = GP(c, p + ".variance_fc.bias");
+        h.dWf = GP(c, p + ".final_fc.weight"); h.dbf = GP(c, p + ".final_fc.bias");
+        long lo = -1, hi = -1;      // trainable range of this member (kind-0 entries are laid out in table order: one contiguous range per member)
+        for (auto& e : c->table) if (e.kind == 0 && e.name.rfind(p + ".", 0) == 0) { if (lo < 0 || e.offset < lo) lo = e.offset; long en = e.offset + (e.numel + 3) / 4 * 4; if (en > hi) hi = en; }
+        c->member_lo[m] = lo < 0 ? 0 : lo; c->member_hi[m] = lo < 0 ? 0 : hi;
+    }
     const int lc[3][2] = {{Cs, Ch}, {2 * Ch, 2 * Ch}, {Ch, Ch}};
     for (int i = 0; i < 3; i++) {
         std::string q = "dynamics_network.recurrent_layers_blocks." + std::to_string(i);
@@ -249,7 +259,7 @@ void build_layers(caddy_ctx* c) {
         for (auto& kv : bnd) { kv.first->dgamma_d = (float*)(pool + kv.second); kv.first->dbeta_d = kv.first->dgamma_d + round_up(kv.first->C, 4); }
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
-    c->sat_flag = (unsigned*)c->persist.alloc(256);
+    c->sat_flag = (unsigned*)c->persist.alloc(sizeof(unsigned) * CADDY_N_FLAGS);
     c->wgrad_det_cap = 16L << 20;      // 64 MB: >= 3 copies of the largest packed weight gradient (ConvLSTM 1 gates, 9 x 1024 x 528), 256 of a 64 x 64 layer
     c->wgrad_det = (float*)c->persist.alloc(sizeof(float) * c->wgrad_det_cap);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
@@ -487,7 +497,13 @@ void caddy_ctx::launch_wgrad_jobs() {
 }
 int caddy_ctx::launch_conv_wgrad(const WgradArgs& a0, double flops, hipStream_t stream) {
     WgradArgs a = a0;
-    if (deterministic) { a.det_slab = wgrad_det; a.det_cap = wgrad_det_cap; }
+    if (deterministic) {
+        // ONE scratch, zero-filled, filled and folded per launch: correct only while every weight-gradient launch of a backward pass goes to one stream (the side stream, or the caller's
+        // under CADDY_STREAMS=0).  A second stream would silently corrupt gradients in exactly the mode that promises bit-reproducibility: refuse it loudly.
+        if (wgrad_det_owner_set && wgrad_det_owner != stream) { fail = true; set_error("internal: the deterministic weight-gradient scratch was used from two streams in one backward pass"); return -1; }
+        wgrad_det_owner = stream; wgrad_det_owner_set = true;
+        a.det_slab = wgrad_det; a.det_cap = wgrad_det_cap;
+    }
     if (!prof) return conv_wgrad_launch(a, stream);
     int cin = 0; for (int s = 0; s < a.nsrc; s++) cin += a.src[s].bcast ? 0 : a.src[s].C;
     const double px = (double)a.N * a.H * a.W;
@@ -512,8 +528,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     g_last_conv_lstm_fused = 0;
     if (lstm_fuse) { a.lstm = lstm_fuse; lstm_fuse = nullptr; }      // (set by lstm_step for the gate convolution of a roll-out cell)
-    if (L.wq && prec_fwd != PREC_FP32) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
-    else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32) { a.precision = PREC_F16X3; a.sat_flag = sat_flag; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
+    const bool range_ok = !layer_fallback[L.flag_idx];      // (a layer that reported |x| > 65504 stays on the exact-fp32 forward: caddy_f16_saturated)
+    if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
+    else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32 && range_ok) { a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
     for (int s = 0; s < nseg; s++)
         if (segs[s].t.bn_scale && !conv_src_lazy_ok(a)) { fail = true; set_error("internal: lazily normalised input handed to a convolution that cannot apply it"); }
     TileStats* ts_slot = nullptr;
@@ -661,7 +678,7 @@ static BNStash bn_forward(caddy_ctx* c, const T4& x, BNL& bn) {
 }
 // can `consumer` (a 3x3 convolution reading x's normalised form as one of its segments, same H x W) apply the BatchNorm while staging -- forward AND weight gradient?
 bool caddy_ctx::lazy_ok(const ConvL& consumer, const T4& x) const {
-    if (!lazy_bn || !consumer.wq || prec_fwd == PREC_FP32 || consumer.pd.KS != 3) return false;
+    if (!lazy_bn || !consumer.wq || prec_fwd == PREC_FP32 || consumer.pd.KS != 3 || layer_fallback[consumer.flag_idx]) return false;
     if (recording) {      // its weight gradient must run on k_wgrad_hx (conv_hx_wgrad_try's conditions)
         if (prec_bwd == PREC_FP32 || consumer.pd.Cout < 32 || consumer.pd.Ktot < 32 || x.W < 8 || x.H < 2) return false;
     }
@@ -872,10 +889,12 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     H.att = alloc(NT, hs, ws, 1);
     RUN(pw_attn_mul(dv(x65), dv(st), dv(H.att), stream));
     if (recording) { T4 att = H.att; tp->push_back([=]() { TV none{}; (void)att; RUN(pw_attn_mul_bwd(dv(x65), gv(st), none, gv(x65), stream)); }); }
-    T4 r = resblock(a_res[0], st, nullptr, !a_res[1].has_down);
-    r = resblock(a_res[1], r, nullptr);
+    ResL* const ar = a_res[member];                          // the member drawn for this forward pass (both A calls: model.py:152,274)
+    const HeadParams hpv = hp[member];
+    T4 r = resblock(ar[0], st, nullptr, !ar[1].has_down);
+    r = resblock(ar[1], r, nullptr);
     HeadBufs& b = H.b;
-    float* feat = falloc((size_t)NT * hp.F);
+    float* feat = falloc((size_t)NT * hpv.F);
     RUN(pw_gap(dv(r), feat, stream));
     b.feat = feat; b.d_feat = tw(this, feat);
     if (recording) { float* df = b.d_feat; tp->push_back([=]() { RUN(pw_gap_bwd(df, gv(r), stream)); }); }
@@ -890,7 +909,7 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
     b.g_dmu = falloc((size_t)NS * Da); b.g_dvar = falloc((size_t)NS * Da);
     b.g_mu = falloc((size_t)NT * Da); b.g_raw = falloc((size_t)NT * Da);
     b.d_logits = tw(this, b.logits); b.d_ddist = tw(this, b.ddist); b.d_sdist = tw(this, b.sdist); b.d_aux = tw(this, b.aux);
-    RUN(head_forward(b, hp, B, T, stream));
+    RUN(head_forward(b, hpv, B, T, stream));
     SampleCfg& sc = H.sc;
     sc = SampleCfg{};
     sc.mode = samples_in ? 2 : (cfg.use_gumbel ? 1 : 0); sc.hard = cfg.hard_gumbel; sc.training = training ? 1 : 0; sc.use_variations = cfg.use_variations;
@@ -901,12 +920,12 @@ void caddy_ctx::action_net(const T4& x65, HeadState& H, const float* eps_s, cons
         sh.samples_buf = falloc((size_t)NS * K); sh.var_buf = falloc((size_t)NS * Da);       // always allocated: the arena layout must not depend on the hooks
         if (samples_in) sh.action = 0;
         if (variations_in) sh.variation = 0;
-        RUN(head_sample(b, hp, sc, NS, cs, hook, hook_user, sh.fn ? &sh : nullptr, stream));
+        RUN(head_sample(b, hpv, sc, NS, cs, hook, hook_user, sh.fn ? &sh : nullptr, stream));
         if (sh.fn && sh.action) { sc.mode = 2; sc.samples_in = sh.samples_buf; }             // what the backward pass must assume
         if (sh.fn && sh.variation) sc.variations_in = sh.var_buf;
     }
     if (recording) { HeadBufs bb = b; SampleCfg s2 = sc; tp->push_back([=]() { if (first) join_aux(stream);      // d(action / variation inputs) of every time step
-                                                                               RUN(head_backward(bb, hp, s2, B, T, first ? 1 : 0, stream)); }); }
+                                                                               RUN(head_backward(bb, hpv, s2, B, T, first ? 1 : 0, stream)); }); }
 }
 
 void caddy_ctx::add_job(JobList& jl, const PackDesc& d, void* buf, int kind, int seg, int p0, int p1, long total) {
@@ -1021,7 +1040,6 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
     c->mark("fwd:begin");
-    if (!dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream);
     c->pack_all();
     c->mark("fwd:packed");
     caddy_noise z{}; if (nz) z = *nz;
@@ -1101,7 +1119,6 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
-    if (!dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream);
     c->pack_all();
     caddy_noise z{}; if (nz) z = *nz;
     c->obs = c->alloc(B * T, H, W, 3 * S);
@@ -1202,6 +1219,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     }
     if (!dry) c->ensure_side();
     c->sev_used = 0;
+    c->wgrad_det_owner_set = false;
     LossWeights w{lc->rec, lc->states, lc->entropy, lc->dir_kl, lc->mi, lc->state_kl, lc->hidden, lc->mi_entropy_lambda, lc->perceptual};
     double nr[3];
     const int Trec = c->pretraining ? T : T - 1;      // pretraining reconstructs all T frames (losses.py:83-87)
@@ -1262,7 +1280,7 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     c->mark("bwd:A1 + E(gt)");
     c->unpack_all();
     c->mark("bwd:join + unpack");
-    if (!dry) c->ck(loss_report_flag(c->sat_flag, c->loss_acc + LOSS_F16_SATURATED, st), "saturation flag");      // after the VGG19 forward passes of this call, on whatever stream they ran
+    if (!dry) c->ck(loss_report_flag(c->sat_flag, CADDY_N_FLAGS, c->loss_acc + LOSS_F16_SATURATED, c->loss_acc + LOSS_TOTAL, st), "saturation flag");      // after the VGG19 forward passes of this call, on whatever stream they ran; a NaN among the clamped values poisons the total (the reference would have propagated it)
     if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); if (!lc->no_sync) hipStreamSynchronize(st); }
     return finish(c);
 }
@@ -1412,8 +1430,8 @@ static int get_output(caddy_ctx* c, int id, void* dst, bool grad) {
 static bool check_cfg(const caddy_config* g) {
     if (!g || g->batch < 1 || g->seq_len < 2 || g->height % 16 || g->width % 16 || g->height < 16 || g->width < 16 || g->stacking < 1 ||
         g->actions < 1 || g->actions > 16 || g->action_dim < 1 || g->action_dim > 8 || g->actions + g->action_dim > AUX_LD ||
-        (g->variant != 0 && g->variant != 1) || g->hidden != (g->variant == 0 ? 128 : 64)) {
-        set_error("invalid caddy_config (H, W multiples of 16; hidden 128 for main / 64 for reduced; K<=16; Da<=8)");
+        (g->variant != 0 && g->variant != 1) || g->hidden != (g->variant == 0 ? 128 : 64) || g->ensemble < 0 || g->ensemble > CADDY_MAX_ENSEMBLE) {
+        set_error("invalid caddy_config (H, W multiples of 16; hidden 128 for main / 64 for reduced; K<=16; Da<=8; ensemble <= 8)");
         return false;
     }
     if (g->perceptual && (g->height < 64 || g->width < 64)) {      // the quarter-resolution image must survive four 2x2 max-pools (relu5_1)
@@ -1474,6 +1492,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (caddy_serial_streams()) c->use_dstream = false;
+    hipMemset(c->sat_flag, 0, sizeof(unsigned) * CADDY_N_FLAGS);      // (sticky until polled: caddy_f16_saturated)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
@@ -1519,15 +1538,28 @@ int caddy_forward_pretraining(caddy_ctx* c, const float* obs, float tau, const c
 int caddy_get_output(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, false); }
 int caddy_get_output_grad(caddy_ctx* c, int id, void* dst) { return get_output(c, id, dst, true); }
 int caddy_loss_backward(caddy_ctx* c, const caddy_loss_cfg* cfg, double* losses_host) { c->fail = false; return loss_backward(c, cfg, losses_host); }
-int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
+int caddy_set_action_member(caddy_ctx* c, int member) {
+    if (member < 0 || member >= c->n_members) { set_error("caddy_set_action_member: member out of range"); return -2; }
+    c->member = member; return 0;
+}
+int caddy_adam_step_member(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, int member_step, float gscale) {
     // torch.optim.Adam skips parameters whose .grad is None -- no moment update, no weight decay.  After forward_full_model that is
-    // state_to_hidden_state_layer (only forward_pretraining uses it, model.py:41-43,413): leave its range untouched.
-    long lo = 0, hi = 0;
-    if (!c->pretraining && c->s2h_hi > c->s2h_lo) { lo = c->s2h_lo; hi = c->s2h_hi; }
+    // state_to_hidden_state_layer (only forward_pretraining uses it, model.py:41-43,413); with an ensemble of action networks also every member that was not drawn for
+    // this step (model.py:152).  The drawn member's range is stepped with its own count (torch keeps `step` per parameter).
+    struct Rng { long lo, hi; int mode; };      // mode 0: skip, 1: member_step
+    std::vector<Rng> special;
+    if (!c->pretraining && c->s2h_hi > c->s2h_lo) special.push_back({c->s2h_lo, c->s2h_hi, 0});
+    if (c->n_members > 1) for (int k = 0; k < c->n_members; k++) if (c->member_hi[k] > c->member_lo[k]) special.push_back({c->member_lo[k], c->member_hi[k], k == c->member ? 1 : 0});
+    std::sort(special.begin(), special.end(), [](const Rng& a, const Rng& b) { return a.lo < b.lo; });
     int rc = 0;
-    if (lo > 0) rc = adam_launch(c->P, c->G, m, v, lo, lr, b1, b2, eps, wd, step, gscale, c->stream);
-    if (!rc && hi < c->n_train) rc = adam_launch(c->P + hi, c->G + hi, m + hi, v + hi, c->n_train - hi, lr, b1, b2, eps, wd, step, gscale, c->stream);
+    long pos = 0;
+    auto run = [&](long lo, long hi, int st) { if (!rc && hi > lo) rc = adam_launch(c->P + lo, c->G + lo, m + lo, v + lo, hi - lo, lr, b1, b2, eps, wd, st, gscale, c->stream); };
+    for (const Rng& r : special) { run(pos, r.lo, step); if (r.mode == 1) run(r.lo, r.hi, member_step); pos = r.hi; }
+    run(pos, c->n_train, step);
     return rc;
+}
+int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
+    return caddy_adam_step_member(c, m, v, lr, b1, b2, eps, wd, step, step, gscale);
 }
 int caddy_vgg_param_count(void) { return vgg_param_count(); }
 int caddy_vgg_param_info_get(int index, caddy_param_info* out) { return vgg_param_info(index, out); }
@@ -1574,14 +1606,26 @@ int caddy_set_precision(caddy_ctx* c, int forward, int backward) {
     if ((forward != PREC_FP32 && forward != PREC_F16X3) || (backward != PREC_FP32 && backward != PREC_BF16X3)) { set_error("caddy_set_precision: forward 0 | 16, backward 0 | 17"); return -2; }
     c->prec_fwd = forward; c->prec_bwd = backward; return 0;
 }
-int caddy_start_inference(caddy_ctx* c) { c->fail = false; if (!c->dry) hipMemsetAsync(c->sat_flag, 0, sizeof(unsigned), c->stream); return start_inference(c); }
-int caddy_f16_saturated(caddy_ctx* c) {      // waits for the stream: 1 if a split-f16 forward convolution met |x| > 65504 since the last forward / start_inference began
-    unsigned v = 0;
+int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inference(c); }
+// Poll of the per-layer f16 range guards: waits for the stream, reads and clears the flag words.  Returns bit 0: a split-f16 forward convolution (model or VGG19) staged |x| > 65504
+// since the last poll (it was clamped); bit 1: a NaN was among them.  The layers that reported -- and only those -- run without a range limit from the next forward on (exact fp32 /
+// split bf16 for VGG19); caddy_fallback_layers counts them.
+int caddy_f16_saturated(caddy_ctx* c) {
     if (c->dry) return 0;
-    hipMemcpyAsync(&v, c->sat_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    unsigned v[CADDY_N_FLAGS];
+    if (c->side) hipStreamSynchronize(c->side);      // (VGG19 levels / ground-truth branch)
+    hipMemcpyAsync(v, c->sat_flag, sizeof(v), hipMemcpyDeviceToHost, c->stream);
     hipStreamSynchronize(c->stream);
-    return v != 0;
+    unsigned any = 0;
+    for (int i = 0; i < CADDY_N_FLAGS; i++) if (v[i]) { any |= v[i]; if (!c->layer_fallback[i]) { c->layer_fallback[i] = true; c->n_fallback++; } }
+    if (any) {
+        hipMemsetAsync(c->sat_flag, 0, sizeof(v), c->stream);
+        if (c->graph_exec) { hipStreamSynchronize(c->stream); if (c->gstream) hipStreamSynchronize(c->gstream); }
+        c->drop_graph();      // (a captured roll-out frame still holds the split-f16 launches of the layers that just moved)
+    }
+    return (int)(any & 3u);
 }
+int caddy_fallback_layers(caddy_ctx* c) { return c->n_fallback; }
 int caddy_generate_next(caddy_ctx* c, const float* observation, int action, const float* variation, float* frame_out, float* obs_out) {
     c->fail = false;
     if (!observation || !frame_out) { set_error("null input"); return -2; }

@@ -51,8 +51,11 @@ struct Arena {
 };
 
 struct BNL;
+#define CADDY_N_FLAGS 128
+#define CADDY_VGG_FLAG0 96
 struct ConvL {
     PackDesc pd{};
+    int flag_idx = 0;                // index of this layer's f16-range-guard word (caddy_ctx::sat_flag) / fallback switch
     float* wp = nullptr; float* dwp = nullptr;
     bool early_bucket = false, early_done = false;   // member of the R / D gradient buckets that are final after the time loop's backward
     float* wpd[CONV_MAX_SRC] = {nullptr, nullptr, nullptr};
@@ -125,7 +128,9 @@ struct caddy_ctx {
     std::vector<BNL*> bns;
     // layers
     ConvL e_stem; BNL e_bn1; ResL e_res[6];
-    ResL a_res[2]; HeadParams hp{};
+    ResL a_res[CADDY_MAX_ENSEMBLE][2]; HeadParams hp[CADDY_MAX_ENSEMBLE]{};      // action_network.{m}: the ensemble members (model.py:47); one is drawn per forward pass (model.py:152)
+    int n_members = 1, member = 0;      // member of the current / next forward pass (caddy_set_action_member); both A calls of a pass use it
+    long member_lo[CADDY_MAX_ENSEMBLE] = {0}, member_hi[CADDY_MAX_ENSEMBLE] = {0};      // trainable ranges of the members in the flat buffers (Adam skips the members that were not drawn)
     LstmL lstm[3]; ConvL r_c0, r_c1, r_c2; BNL r_bn0, r_bn1, r_bn2;
     ConvL d_up[3]; BNL d_norm[3]; ResL d_res[2]; ConvL d_final[3];
     ConvL s2h;
@@ -153,7 +158,13 @@ struct caddy_ctx {
     // weight-gradient launch into its own copy of the packed layout + fixed-order reduce (WgradArgs.det_slab), single-workgroup bias sums
     bool deterministic = false;
     float* wgrad_det = nullptr; long wgrad_det_cap = 0;      // scratch of the deterministic weight gradients (the stream the weight gradients run on)
-    unsigned* sat_flag = nullptr;    // f16 range guard of the split-f16 forward (ConvArgs.sat_flag): ORed by any staging thread that met |x| > 65504 since the last forward began
+    hipStream_t wgrad_det_owner = nullptr; bool wgrad_det_owner_set = false;      // ... and that stream, per backward pass (launch_conv_wgrad refuses a second one)
+    // f16 range guard of the split-f16 forward (ConvArgs.sat_flag), per LAYER (round 5): word i belongs to convs[i] (model) / CADDY_VGG_FLAG0 + i (VGG19 conv i); ORed by any staging
+    // thread that met |x| > 65504 (| 2: a NaN); sticky on the device until caddy_f16_saturated() polls them, which also moves the reporting layers -- and only those -- onto a forward
+    // without a range limit (layer_fallback: exact fp32 for model layers, split bf16 for VGG19; sticky for the context's lifetime)
+    unsigned* sat_flag = nullptr;
+    bool layer_fallback[CADDY_N_FLAGS] = {false};
+    int n_fallback = 0;
     float* conv_split = nullptr; long conv_split_cap = 0;   // slabs of the deterministic forward split-K (main stream only)
     float* conv_aux = nullptr;       // CONV_AUX_BYTES scratch of the thin-channel conv kernels (main stream only)
     float* conv_aux2 = nullptr;      // ... of the VGG19 levels that run on the side stream (perceptual.hip)

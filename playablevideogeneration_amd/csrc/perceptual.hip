@@ -292,7 +292,9 @@ int conv_call(caddy_ctx* c, const ConvArgs& a, double flops, int kind) {
 // read them)
 bool vgg_use_s16(const caddy_ctx* c) { return c->vgg_s16 && c->vgg_precision == PREC_F16X3 && c->vgg_precision_bwd == PREC_BF16X3; }
 // is conv i's launch on an N x H x W input one of the k_conv_hx variants that read / write S16 tensors?
-bool vgg_io_ok(const caddy_ctx* c, int i, int N, int H, int W) { return vgg_use_s16(c) && VGG[i].cin >= 32 && conv_hx_s16_ok(N, H, W, VGG[i].cout); }
+bool vgg_io_ok(const caddy_ctx* c, int i, int N, int H, int W) {
+    return vgg_use_s16(c) && VGG[i].cin >= 32 && !c->layer_fallback[CADDY_VGG_FLAG0 + i] && conv_hx_s16_ok(N, H, W, VGG[i].cout);      // (a layer on the split-bf16 fallback exchanges fp32 tensors)
+}
 
 // 13 x (conv3x3 + bias + ReLU) with the 2x2 max-pools; taps[] (if given) receive the five tapped feature maps in place.
 // Formats (round 5): a feature map is written PRE-SPLIT (S16-f16, T4::fmt) by the epilogue of its producer when that launch and the launch of the convolution that consumes it
@@ -323,8 +325,11 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
         a.nsrc = 1; a.N = x.N; a.H = x.H; a.W = x.W; a.KS = 3; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
         a.bias = L.bias; a.act = 2; a.out = out.d; a.out_sn = out.sn; a.out_ld = out.ld;
         a.precision = c->vgg_precision == PREC_F16X1 ? PREC_F16X1 : (c->vgg_precision == PREC_FP32 ? PREC_FP32 : (c->vgg_precision == PREC_BF16X3 ? PREC_BF16X3 : PREC_F16X3));
+        // f16 range guard: real VGG19 weights on un-normalised inputs are where a forward activation could leave the f16 range.  A layer that reported it (caddy_f16_saturated) runs
+        // on split bf16 from then on -- 8 + 8 mantissa bits, the full fp32 exponent range -- and only that layer (round 4 moved the whole context to exact fp32: 2.2 x slower)
+        if (a.precision == PREC_F16X3 && c->layer_fallback[CADDY_VGG_FLAG0 + i]) a.precision = PREC_BF16X3;
         if (a.precision != PREC_FP32) a.wq = L.wq[a.precision == PREC_F16X1 ? 1 : (a.precision == PREC_BF16X3 ? 2 : 0)];
-        a.sat_flag = c->sat_flag;      // f16 range guard: real VGG19 weights on un-normalised inputs are where a forward activation could leave the f16 range
+        a.sat_flag = c->sat_flag + CADDY_VGG_FLAG0 + i;
         const bool io_here = vgg_io_ok(c, i, x.N, x.H, x.W);
         const bool pool_next = i + 1 < VGG_NCONV && VGG[i + 1].pool_before;
         a.in_s16 = x.fmt;

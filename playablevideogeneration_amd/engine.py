@@ -25,7 +25,7 @@ class CaddyConfig(C.Structure):
     _fields_ = [("variant", C.c_int), ("batch", C.c_int), ("seq_len", C.c_int), ("height", C.c_int), ("width", C.c_int),
                 ("stacking", C.c_int), ("actions", C.c_int), ("action_dim", C.c_int), ("hidden", C.c_int),
                 ("use_gumbel", C.c_int), ("hard_gumbel", C.c_int), ("use_variations", C.c_int), ("centroid_alpha", C.c_float),
-                ("perceptual", C.c_int)]
+                ("perceptual", C.c_int), ("ensemble", C.c_int)]
 
 
 class ParamInfo(C.Structure):
@@ -92,6 +92,8 @@ def _bind(lib):
     lib.caddy_get_output_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.caddy_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
+    lib.caddy_adam_step_member.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
+    lib.caddy_set_action_member.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_vgg_param_floats.restype = C.c_long
     lib.caddy_vgg_param_info_get.argtypes = [C.c_int, C.c_void_p]
     lib.caddy_load_vgg.argtypes = [C.c_void_p, C.c_void_p]
@@ -107,6 +109,7 @@ def _bind(lib):
     lib.caddy_set_precision.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.caddy_start_inference.argtypes = [C.c_void_p]
     lib.caddy_f16_saturated.argtypes = [C.c_void_p]
+    lib.caddy_fallback_layers.argtypes = [C.c_void_p]
     lib.caddy_perceptual_per_frame.argtypes = [C.c_void_p, C.c_void_p]
     lib.caddy_sequence_losses_per_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_set_deterministic.argtypes = [C.c_void_p, C.c_int]
@@ -125,12 +128,12 @@ class CaddyError(Exception):
 class Engine:
     def __init__(self, *, variant: str, batch: int, seq_len: int, height: int, width: int, stacking: int, actions: int,
                  action_dim: int, hidden: int, use_gumbel=True, hard_gumbel=False, use_variations=True, centroid_alpha=0.1,
-                 device="cuda", lib=None, params=None, grads=None, perceptual=False):
+                 device="cuda", lib=None, params=None, grads=None, perceptual=False, ensemble=1):
         self.lib = _bind(lib if lib is not None else _lib.load())
         self.device = torch.device(device)
         self.cfg = CaddyConfig(0 if variant == "main" else 1, batch, seq_len, height, width, stacking, actions, action_dim, hidden,
-                               int(use_gumbel), int(hard_gumbel), int(use_variations), centroid_alpha, int(perceptual))
-        self.perceptual, self.vgg_loaded = bool(perceptual), False
+                               int(use_gumbel), int(hard_gumbel), int(use_variations), centroid_alpha, int(perceptual), int(ensemble))
+        self.perceptual, self.vgg_loaded, self.ensemble = bool(perceptual), False, int(ensemble)
         self.B, self.T, self.H, self.W, self.S, self.K, self.Da, self.Ch = batch, seq_len, height, width, stacking, actions, action_dim, hidden
         n = self.lib.caddy_param_floats(C.byref(self.cfg))
         if n <= 0:
@@ -217,10 +220,12 @@ class Engine:
             if world > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
             uid, ok = box[0]
+            rc = 0
             if ok:
                 self._stream()
-                ok = int(self.lib.caddy_dp_init(self.ctx, uid, world, rank, int(bool(overlap))) == 0)
-            if not ok and "did not return within" in self._err():      # a rank never arrived: the other ranks' state is unknown, there is nothing to fall back to
+                rc = int(self.lib.caddy_dp_init(self.ctx, uid, world, rank, int(bool(overlap))))
+                ok = int(rc == 0)
+            if rc == -3:      # the library's own code for "ncclCommInitRank did not return in time" (dp_rccl.cpp): a rank never arrived, the others' state is unknown, nothing to fall back to
                 raise RuntimeError(self._err())
             if world > 1:      # every rank must take the same path: one failed communicator sends all of them to the hook path
                 flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
@@ -445,6 +450,7 @@ class Engine:
     def forward_full(self, obs: torch.Tensor, gt_init: int, tau: float, noise: Dict[str, torch.Tensor], training=True,
                      samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
         obs, cn, si, vi = self._prepare(obs, noise, samples_in, variations_in)
+        self.last_pretraining = False
         self._check(self.lib.caddy_forward_full(self.ctx, obs.data_ptr(), gt_init, float(tau), C.byref(cn), int(training),
                                                 si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
         return self._fetch(False) if fetch_outputs else None      # fused-loss training: outputs stay in the workspace
@@ -452,6 +458,7 @@ class Engine:
     def forward_pretraining(self, obs: torch.Tensor, tau: float, noise: Dict[str, torch.Tensor], training=True,
                             samples_in: Optional[torch.Tensor] = None, variations_in: Optional[torch.Tensor] = None, fetch_outputs=True) -> List:
         obs, cn, si, vi = self._prepare(obs, noise, samples_in, variations_in)
+        self.last_pretraining = True
         self._check(self.lib.caddy_forward_pretraining(self.ctx, obs.data_ptr(), float(tau), C.byref(cn), int(training),
                                                        si.data_ptr() if si is not None else None, vi.data_ptr() if vi is not None else None))
         return self._fetch(True) if fetch_outputs else None
@@ -490,12 +497,18 @@ class Engine:
         self._check(self.lib.caddy_loss_backward(self.ctx, C.byref(lc), host))
         return _losses_dict(host, bool(diagnostics), with_perc)
 
-    def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0):
+    def set_action_member(self, member: int):
+        """model.action_network.ensamble_size > 1: the action network both A calls of the NEXT forward pass use (model.py:152,274: random.choice(self.action_network))"""
+        self._check(self.lib.caddy_set_action_member(self.ctx, int(member)))
+
+    def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0, member_step=None):
+        """member_step: step count of the ensemble member this pass used (torch.optim.Adam keeps `step` per parameter, and a member that was not drawn is not stepped);
+        None = `step`"""
         if self.adam_m is None:
             self.adam_m, self.adam_v = torch.zeros_like(self.grads), torch.zeros_like(self.grads)
         self._stream()
-        self._check(self.lib.caddy_adam_step(self.ctx, self.adam_m.data_ptr(), self.adam_v.data_ptr(), lr, betas[0], betas[1], eps,
-                                             weight_decay, step, grad_scale))
+        self._check(self.lib.caddy_adam_step_member(self.ctx, self.adam_m.data_ptr(), self.adam_v.data_ptr(), lr, betas[0], betas[1], eps,
+                                                    weight_decay, step, step if member_step is None else int(member_step), grad_scale))
 
     # ---- roll-out (Model.start_inference / generate_next) ----
     def sequence_losses_per_frame(self, pretraining=False):
@@ -517,10 +530,17 @@ class Engine:
         self._check(self.lib.caddy_perceptual_per_frame(self.ctx, out.data_ptr()))
         return out
 
+    def numerics_flags(self) -> int:
+        """Poll of the per-layer f16 range guards (waits for the stream; reads and clears them).  Bit 0: a split-f16 forward convolution (model or VGG19) met |x| > 65504 since the
+        last poll and clamped it; bit 1: a NaN was among them.  The layers that reported move to a forward without a range limit (exact fp32 / split bf16 for VGG19) for good."""
+        return int(self.lib.caddy_f16_saturated(self.ctx))
+
     def f16_saturated(self) -> bool:
-        """True if a split-f16 forward convolution (model or VGG19) met |x| > 65504 since the last forward / start_inference began: the value was clamped to the f16 range.
-        Remedy: `set_precision(0, 17)` / `set_vgg_precision(0, 17)` (exact-fp32 forward).  Waits for the stream."""
-        return bool(self.lib.caddy_f16_saturated(self.ctx))
+        return bool(self.numerics_flags() & 1)
+
+    def fallback_layers(self) -> int:
+        """convolution layers this engine has moved off the split-f16 forward after a range-guard report"""
+        return int(self.lib.caddy_fallback_layers(self.ctx))
 
     def start_inference(self):
         self._stream()

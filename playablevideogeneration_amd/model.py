@@ -11,6 +11,8 @@ torch's global CPU generator with the reference's calls in the reference's order
 reference's action samples bit-for-bit.
 """
 import ctypes as C
+import random
+import warnings
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -57,13 +59,16 @@ class Model(nn.Module):
                          stacking=config["training"]["batching"]["observation_stacking"], actions=config["data"]["actions_count"],
                          action_dim=an["action_space_dimension"], hidden=config["model"]["dynamics_network"]["hidden_state_size"],
                          use_gumbel=bool(an["use_gumbel"]), hard_gumbel=bool(an["hard_gumbel"]), use_variations=bool(an.get("use_variations", True)),
-                         centroid_alpha=config["model"]["centroid_estimator"]["alpha"])
+                         centroid_alpha=config["model"]["centroid_estimator"]["alpha"], ensemble=int(an.get("ensamble_size", 1)))
+        if not 1 <= self.dims["ensemble"] <= 8:
+            raise Exception("model.action_network.ensamble_size must be between 1 and 8")
+        self.last_member = 0           # ensemble member of the last forward pass (model.py:152: random.choice(self.action_network))
         self.random_noise_size = config["model"]["dynamics_network"]["random_noise_size"]
         self.current_temperature = an["gumbel_temperature"]      # GumbelSoftmax.current_temperature (gumbel_softmax.py:21)
         self._lib = _bind(lib if lib is not None else _lib.load())
         d = self.dims
         cc = CaddyConfig(0 if d["variant"] == "main" else 1, 1, 2, d["height"], d["width"], d["stacking"], d["actions"], d["action_dim"], d["hidden"],
-                         int(d["use_gumbel"]), int(d["hard_gumbel"]), int(d["use_variations"]), d["centroid_alpha"])
+                         int(d["use_gumbel"]), int(d["hard_gumbel"]), int(d["use_variations"]), d["centroid_alpha"], 0, d["ensemble"])
         n = self._lib.caddy_param_floats(C.byref(cc))
         if n <= 0:
             raise Exception(self._lib.caddy_last_error().decode())
@@ -79,8 +84,6 @@ class Model(nn.Module):
         self._bn_counters: Dict[str, torch.Tensor] = {}
         self._register_tree()
         init_parameters(self, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
-        if an.get("ensamble_size", 1) != 1:
-            raise Exception("model.action_network.ensamble_size != 1 is not supported (every reference config uses 1; model.py:152 draws the member at random)")
         self._engines: Dict[Tuple[int, int], Engine] = {}
         self._vgg_state = None           # VGG19 weights of the perceptual loss (set by the trainer: enable_perceptual)
         self._infer: Optional[Engine] = None
@@ -250,6 +253,16 @@ class Model(nn.Module):
         if action_sampler is not None:                       # model.py:172-173: actions[:, :-1].reshape((-1,))
             gt_actions = batch_tuple[1][:, :-1].reshape((-1,)).to(self._flat.device)
         eng.set_samplers(action_sampler, action_variation_sampler, gt_actions)
+        # model.py:152 / :358: `random.choice(self.action_network)` -- one draw from Python's global `random` state per forward pass, also for an ensemble of one.  Under
+        # torch.distributed the reference's single process drew once for all replicas: rank 0's draw is broadcast (the members that were not drawn are not stepped by Adam)
+        member = random.choice(range(d_ens := self.dims["ensemble"]))
+        if d_ens > 1 and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            mt = torch.tensor([member], dtype=torch.int64, device=self._flat.device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.broadcast(mt, 0)
+            member = int(mt.item())
+        if d_ens > 1:
+            eng.set_action_member(member)
+        self.last_member = member
         if gumbel_temperature is not None:
             self.current_temperature = gumbel_temperature
         d = self.dims
@@ -269,8 +282,21 @@ class Model(nn.Module):
                                    training=self.training, fetch_outputs=fetch_outputs)
         if self.training:
             self._sync_bn_counters(eng, (B, T))
+        else:
+            self._check_numerics(eng)      # (training passes report through the loss call: trainer._check_saturation)
         self.last_engine = eng
         return tuple(out) if out is not None else None
+
+    @staticmethod
+    def _check_numerics(eng):
+        """f16 range guards of the split-f16 forward on passes without a loss call (evaluation, roll-out): a clamped activation is reported once and the layers that met it move to a
+        forward without a range limit; a NaN -- which the clamp would have hidden -- raises, as the reference's fp32 arithmetic would have produced NaN outputs"""
+        bits = eng.numerics_flags()
+        if bits & 2:
+            raise Exception("NaN activation in the forward pass (found by the f16 range guard of the split-f16 convolutions)")
+        if bits & 1:
+            warnings.warn(f"a forward activation exceeded the f16 range (|x| > 65504) and was clamped in the pass that just ran; {eng.fallback_layers()} convolution "
+                          "layer(s) now run without a range limit -- repeat the pass for unclamped results")
 
     # ---- play.py path (model.py:561-607) ---------------------------------------------------------------------------------
     def start_inference(self):
@@ -284,7 +310,12 @@ class Model(nn.Module):
             raise Exception("start_inference() must be called before generate_next()")
         variation = torch.randn((1, self.dims["action_dim"]), dtype=torch.float32)[0] if noise else None
         torch.randn((1, self.random_noise_size))             # generate_noise(batch_size=1), unused by R (model.py:596)
-        return self._infer.generate_next(observation, action, variation)
+        out = self._infer.generate_next(observation, action, variation)
+        self._frames_since_poll = getattr(self, "_frames_since_poll", 0) + 1
+        if self._frames_since_poll >= 64:                    # (a poll waits for the stream: not every frame)
+            self._frames_since_poll = 0
+            self._check_numerics(self._infer)
+        return out
 
     def generate_next_interpolation(self, observation: torch.Tensor, first_action: int, second_action: int, interpolation_factor: float):
         """model.py:609-655: act with the centroid nearer to the interpolated point, the offset to it as the action variation."""

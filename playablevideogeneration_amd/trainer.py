@@ -35,8 +35,9 @@ class Trainer:
         # options of the reference this path does not implement must not be ignored silently
         if tr.get("use_motion_weights", False):
             raise Exception("training.use_motion_weights is not supported by playablevideogeneration_amd.trainer (MotionLossWeightMaskCalculator, training/losses.py:591-649)")
-        if config["model"]["action_network"].get("ensamble_size", 1) != 1:
-            raise Exception("model.action_network.ensamble_size != 1 is not supported by playablevideogeneration_amd (the reference configs all use 1)")
+        # ensemble of action networks (model.py:28,47,152): torch.optim.Adam keeps `step` per parameter and skips parameters without a gradient, so every member carries its own
+        # step count (= the number of passes it was drawn for)
+        self.member_steps = [0] * int(config["model"]["action_network"].get("ensamble_size", 1))
         lw = tr["loss_weights"]
         self.perceptual_lambda = float(lw.get("perceptual_loss_lambda", 0.0))
         self.perceptual_lambda_pretraining = float(lw.get("perceptual_loss_lambda_pretraining", 0.0))
@@ -54,6 +55,7 @@ class Trainer:
         self.adam_m = self.adam_v = None
         self.mi_ema = None
         self.opt_steps = 0
+        self.s2h_steps = 0      # optimiser steps that followed a PRETRAINING pass: the only ones in which state_to_hidden_state_layer has a gradient (model.py:41-43,413) -- its own Adam step count
 
     @staticmethod
     def _find_vgg_weights(tr):
@@ -171,15 +173,15 @@ class Trainer:
         return lambda: self._loss_info(model, eng, pending.result() if hasattr(pending, "result") else pending, w, gt, tau, observations_count)
 
     def _check_saturation(self, eng, li):
-        """f16 range guard of the split-f16 forward (CADDY_LOSS_F16_SATURATED): a forward activation beyond +-65504 was clamped in that step.  The engine keeps training on the
-        exact-fp32 forward from here on (slower, no range limit); the reference has no such limit (fp32 throughout)."""
-        if li.get("f16_saturated") and not getattr(self, "_saturation_handled", False):
-            self._saturation_handled = True
-            eng.set_precision(0, 17)
-            if self.vgg_state is not None:
-                eng.set_vgg_precision(0, 17)
+        """f16 range guard of the split-f16 forward (CADDY_LOSS_F16_SATURATED): a forward activation beyond +-65504 was clamped in that step.  Polling the engine moves the layers that
+        reported -- only those -- onto a forward without a range limit (exact fp32 for model layers, split bf16 for VGG19 layers); the reference has no such limit (fp32 throughout).
+        Every engine polls for itself (the sequence-length curriculum and the evaluators create new ones)."""
+        if li.get("f16_saturated"):
+            bits = eng.numerics_flags()
             if self.logger is not None:
-                self.logger.print("warning: a forward activation exceeded the f16 range (|x| > 65504) and was clamped; switching the engine to the exact-fp32 forward")
+                self.logger.print(f"warning: a forward activation exceeded the f16 range (|x| > 65504) and was clamped in this step"
+                                  + (" -- a NaN among them, the total loss reads NaN" if bits & 2 else "")
+                                  + f"; {eng.fallback_layers()} convolution layer(s) of this engine now run without a range limit")
 
     def _loss_info(self, model, eng, li, w, gt, tau, observations_count):
         self._check_saturation(eng, li)
@@ -241,7 +243,12 @@ class Trainer:
         eng.adam_m, eng.adam_v = self.adam_m, self.adam_v
         lr = self._get_current_lr()          # optimizer.step() runs BEFORE lr_scheduler.step() (trainer.py:586-587): step m+1 is the first at the decayed rate
         self.opt_steps += 1
-        eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size)
+        if getattr(eng, "last_pretraining", False):
+            self.s2h_steps += 1
+        member = getattr(model.module, "last_member", 0)
+        self.member_steps[member] += 1
+        eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size,
+                      member_step=self.member_steps[member] if len(self.member_steps) > 1 else None)
 
     def _to_engine_device(self, eng):
         """optimiser / MI state loaded from a checkpoint before model.cuda() lives on the wrong device: the kernels take raw pointers"""
@@ -311,13 +318,24 @@ class Trainer:
             m, v = self.adam_m.cpu(), self.adam_v.cpu()
             for i, (name, off, n, shape, kind) in enumerate(params):
                 if kind == 0:
-                    state[i] = {"step": torch.tensor(float(self.opt_steps)), "exp_avg": m[off:off + n].view(shape).clone(),
+                    steps = self._param_steps(name)
+                    if steps == 0:
+                        continue                      # (torch creates a parameter's state at its first step: an ensemble member that was never drawn has none)
+                    state[i] = {"step": torch.tensor(float(steps)), "exp_avg": m[off:off + n].view(shape).clone(),
                                 "exp_avg_sq": v[off:off + n].view(shape).clone()}
         group = {"lr": self._get_current_lr(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
                  "initial_lr": self.lr, "params": list(range(len(params)))}
         sched = {"milestones": collections.Counter(self.lr_schedule), "gamma": self.lr_gamma, "base_lrs": [self.lr], "last_epoch": self.opt_steps,
                  "_step_count": self.opt_steps + 1, "_get_lr_called_within_step": False, "_last_lr": [self._get_current_lr()]}
         return {"state": state, "param_groups": [group]}, sched
+
+    def _param_steps(self, name):
+        """Adam step count of a parameter: the optimiser's, or its ensemble member's own (action_network.{m}.*)"""
+        if len(self.member_steps) > 1 and name.startswith("action_network."):
+            return self.member_steps[int(name.split(".")[1])]
+        if name.startswith("state_to_hidden_state_layer."):
+            return self.s2h_steps
+        return self.opt_steps
 
     def _import_optimizer(self, model, opt, sched):
         dev = model.module._flat.device
@@ -338,6 +356,12 @@ class Trainer:
                 continue
             m[off:off + n] = st["exp_avg"].reshape(-1).float()
             v[off:off + n] = st["exp_avg_sq"].reshape(-1).float()
+            if len(self.member_steps) > 1 and name.startswith("action_network."):
+                self.member_steps[int(name.split(".")[1])] = int(float(st["step"]))
+                continue
+            if name.startswith("state_to_hidden_state_layer."):
+                self.s2h_steps = int(float(st["step"]))
+                continue
             steps = max(steps, int(float(st["step"])))
         self.adam_m, self.adam_v, self.opt_steps = m.to(dev), v.to(dev), steps
         if sched and "last_epoch" in sched:

@@ -21,7 +21,7 @@ def load_case(name):
 def dims_of(c):
     return O.Dims(variant=c["variant"], actions=c["K"], action_dim=c["Da"], hidden=c["Ch"], stacking=c["S"],
                   state_res=(c["H"] // 8, c["W"] // 8), hard_gumbel=c.get("hard", False), use_gumbel=c.get("use_gumbel", True),
-                  use_variations=c.get("use_variations", True))
+                  use_variations=c.get("use_variations", True), ensemble=c.get("ens", 1))
 
 
 def inputs_of(c):

@@ -24,7 +24,7 @@ SIM_SPLIT = False      # simulator runs: exact-fp32 convolutions by default (the
 def make_engine(c, lib, dev, perceptual=False):
     eng = Engine(variant=c["variant"], batch=c["B"], seq_len=c["T"], height=c["H"], width=c["W"], stacking=c["S"], actions=c["K"],
                  action_dim=c["Da"], hidden=c["Ch"], hard_gumbel=c.get("hard", False), use_gumbel=c.get("use_gumbel", True),
-                 use_variations=c.get("use_variations", True), device=dev, lib=lib, perceptual=perceptual)
+                 use_variations=c.get("use_variations", True), device=dev, lib=lib, perceptual=perceptual, ensemble=c.get("ens", 1))
     if dev == "cpu":
         eng.set_precision(*((16, 17) if SIM_SPLIT else (0, 0)))
         eng.set_vgg_precision(*((16, 17) if SIM_SPLIT else (0, 0)))
@@ -55,7 +55,7 @@ def _oracle_run(c, d, P, obs, dtype, record):
     for k in Po:
         if O.is_trainable(k):
             Po[k].requires_grad_(True)
-    orc = O.Oracle(d, Po, training=True)
+    orc = O.Oracle(d, Po, training=True, member=c.get("_member"))      # (ensemble cases: the member full_case drew)
     out = orc.forward_full(obs.to(dtype), c["gt"], tau=c["tau"], noise=O.Noise(replay=[t.to(dtype) for t in record]))
     ema0 = None if c.get("mi") == "plain" else torch.full((d.K, d.K), 1.0 / (d.K * d.K), dtype=dtype)
     total, comp, ema = O.full_model_loss(out, obs.to(dtype), H.LOSS_W, mi_ema=ema0, mi_alpha=0.2)
@@ -81,10 +81,16 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
     orc = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True)
     nz = O.Noise()
     torch.manual_seed(H.NOISE_SEED)
+    import random
+    random.seed(c.get("rseed", H.NOISE_SEED))      # model.py:152: the ensemble member comes from Python's global `random` state
     with torch.no_grad():
         oout = orc.forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
     eng = make_engine(c, lib, dev)
     eng.load_state_dict(P)
+    if c.get("ens", 1) > 1:
+        assert orc.member == int(z["member"]) == 1, (orc.member, int(z["member"]))      # the oracle draws what the reference drew (and not the default member)
+        eng.set_action_member(orc.member)
+        c = dict(c, _member=orc.member)
     if prep is not None:
         prep(eng)
     smooth = c.get("mi") != "plain"

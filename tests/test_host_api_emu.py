@@ -381,9 +381,73 @@ def test_trainer_refuses_objectives_it_does_not_implement(monkeypatch):
     with pytest.raises(Exception, match="use_motion_weights"):
         smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
     cfg["training"]["use_motion_weights"] = False
-    cfg["model"]["action_network"]["ensamble_size"] = 3
+    cfg["model"]["action_network"]["ensamble_size"] = 9      # (1 .. 8 are built since round 5)
     with pytest.raises(Exception, match="ensamble_size"):
         _make_model(cfg)
+
+
+def trainer_ensemble_case(make_model, tmp_path):
+    """model.action_network.ensamble_size = 2 (model/main_model/model.py:28,47,152): three training steps of the REAL reference trainer (tools/gen_trainer_golden.py: members
+    1, 0, 1 drawn by random.choice) vs the mirror -- per-step losses, the parameters after the three Adam steps (the member that was not drawn is neither updated nor decayed in
+    that step), Adam's per-parameter step counts in the exported optimizer state (member 1: 2, member 0: 1, state_to_hidden_state_layer: no state, everything else 3)."""
+    import random
+    from playablevideogeneration_amd import smooth_mi_trainer
+    z = np.load(H.GOLDEN + "/trainer_ens2_reduced_s1.npz", allow_pickle=False)
+    cfg = _config(res=(8, 8))
+    cfg["model"]["action_network"]["ensamble_size"] = 2
+    cfg["training"]["loss_weights"].update(PRE_W)
+    cfg["logging"] = {"save_root_directory": str(tmp_path)}
+    m = make_model(cfg)
+    d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
+    assert d.ensemble == 2
+    m.load_state_dict(O.make_params(d, seed=7))
+    m.train()
+    tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
+    tr.global_step = int(z["global_step"])
+    obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    before = {n: p.detach().clone().cpu() for n, p in m.named_parameters()}
+    for i, rs in enumerate(z["rseeds"]):
+        torch.manual_seed(int(z["step_seed"]) + i)
+        random.seed(int(rs))
+        snap = {n: p.detach().clone().cpu() for n, p in m.named_parameters() if n.startswith("action_network.")}
+        loss, info, _ = tr.compute_losses(m, (obs, torch.zeros(2, 4, dtype=torch.int32), None, None), 4)
+        assert m.last_member == int(z["members"][i]), (i, m.last_member)
+        # (an Adam FIRST step moves every element by +-lr whatever its gradient's size, so round-off-sized gradients step either way: 0.05 % of the elements after step 0,
+        #  then the perturbed weights perturb the next gradients -- measured against the reference trainer: 3e-5 at the second loss, 7e-4 at the third; without the ensemble 1e-5 / 1e-4)
+        assert abs(loss - float(z["losses"][i])) < (1e-5, 3e-4, 3e-3)[i] * max(1.0, abs(float(z["losses"][i]))), (i, loss, float(z["losses"][i]))
+        tr.optimizer_step(m)
+        for n, p in m.named_parameters():      # the member that was not drawn: bit-identical after the step (no update, no weight decay)
+            if n.startswith(f"action_network.{1 - m.last_member}."):
+                assert torch.equal(p.detach().cpu(), snap[n]), (i, n)
+            elif n.startswith(f"action_network.{m.last_member}.") and p.numel() > 8:
+                assert not torch.equal(p.detach().cpu(), snap[n]), (i, n)
+    assert tr.member_steps == [1, 2]
+    assert np.allclose(tr.mi_ema.cpu().numpy(), z["mi_ema"], atol=3e-3)      # (carries the third pass's action probabilities: same drift as its loss)
+    sd = dict(m.named_parameters())
+    lr = float(z["lr"])
+    for n, s_, a_ in zip(z["param_names"], z["param_sum"], z["param_abs"]):
+        p = sd[str(n)].detach().double().cpu()
+        slack = 3 * lr * (6 + 0.05 * p.numel()) + 1e-5 * max(1.0, a_)      # three Adam steps of ~lr per element; round-off-sized gradients may step either way (see trainer_golden_case)
+        assert abs(p.abs().sum().item() - a_) <= slack and abs(p.sum().item() - s_) <= slack + 2e-4 * max(1.0, a_ ** 0.5), (str(n), p.abs().sum().item(), a_, p.sum().item(), s_)
+    # exported optimizer state (torch.optim.Adam.state_dict layout): per-parameter step counts as torch keeps them
+    opt, _ = tr._export_optimizer(m)
+    steps = {}
+    for i, (name, off, n_, shape, kind) in enumerate(tr._optimizer_params(m)):
+        steps[name] = int(float(opt["state"][i]["step"])) if i in opt["state"] else 0
+    for n, want in zip(z["param_names"], z["adam_steps"]):
+        if str(n) in steps and not str(n).startswith("centroid"):
+            assert steps[str(n)] == int(want), (str(n), steps[str(n)], int(want))
+    # and back: a trainer resumed from that state carries the members' own counts
+    tr.save_checkpoint(m)
+    m2 = make_model(cfg); m2.train()
+    tr2 = smooth_mi_trainer.trainer(cfg, m2, dataset=None, logger=None)
+    tr2.load_checkpoint(m2)
+    assert tr2.member_steps == [1, 2] and tr2.opt_steps == 3
+    return before
+
+
+def test_trainer_mirror_ensemble_of_action_networks_matches_reference_trainer(tmp_path):
+    trainer_ensemble_case(_make_model, tmp_path)
 
 
 def test_multistep_lr_timing_matches_torch():

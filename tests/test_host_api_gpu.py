@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import caddy_oracle as O
-from tests.test_host_api_emu import _config, trainer_golden_case
+from tests.test_host_api_emu import _config, trainer_ensemble_case, trainer_golden_case
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,12 @@ def test_plugin_factories_forward_and_training_progress(tmp_path):
 def test_trainer_mirror_matches_reference_trainer_golden_on_gpu(name):
     """the REAL reference's training step (loss_info, MI estimator, post-Adam parameters), perceptual weight 0 and 1, on the real library"""
     trainer_golden_case(name, _build, with_vgg=True)
+
+
+def test_trainer_mirror_ensemble_of_action_networks_on_gpu(tmp_path):
+    """model.action_network.ensamble_size = 2: three steps of the real reference trainer (members 1, 0, 1) vs the mirror on the real library -- losses, parameters, the untouched
+    member of every step, Adam's per-parameter step counts, checkpoint round trip"""
+    trainer_ensemble_case(_build, tmp_path)
 
 
 def test_checkpoint_loaded_before_cuda_then_step(tmp_path):

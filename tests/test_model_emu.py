@@ -60,6 +60,11 @@ def test_random_model_configurations():
     M.random_config_sweep(load_emu(), "cpu", 1, seed=21)
 
 
+def test_full_model_ensemble_of_action_networks():
+    """model.action_network.ensamble_size = 2 (model.py:28,47,152): golden of the reference itself with member 1 drawn by random.choice -- forward, losses, gradients (member 0: none)"""
+    M.full_case("full_reduced_s1_ens2", load_emu(), "cpu")
+
+
 def test_perceptual_loss_small():
     """VGG19 perceptual term (forward, per-level losses, dgrad chain with fused ReLU masks / L1 seeds, odd-sized max-pools) on the smallest
     geometry the loss accepts; the reference goldens perc_* run on the GPU (the simulator needs minutes for them)"""

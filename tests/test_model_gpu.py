@@ -29,10 +29,11 @@ def test_full_model_parity_deterministic_backward(lib, name):
     print(info)
 
 
-@pytest.mark.parametrize("name", ["full_reduced_s1_plainmi", "full_main_s1_nogumbel", "full_reduced_s1_novar"])
+@pytest.mark.parametrize("name", ["full_reduced_s1_plainmi", "full_main_s1_nogumbel", "full_reduced_s1_novar", "full_reduced_s1_ens2"])
 def test_full_model_parity_config_branches(lib, name):
     """reference configuration branches outside the BAIR / Breakout YAMLs: the plain MutualInformationLoss of `training.trainer` (03_tennis.yaml,
-    caddy_loss_cfg.mi_ema = NULL), use_gumbel: False, use_variations: False -- forward, losses, gradients against goldens of the reference itself"""
+    caddy_loss_cfg.mi_ema = NULL), use_gumbel: False, use_variations: False, ensamble_size: 2 (member 1 drawn by random.choice, model.py:152) -- forward, losses, gradients
+    against goldens of the reference itself"""
     M.full_case(name, lib, "cuda")
 
 
@@ -284,8 +285,9 @@ def test_breakout160_perceptual_loss_vs_oracle(lib):
 
 
 def test_f16_range_guard_reports_through_the_losses(lib):
-    """1e6-scale observations drive VGG19's first feature maps beyond the f16 range: the split-f16 forward clamps and reports (losses["f16_saturated"], Engine.f16_saturated),
-    the losses stay finite; in-range observations report nothing; the exact-fp32 forward never reports"""
+    """1e6-scale observations drive VGG19's first feature maps beyond the f16 range: the split-f16 forward clamps and reports (losses["f16_saturated"]), the losses stay finite;
+    in-range observations report nothing; the exact-fp32 forward never reports.  Round 5: the poll (Engine.numerics_flags) moves exactly the layers that reported onto split bf16 --
+    the same pass then neither clamps nor reports and its perceptual loss agrees with the exact-fp32 forward's; a NaN observation makes the total NaN instead of a finite number."""
     from playablevideogeneration_amd.init import init_parameters, random_vgg19_state
     c = dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=64, gt=1, tau=0.7)
     eng = M.make_engine(c, lib, "cuda", perceptual=True)
@@ -297,13 +299,39 @@ def test_f16_range_guard_reports_through_the_losses(lib):
              "gumbel_uniform": torch.rand(c["B"] * n, 3, device="cuda", generator=g),
              "eps_states_rec": torch.randn(c["B"] * c["T"], 1, device="cuda", generator=g), "eps_dirs_rec": torch.randn(c["B"] * n, 1, device="cuda", generator=g)}
     w = dict(H.LOSS_W, perceptual=1.0)
-    for scale, vgg_prec, expect in ((1.0, (16, 17), False), (1.0e6, (16, 17), True), (1.0e6, (0, 17), False)):
+    small = torch.rand(c["B"], c["T"], 3, 64, 64, device="cuda", generator=g) * 2 - 1
+    big = (torch.rand(c["B"], c["T"], 3, 64, 64, device="cuda", generator=g) * 2 - 1) * 1.0e6
+
+    def run(obs, vgg_prec=(16, 17)):
         eng.set_vgg_precision(*vgg_prec)
-        obs = (torch.rand(c["B"], c["T"], 3, 64, 64, device="cuda", generator=g) * 2 - 1) * scale
         eng.forward_full(obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
-        li = eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
-        assert li["f16_saturated"] == expect and eng.f16_saturated() == expect, (scale, vgg_prec, li["f16_saturated"])
-        assert all(v == v and abs(v) != float("inf") for k, v in li.items() if isinstance(v, float)), li
+        return eng.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    li = run(small)
+    assert not li["f16_saturated"] and eng.numerics_flags() == 0 and eng.fallback_layers() == 0
+    exact = run(big, (0, 17))                                  # exact-fp32 VGG19: nothing to report (the model's own layers see BatchNorm-scaled values)
+    assert not exact["f16_saturated"] and eng.numerics_flags() == 0
+    li = run(big)
+    assert li["f16_saturated"] and all(v == v and abs(v) != float("inf") for k, v in li.items() if isinstance(v, float)), li
+    assert eng.numerics_flags() == 1                           # clamped, no NaN; the poll clears the flags and moves the reporting layers
+    nfb = eng.fallback_layers()
+    assert 1 <= nfb <= 13 and eng.numerics_flags() == 0, nfb
+    for _ in range(3):                                         # (a layer further down may only see out-of-range values once the ones in front of it stopped clamping)
+        li = run(big)
+        if not li["f16_saturated"]:
+            break
+        eng.numerics_flags()
+    assert not li["f16_saturated"] and eng.fallback_layers() <= 13
+    rel = abs(li["perceptual"] - exact["perceptual"]) / abs(exact["perceptual"])
+    assert rel < 1e-3, (li["perceptual"], exact["perceptual"])      # split bf16 (8 + 8 bits) on the layers that moved, split f16 elsewhere
+    li = run(small)                                            # the moved layers stay moved; in-range data still agrees with itself
+    assert not li["f16_saturated"]
+    nan_obs = big.clone(); nan_obs[0, 1, 0, 3, 3] = float("nan")
+    eng2 = M.make_engine(c, lib, "cuda", perceptual=True)
+    init_parameters(eng2, 1)
+    eng2.load_vgg(random_vgg19_state(0))
+    eng2.forward_full(nan_obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
+    li2 = eng2.loss_backward(w, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+    assert li2["total"] != li2["total"] and (eng2.numerics_flags() & 2)      # the reference's fp32 arithmetic would have propagated the NaN: never a finite total
     torch.cuda.empty_cache()
 
 

@@ -11,7 +11,7 @@ import torch
 from oracle import caddy_oracle as O
 from tests import helpers as H
 
-FULL_CASES = ["full_reduced_s1", "full_main_s1", "full_main_s4_hard"]
+FULL_CASES = ["full_reduced_s1", "full_main_s1", "full_main_s4_hard", "full_reduced_s1_ens2"]      # ..._ens2: model.action_network.ensamble_size 2, member drawn with random.choice
 
 
 def _cmp(a, b, tol, what):
@@ -32,7 +32,11 @@ def test_oracle_full_model_matches_reference_golden(name):
     P = {k: v.clone().requires_grad_(O.is_trainable(k)) for k, v in P.items()}
     orc = O.Oracle(d, P, training=True)
     torch.manual_seed(H.NOISE_SEED)
+    random.seed(c.get("rseed", H.NOISE_SEED))      # model.py:152: the ensemble member is drawn from Python's global `random` state
     out = orc.forward_full(obs, c["gt"], tau=c["tau"])
+    if c.get("ens", 1) > 1:
+        assert orc.member == int(z["member"]) == 1      # the same draw as the reference's, and not the default member
+        assert all(P[k].grad is None for k in P if k.startswith("action_network.0."))
     _cmp(out, H.golden_outputs(z), 1e-6, name)
     total, comp, ema = O.full_model_loss(out, obs, H.LOSS_W, mi_ema=torch.full((d.K, d.K), 1.0 / (d.K * d.K)), mi_alpha=0.2)
     assert abs(total.item() - float(z["loss_total"])) < 1e-6
@@ -180,6 +184,25 @@ def test_oracle_bitwise_vs_imported_reference():
     torch.manual_seed(3)
     oout = orc.forward_full(obs, 2, tau=0.6)
     _cmp(oout, list(rout), 0.0, "bitwise")
+    # ensemble of three action networks (model.py:28,47,152): over several passes the oracle draws the members the reference draws (same `random` state) and matches it bit for bit
+    cfg3 = rh.make_config(variant="reduced", actions=3, action_dim=1, hidden=64, stacking=1, state_res=(4, 4), ensamble_size=3)
+    d3 = O.Dims.from_config(cfg3)
+    P3 = O.make_params(d3, seed=12)
+    ref3 = rh.build_reference_model(cfg3, P3)
+    ref3.train()
+    orc3 = O.Oracle(d3, {k: v.clone() for k, v in P3.items()}, training=True)
+    obs3 = torch.rand(2, 3, 3, 32, 32) * 2 - 1
+    drawn = set()
+    for it in range(4):
+        torch.manual_seed(20 + it); random.seed(40 + it)
+        with torch.no_grad():
+            r3 = ref3((obs3, torch.zeros(2, 3, dtype=torch.int32), None, None), 1, gumbel_temperature=0.8)
+        torch.manual_seed(20 + it); random.seed(40 + it)
+        with torch.no_grad():
+            o3 = orc3.forward_full(obs3, 1, tau=0.8)
+        _cmp(o3, list(r3), 0.0, f"bitwise, ensemble pass {it}")
+        drawn.add(orc3.member)
+    assert len(drawn) > 1      # (the passes exercised different members)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree only exists in the build container")

@@ -35,6 +35,9 @@ CASES = {
     "full_reduced_s1_plainmi": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False, mi="plain"),
     "full_main_s1_nogumbel": dict(variant="main", K=7, Da=2, Ch=128, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.4, hard=False, pre=False, use_gumbel=False),
     "full_reduced_s1_novar": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False, use_variations=False),
+    # model.action_network.ensamble_size: 2 (model.py:28,47): two action networks, `random.choice` draws the one both A calls of the pass use (model.py:152,274); rseed makes
+    # Python's `random` draw member 1, so that a driver that ignores the member cannot pass
+    "full_reduced_s1_ens2": dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=4, H=32, W=32, gt=2, tau=0.7, hard=False, pre=False, ens=2, rseed=7),
 }
 INTERP = [(1, 2, 0.3), (0, 2, 0.8)]           # (first_action, second_action, interpolation_factor) appended to the roll-out cases
 SAMPLER_CASES = {
@@ -48,7 +51,7 @@ PARAM_SEED, OBS_SEED, NOISE_SEED = 7, 1, 5
 def case_inputs(c):
     cfg = rh.make_config(variant=c["variant"], actions=c["K"], action_dim=c["Da"], hidden=c["Ch"], stacking=c["S"],
                          state_res=(c["H"] // 8, c["W"] // 8), hard_gumbel=c["hard"], use_gumbel=c.get("use_gumbel", True),
-                         use_variations=c.get("use_variations", True))
+                         use_variations=c.get("use_variations", True), ensamble_size=c.get("ens", 1))
     d = O.Dims.from_config(cfg)
     P = O.make_params(d, seed=PARAM_SEED)
     obs = torch.rand(c["B"], c["T"], 3 * c["S"], c["H"], c["W"], generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
@@ -80,9 +83,13 @@ def main():
         ref.train()
         acts = torch.zeros(c["B"], c["T"], dtype=torch.int32)
         torch.manual_seed(NOISE_SEED)
-        random.seed(NOISE_SEED)
+        random.seed(c.get("rseed", NOISE_SEED))
+        if c.get("ens", 1) > 1:      # which member will `random.choice(self.action_network)` draw?  (recorded in the fixture; the tests re-derive it from the same seed)
+            st_ = random.getstate(); data_member = random.choice(range(c["ens"])); random.setstate(st_)
         out = ref((obs, acts, None, None), c["gt"], pretraining=c["pre"], gumbel_temperature=c["tau"])
         data = flat_outputs(out)
+        if c.get("ens", 1) > 1:
+            data["member"] = np.array(data_member)
         data["case"] = np.array(repr(c))
         if not c["pre"] or c.get("perc"):
             smi = RL.MutualInformationLoss() if c.get("mi") == "plain" else RL.SmoothMutualInformationLoss(cfg)

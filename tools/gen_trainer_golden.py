@@ -34,6 +34,64 @@ def main():
                 one(pre, perc)
     if not only or "plain" in only:
         one(False, 0.0, plain=True)          # training.trainer (03_tennis.yaml): plain MutualInformationLoss, no estimator state in the checkpoint
+    if not only or "ensemble" in only:
+        ensemble()
+
+
+ENS_RSEEDS = [7, 1, 5]      # Python `random` seed of each step: random.choice(self.action_network) (model.py:152) then draws members 1, 0, 1
+
+
+def ensemble():
+    """model.action_network.ensamble_size = 2: three training steps of the real reference trainer.  Each step draws ONE action network (model.py:152); the other one has
+    `.grad is None` after optimizer.zero_grad() and torch.optim.Adam neither updates nor decays it, and Adam's per-parameter step counts diverge (member 1: 2 steps, member 0: 1)."""
+    rh.install()
+    cfg = _config(res=(8, 8))
+    cfg["model"]["architecture"] = "model.reduced_model.model"
+    cfg["model"]["action_network"]["use_variations"] = True
+    cfg["model"]["action_network"]["ensamble_size"] = 2
+    tr = cfg["training"]
+    tr["trainer"] = "training.smooth_mi_trainer"
+    tr["batching"].update(batch_size=2, num_workers=0)
+    tr.update(motion_weights_bias=0.1, use_motion_weights=False, action_mutual_information_entropy_lambda=1.0, action_direction_plotting_freq=10 ** 9, max_steps=10 ** 6)
+    tr["loss_weights"]["perceptual_loss_lambda"] = 0.0
+    tr["loss_weights"].update(PRE_W)
+    cfg["logging"] = {"save_root_directory": "/tmp", "output_images_directory": "/tmp"}
+    d = O.Dims.from_config(cfg)
+    P = O.make_params(d, seed=PARAM_SEED)
+    ref = nn.DataParallel(rh.build_reference_model(cfg, P))
+    import importlib
+    logger = types.SimpleNamespace(print=lambda *a, **k: None, get_wandb=lambda: types.SimpleNamespace(log=lambda *a, **k: None))
+    trainer = importlib.import_module(tr["trainer"]).trainer(cfg, ref, [0] * 8, logger)
+    trainer.global_step = GLOBAL_STEP
+    obs = torch.rand(2, 4, 3, 64, 64, generator=torch.Generator().manual_seed(OBS_SEED)) * 2 - 1
+    acts = torch.zeros(2, 4, dtype=torch.int32)
+    batch = types.SimpleNamespace(observations=obs, actions=acts, size=4, to_tuple=lambda cuda=True: (obs, acts, None, None))
+    ref.train()
+    losses, members = [], []
+    for i, rs in enumerate(ENS_RSEEDS):
+        torch.manual_seed(STEP_SEED + i)
+        random.seed(rs)
+        st_ = random.getstate(); members.append(random.choice(range(2))); random.setstate(st_)
+        loss, info, _ = trainer.compute_losses(ref, batch, 4)
+        trainer.optimizer.zero_grad()
+        loss.backward()
+        trainer.optimizer.step()
+        trainer.lr_scheduler.step()
+        losses.append(loss.item())
+    data = {"losses": np.array(losses), "members": np.array(members), "rseeds": np.array(ENS_RSEEDS), "global_step": np.array(GLOBAL_STEP), "step_seed": np.array(STEP_SEED)}
+    names, psum, pabs, first, steps = [], [], [], [], []
+    for n, p in ref.module.named_parameters():
+        names.append(n); psum.append(p.detach().double().sum().item()); pabs.append(p.detach().double().abs().sum().item())
+        first.append(p.detach().flatten()[:4].tolist() + [0.0] * max(0, 4 - p.numel()))
+        st = trainer.optimizer.state.get(p)
+        steps.append(int(float(st["step"])) if st else 0)
+    data["param_names"], data["param_sum"], data["param_abs"], data["param_first4"] = np.array(names), np.array(psum), np.array(pabs), np.array(first, dtype=np.float32)
+    data["adam_steps"] = np.array(steps)
+    data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
+    data["lr"] = np.array(trainer._get_current_lr())
+    out = os.path.join(ROOT, "tests", "golden", "trainer_ens2_reduced_s1.npz")
+    np.savez_compressed(out, **data)
+    print("written", out, "members", members, "losses", losses, "adam steps", sorted(set(steps)))
 
 
 def one(pretraining, perc=0.0, plain=False):

@@ -77,7 +77,7 @@ def install():
 
 
 def make_config(*, variant, actions, action_dim, hidden, stacking, state_res, hard_gumbel=False, use_gumbel=True,
-                use_variations=True, alpha=0.1, mi_alpha=0.2):
+                use_variations=True, alpha=0.1, mi_alpha=0.2, ensamble_size=1):
     """Minimal config dict with exactly the keys the hot path reads (SURVEY 8a 'Config keys')."""
     return {
         "data": {"actions_count": actions},
@@ -85,7 +85,7 @@ def make_config(*, variant, actions, action_dim, hidden, stacking, state_res, ha
             "architecture": "model.main_model.model" if variant == "main" else "model.reduced_model.model",
             "representation_network": {"state_features": 64, "state_resolution": list(state_res)},
             "dynamics_network": {"hidden_state_size": hidden, "random_noise_size": 32},
-            "action_network": {"ensamble_size": 1, "use_gumbel": use_gumbel, "hard_gumbel": hard_gumbel,
+            "action_network": {"ensamble_size": ensamble_size, "use_gumbel": use_gumbel, "hard_gumbel": hard_gumbel,
                                "gumbel_temperature": 1.0, "action_space_dimension": action_dim,
                                "use_variations": use_variations},
             "centroid_estimator": {"alpha": alpha},
