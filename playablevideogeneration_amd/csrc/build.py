@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["conv_mfma.hip", "conv_hx.hip", "conv_hx_wgrad.hip", "conv_head.hip", "conv_direct.hip", "conv_thin.hip", "conv_narrow.hip", "pointwise.hip", "pack.hip", "head.hip", "perceptual.hip", "net.cpp", "capi_kernels.cpp", "dp_rccl.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_hx.hip", "conv_hx_wgrad.hip", "conv_head.hip", "conv_direct.hip", "conv_thin.hip", "conv_narrow.hip", "conv_stream.hip", "pointwise.hip", "pack.hip", "head.hip", "perceptual.hip", "net.cpp", "capi_kernels.cpp", "dp_rccl.cpp"]
 LIB = os.path.join(HERE, "libcaddy_hip.so")
 
 

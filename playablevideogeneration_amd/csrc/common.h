@@ -199,6 +199,8 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
 int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st);    // conv_head.hip: dgrad of the 7x7 head (3 -> C channels) on the split-bf16 matrix pipe (ConvArgs.precision == PREC_BF16X3, no wq)
 int conv_direct_try(const ConvArgs& a, hipStream_t st);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
+int conv_stream_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: HBM-bound 1x1 weight gradients, operands straight from global memory into the fp32 MFMA (1 = handled)
+extern thread_local int g_last_wgrad_grouped;      // 1: the kernel the last conv_*_wgrad_try picked understands time-batched arguments (WgradArgs.group_n)
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA

@@ -899,7 +899,7 @@ int wgrad_det_end(const WgradArgs& a, long splits, hipStream_t st) {
 static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry);   // dry: only report the kernel (g_last_conv_kernel)
 int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st) {
     if (a0.group_n <= 0 || a0.N <= a0.group_n) return conv_wgrad_launch1(a0, st, false);
-    if (conv_wgrad_launch1(a0, st, true) == 0 && (g_last_conv_kernel == CK_WGRAD_TILE || g_last_conv_kernel == CK_WGRAD_HX)) return conv_wgrad_launch1(a0, st, false);
+    if (conv_wgrad_launch1(a0, st, true) == 0 && (g_last_conv_kernel == CK_WGRAD_TILE || g_last_conv_kernel == CK_WGRAD_HX || g_last_wgrad_grouped)) return conv_wgrad_launch1(a0, st, false);
     // time-batched arguments on a kernel without (group, sample) addressing: one launch per group
     for (int g = 0; g * a0.group_n < a0.N; g++) {
         WgradArgs a = a0;
@@ -919,6 +919,8 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     if (a.group_n > 0 && a.N <= a.group_n) a.group_n = 0;
     if (conv_hx_wgrad_try(a, st, dry) == 1) return 0;       // wide 3x3 layers: split bf16 on the 16-bit matrix pipe (conv_hx.hip)
     for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs: k_wgrad_hx only
+    g_last_wgrad_grouped = 0;
+    { int rc = conv_stream_wgrad_try(a, st, dry); if (rc != 0) return rc < 0 ? rc : 0; }      // 1x1 layers: streaming kernel, both operands straight into the fp32 MFMA (conv_stream.hip)
     if (conv_c4_wgrad_try(a, st, dry) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
     if (conv_thin_wgrad_try(a, st, dry) == 1) return 0;
     if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)
