@@ -247,6 +247,9 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     if (g < 1) g = 1;
     if (g > ntiles) g = ntiles;
     WgradArgs b = a;
+    // bit-reproducible mode: one copy of the packed layout per pixel split.  With ONE split (kt x ot >= 129 tiles: the ConvLSTM gate layers) every element of dwp has exactly one
+    // contributing lane per launch -- the plain flush is already order-free: no copies, no fold (the row-split layout of <= 32 output channels has two contributors per element)
+    if (b.det_slab && g == 1 && a.Cout > 32) b.det_slab = nullptr;
     if (b.det_slab) { g = wgrad_det_begin(b, g, st); if (g <= 0) return -1; }
     if (a.Cout <= 32) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, true>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
     else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, false>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);

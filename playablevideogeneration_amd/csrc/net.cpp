@@ -380,9 +380,9 @@ void caddy_ctx::flush_aux() {
     hipStream_t as = aux_grad_stream();      // ONE fork
     if (as == stream) { for (auto& j : jobs) j(); return; }
     StreamRes keep{stream, conv_aux, conv_split, red_scratch};
-    stream = as; conv_aux = dsr.aux; conv_split = dsr.split;
+    stream = as; conv_aux = dsr.aux; conv_split = dsr.split; red_scratch = dsr.red;
     for (auto& j : jobs) j();
-    stream = keep.st; conv_aux = keep.aux; conv_split = keep.split;
+    stream = keep.st; conv_aux = keep.aux; conv_split = keep.split; red_scratch = keep.red;
 }
 void caddy_ctx::step_boundary() { flush_aux(); launch_wgrad_jobs(); }
 void caddy_ctx::join_aux(hipStream_t onto) {
@@ -578,7 +578,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                         RUN(pw_bcast_input_grad(dzv, Lp->pd, s, tmpv[s].d, sgv[s].t.g, sgv[s].t.sn, bd ? nullptr : Lp->dbias, stream));
                         bd = true;
                     }
-                    if (!bd) RUN(pw_colsum(dzv, Lp->dbias, stream, deterministic));
+                    if (!bd) RUN(pw_colsum(dzv, Lp->dbias, stream, deterministic, red_scratch));
                 });
             }
             for (int s = 0; s < nseg; s++) {
@@ -1493,6 +1493,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (c->fail) { delete c; return nullptr; }
     if (caddy_serial_streams()) c->use_dstream = false;
     hipMemset(c->sat_flag, 0, sizeof(unsigned) * CADDY_N_FLAGS);      // (sticky until polled: caddy_f16_saturated)
+    if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }

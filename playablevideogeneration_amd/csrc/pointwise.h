@@ -41,7 +41,7 @@ int pw_attn_mul(const TV& x, const TV& out, const TV& att, hipStream_t st);
 int pw_attn_mul_bwd(const TV& x, const TV& dout, const TV& datt, const TV& dx, hipStream_t st);
 int pw_gap(const TV& x, float* out, hipStream_t st);
 int pw_gap_bwd(const float* dout, const TV& dx, hipStream_t st);
-int pw_colsum(const TV& x, float* out, hipStream_t st, bool det = false);                     // det: single workgroup (bit-reproducible: no float atomics between workgroups)
+int pw_colsum(const TV& x, float* out, hipStream_t st, bool det = false, double* scratch = nullptr);                     // det: single workgroup (bit-reproducible: no float atomics between workgroups)
 int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st, bool det = false);   // det: one workgroup per sample
 int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st);
 int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st);

@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
                 else { atomicAdd(&a.sums[2 * (c + e)], s[e]); atomicAdd(&a.sums[2 * (c + e) + 1], s[4 + e]); }
             }
             else if (MODE == 2) atomicAdd(&a.outf[(long)blockIdx.y * a.out_sn + c + e], (float)(s[e] * a.scale));
+            else if (a.partials) a.partials[(long)blockIdx.x * C + c + e] = s[e];      // bit-reproducible bias gradient: per-block sums, folded in block order by k_sum_partials
             else atomicAdd(&a.outf[c + e], (float)s[e]);
         }
     }
@@ -423,7 +424,7 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, doubl
     f.mean[c] = m; f.invstd[c] = is; f.scale[c] = g * is; f.shift[c] = b - m * g * is;
 }
 
-__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums, float* dgamma, float* dbeta, BnFin fin) {
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int nb, int n2c, double* sums, float* dgamma, float* dbeta, BnFin fin, float* addf = nullptr) {
     // sums[i] = sum_b partials[b][i] (assign: no memset needed); one wave per output index (4 per workgroup), lanes stride over blocks.
     // Optionally fused BatchNorm parameter gradients: dbeta[c] += sums[2c], dgamma[c] += sums[2c+1].
     __shared__ double sh[4];
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* partials, in
     if (i < n2c) for (int b = lane; b < nb; b += 64) s += partials[(long)b * n2c + i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (i < n2c && lane == 0) {
-        sums[i] = s;
+        if (addf) addf[i] += (float)s;      // (MODE 3: the bias gradient accumulates over the time steps, one writer per element and launch)
+        else sums[i] = s;
         if (dgamma) { if (i & 1) dgamma[i >> 1] += (float)s; else dbeta[i >> 1] += (float)s; }
     }
     if (fin.mean) {                                   // workgroup b owns channels 2b, 2b+1 (indices 4b .. 4b+3)
@@ -468,7 +470,9 @@ int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
         if (full) hipLaunchKernelGGL((k_reduce<MODE, true, 0>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_reduce<MODE, false, 0>), dim3(cdiv(HW, ppb), a.x.N), dim3(256), 0, st, a);
     } else {
-        long maxb = (MODE <= 1 && a.partials) ? RED_MAX_BLOCKS : ((MODE == 3 && a.det) ? 1 : 1024);
+        // (MODE 3, bit-reproducible: per-block partial sums + fixed-order fold when the caller provides scratch; the former single-workgroup form took 460 us per launch on D's
+        //  full-resolution maps -- 20 of the 29 ms the mode added to the serialised step)
+        long maxb = ((MODE <= 1 || MODE == 3) && a.partials) ? RED_MAX_BLOCKS : ((MODE == 3 && a.det) ? 1 : 1024);
         long ppb = (P + maxb - 1) / maxb;
         int C4r = (a.x.C + 3) / 4; int ptr = 256 / (C4r < 256 ? C4r : 256);      // pixel rows handled in parallel by one block
         long minp = ptr * 4 > 16 ? ptr * 4 : 16;                                 // >= 4 pixels per thread
@@ -481,7 +485,8 @@ int run_reduce(RedArgs a, hipStream_t st, const BnFin* fin = nullptr) {
         else { if (actm == 2) RED_LAUNCH(false, 2); else if (actm == 1) RED_LAUNCH(false, 1); else RED_LAUNCH(false, 0); }
 #undef RED_LAUNCH
         BnFin nofin{}; nofin.mean = nullptr;
-        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums, a.dgamma, a.dbeta, fin ? *fin : nofin);
+        if (MODE <= 1 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(2 * a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, 2 * a.x.C, a.sums, a.dgamma, a.dbeta, fin ? *fin : nofin, (float*)nullptr);
+        if (MODE == 3 && a.partials) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(a.x.C, 4)), dim3(256), 0, st, (const double*)a.partials, nb, a.x.C, (double*)nullptr, (float*)nullptr, (float*)nullptr, nofin, a.outf);
     }
     return 0;
 }
@@ -798,7 +803,9 @@ int pw_gap(const TV& x, float* out, hipStream_t st) {
     return run_reduce<2>(a, st);
 }
 int pw_gap_bwd(const float* dout, const TV& dx, hipStream_t st) { return run_map((long)dx.N * dx.H * dx.W, dx.C, FGapBwd{dx, dout, make_fdiv(dx.H * dx.W), 1.f / (float)(dx.H * dx.W)}, st, quads(dx.C)); }
-int pw_colsum(const TV& x, float* out, hipStream_t st, bool det) { RedArgs a{}; a.x = x; a.outf = out; a.det = det ? 1 : 0; return run_reduce<3>(a, st); }
+int pw_colsum(const TV& x, float* out, hipStream_t st, bool det, double* scratch) {      // scratch (RED_MAX_BLOCKS x C doubles, private to the stream): the bit-reproducible form's partial sums
+    RedArgs a{}; a.x = x; a.outf = out; a.det = det ? 1 : 0; a.partials = det ? scratch : nullptr; return run_reduce<3>(a, st);
+}
 int pw_spatial_sum(const TV& x, float* out, long out_sn, hipStream_t st, bool det) { RedArgs a{}; a.x = x; a.outf = out; a.out_sn = out_sn; a.scale = 1.f; a.det = det ? 1 : 0; return run_reduce<2>(a, st); }
 int pw_nchw_to_nhwc(const float* src, long src_sn, const TV& d, hipStream_t st) { return run_map((long)d.N * d.H * d.W, 1, FNchwToNhwc{src, src_sn, d, make_fdiv(d.H * d.W)}, st); }
 int pw_nhwc_to_nchw(const TV& s, float* dst, long dst_sn, int acc, hipStream_t st) { return run_map((long)s.N * s.H * s.W, 1, FNhwcToNchw{s, dst, dst_sn, make_fdiv(s.H * s.W), acc}, st); }
