@@ -416,18 +416,18 @@ def run(a, dev, lib=None, backend="nccl"):
         if perc:
             eng.set_vgg_precision(16, 17)
         log(f"exact-fp32 kernels: {ms_exact:.1f} ms/step")
-    ms_det = ms_det_erad = None      # the bit-reproducible backward (caddy_set_deterministic): what it costs, full step and E/R/A/D-only step
+    ms_det = ms_det_erad = None      # the arrival-order backward (caddy_set_deterministic(0): fp32 atomics) beside the default bit-reproducible one: what reproducibility costs
     if extra and world == 1 and on_gpu and not quick:
-        eng.set_deterministic(True)
+        eng.set_deterministic(False)
         step()
-        ms_det, _ = timed(max(2, a.steps // 4))
+        ms_det, _ = timed(max(2, a.steps // 2))
         if perc:
             eng.set_perceptual_prefetch(False)
             step(loss_w_erad)
-            ms_det_erad, _ = timed(max(2, a.steps // 4), loss_w_erad)
+            ms_det_erad, _ = timed(max(2, a.steps // 2), loss_w_erad)
             eng.set_perceptual_prefetch(True)
-        eng.set_deterministic(False)
-        log(f"deterministic backward: {ms_det:.1f} ms/step" + (f", E/R/A/D-only {ms_det_erad:.1f} ms/step" if ms_det_erad else ""))
+        eng.set_deterministic(True)
+        log(f"arrival-order (atomic) backward: {ms_det:.1f} ms/step" + (f", E/R/A/D-only {ms_det_erad:.1f} ms/step" if ms_det_erad else ""))
     if world > 1:
         dist.barrier()
     res = None
@@ -444,8 +444,9 @@ def run(a, dev, lib=None, backend="nccl"):
                "loss": losses["total"], "rccl_ranks_seen": ranks_seen,
                "erad_only": {"ms_per_step": ms_erad, "clips_per_s": world * B * 1e3 / ms_erad, "what": "the same step with perceptual weight 0 and no VGG19 branch: E -> R -> A -> D forward + L1 / states / KL / MI losses + BPTT + Adam"},
                "exact_fp32_ms_per_step": ms_exact,
-               "deterministic_backward": {"ms_per_step": ms_det, "erad_only_ms_per_step": ms_det_erad,
-                                          "what": "caddy_set_deterministic(1): slabs + fixed-order reduces instead of fp32 atomics in the backward (bit-identical gradients run to run)"},
+               "backward": "bit-reproducible (library default since round 5: slabs + fixed-order folds; two backward passes over one forward give bit-identical gradients)",
+               "atomic_backward": {"ms_per_step": ms_det, "erad_only_ms_per_step": ms_det_erad,
+                                   "what": "caddy_set_deterministic(0): fp32 atomics in arrival order instead of slabs + fixed-order folds -- the non-reproducible form, for comparison"},
                "roofline": roof, "roofline_full_step": roof_full}
     del eng
     if on_gpu:

@@ -130,10 +130,10 @@ int caddy_set_vgg_precision(caddy_ctx* ctx, int forward, int dgrad);
  * epilogues, the ConvLSTM cells' BatchNorm as a second output of the gate kernel): ~35 fewer launches per frame.  off: one BatchNorm launch per
  * nn.BatchNorm2d as in the training graph.  Only caddy_generate_next is affected (model.py:570-607, eval mode). */
 int caddy_set_rollout_fold(caddy_ctx* ctx, int on);
-/* Bit-reproducible backward pass (default off).  The forward pass is always bit-reproducible (fixed-order split-K, action indices!); the default backward combines the partial
- * sums of under-filled dgrads and of the weight-gradient pixel splits with fp32 atomics in arrival order (run-to-run: ~1e-5 relative on the flat gradient, amplified by BPTT
- * through the closed-loop steps -- the reference's CPU path is bit-repeatable).  on: slabs + fixed-order reduces everywhere; two backward passes over the same forward then
- * give bit-identical gradients.  Cost: profiles/. */
+/* Bit-reproducible backward pass (default ON since round 5: two backward passes over the same forward give bit-identical gradients, like the reference's CPU path -- training/
+ * trainer.py:575-587 on torch CPU kernels).  The forward pass is always bit-reproducible (fixed-order split-K, action indices!).  on = 0 selects the arrival-order form: the partial
+ * sums of under-filled dgrads and of the weight-gradient pixel splits meet through fp32 atomics (run-to-run ~1e-5 relative on the flat gradient, amplified by BPTT through the
+ * closed-loop steps); it is < 1 % faster (profiles/r05_experiments.md: slabs + fixed-order folds cost 0.6 / 0.9 ms of the 61.5 / 125.2 ms steps). */
 int caddy_set_deterministic(caddy_ctx* ctx, int on);
 
 /* --- context --- */

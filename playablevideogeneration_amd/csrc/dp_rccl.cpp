@@ -71,30 +71,33 @@ void bucket_allreduce(float* grads, long offset, long count, void* stream, void*
     c->comm_buckets.push_back({offset, count});
     c->comm_bucket_stream = (hipStream_t)stream;
 }
-// ncclCommInitRank with a time limit: the call blocks until EVERY rank has made it.  It runs in a helper thread; when the limit passes the caller gets an error (the helper
-// stays blocked and is detached: the process is expected to exit -- there is no way to cancel a rendezvous that another rank never joins).
+// ncclCommInitRank with a time limit: the call blocks until EVERY rank has made it.  It runs in a helper thread that is joined when it returns; only when the limit passes is it
+// detached -- it stays blocked, the caller gets an error and the process is expected to exit: there is no way to cancel a rendezvous that another rank never joins.
 struct InitJob { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; void* comm = nullptr; };
 int comm_init_guarded(void** out, int world_size, const UniqueId& id, int rank, const char* which) {
     int device = 0;
     hipGetDevice(&device);
     auto job = std::make_shared<InitJob>();
     const init_fn fn = g_rccl.CommInitRank;
-    std::thread([job, fn, world_size, id, rank, device]() {
+    std::thread helper([job, fn, world_size, id, rank, device]() {
         hipSetDevice(device);      // (the helper thread must target the caller's GPU)
         void* comm = nullptr;
         const int rc = fn(&comm, world_size, id, rank);
         std::lock_guard<std::mutex> g(job->m);
         job->rc = rc; job->comm = comm; job->done = true;
         job->cv.notify_all();
-    }).detach();
+    });
     const char* e = getenv("CADDY_DP_INIT_TIMEOUT_S");
     const long limit = e && atol(e) > 0 ? atol(e) : 180;
     std::unique_lock<std::mutex> lk(job->m);
     if (!job->cv.wait_for(lk, std::chrono::seconds(limit), [&] { return job->done; })) {
+        helper.detach();      // still blocked in the rendezvous: nothing can cancel it, the process is expected to exit
         set_error(std::string("ncclCommInitRank (") + which + ") did not return within " + std::to_string(limit) + " s on rank " + std::to_string(rank) + " of " +
                   std::to_string(world_size) + ": another rank never reached caddy_dp_init (CADDY_DP_INIT_TIMEOUT_S)");
         return -3;
     }
+    lk.unlock();
+    helper.join();            // (returned: no thread outlives the call)
     if (job->rc != 0) return nccl_fail("ncclCommInitRank", job->rc);
     *out = job->comm;
     return 0;

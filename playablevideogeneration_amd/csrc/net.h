@@ -156,7 +156,7 @@ struct caddy_ctx {
     SamplerHooks samplers{};         // evaluation action / variation samplers (caddy_set_sampler_hook)
     // caddy_set_deterministic: the backward pass is bit-reproducible -- split-K dgrads through slabs + fixed-order reduce instead of fp32 atomics, every pixel split of a
     // weight-gradient launch into its own copy of the packed layout + fixed-order reduce (WgradArgs.det_slab), single-workgroup bias sums
-    bool deterministic = false;
+    bool deterministic = true;       // (round 5: the default -- the mode costs < 1 % of the step since its single-workgroup bias sums and serial folds are gone; 0 = arrival-order atomics)
     float* wgrad_det = nullptr; long wgrad_det_cap = 0;      // scratch of the deterministic weight gradients (the stream the weight gradients run on)
     hipStream_t wgrad_det_owner = nullptr; bool wgrad_det_owner_set = false;      // ... and that stream, per backward pass (launch_conv_wgrad refuses a second one)
     // f16 range guard of the split-f16 forward (ConvArgs.sat_flag), per LAYER (round 5): word i belongs to convs[i] (model) / CADDY_VGG_FLAG0 + i (VGG19 conv i); ORed by any staging

@@ -337,7 +337,7 @@ class Engine:
 
     def set_deterministic(self, on: bool):
         """bit-reproducible backward pass (slabs + fixed-order reduces instead of fp32 atomics in arrival order; the forward pass always is): two backward passes over the
-        same forward give bit-identical gradients, as the reference's CPU path does.  Slower (see profiles/); default off."""
+        same forward give bit-identical gradients, as the reference's CPU path does.  The library's default since round 5 (< 1 % of the step); False selects the atomics."""
         self._check(self.lib.caddy_set_deterministic(self.ctx, int(bool(on))))
 
     def set_precision(self, forward: int, backward: int):

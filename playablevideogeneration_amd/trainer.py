@@ -247,8 +247,8 @@ class Trainer:
             self.s2h_steps += 1
         member = getattr(model.module, "last_member", 0)
         self.member_steps[member] += 1
-        eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size,
-                      member_step=self.member_steps[member] if len(self.member_steps) > 1 else None)
+        extra = {"member_step": self.member_steps[member]} if len(self.member_steps) > 1 else {}
+        eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size, **extra)
 
     def _to_engine_device(self, eng):
         """optimiser / MI state loaded from a checkpoint before model.cuda() lives on the wrong device: the kernels take raw pointers"""

@@ -63,7 +63,7 @@ def _oracle_run(c, d, P, obs, dtype, record):
     return Po, out
 
 
-def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
+def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=True, grad_floor=5e-3):
     """forward_full_model + losses + backward + BN buffers + centroids + MI-EMA.
 
     Forward / losses / buffers: against the REFERENCE's golden vectors (and the oracle).  Gradients are compared with an
@@ -72,9 +72,9 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
     slope is discontinuous at 0, so pre-activations within the ~1e-5 forward round-off of zero take the other slope
     (0.2 <-> 1) and shift the BatchNorm-backward means -- O(1e-3) relative, data dependent (verified element by element
     with the caddy_debug_* introspection API; single-step graphs, where no flip occurs, agree to 2e-5).  Criterion:
-    relative L2 error <= max(5 x fp32-oracle error, 3e-2) and per-parameter max error <= max(5 x, 1e-1); a missing
-    or wrong term in the backward graph shows up as O(0.1 - 1).  deterministic=True (caddy_set_deterministic: no arrival-order atomics, so no run-to-run noise
-    on top of the arithmetic's own error): relative L2 error <= max(2 x fp32-oracle error, 5e-3).
+    relative L2 error <= max(2 x fp32-oracle error, 5e-3) and per-parameter max error <= max(5 x, 1e-1) on the library's default, bit-reproducible backward (round 5; no
+    arrival-order atomics, so no run-to-run noise on top of the arithmetic's own error); a missing or wrong term in the backward graph shows up as O(0.1 - 1).
+    deterministic=False (caddy_set_deterministic(0): fp32 atomics in arrival order): relative L2 error <= max(5 x fp32-oracle error, 3e-2).
     """
     c, z = H.load_case(name)
     d, P, obs = H.inputs_of(c)
@@ -104,8 +104,7 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
     # frame MSE criterion of the north star (evaluation/metrics/mse.py:21): mean over C,H,W per (b,t), within 1e-5
     mse = ((out[0].cpu() - torch.from_numpy(z["out0"])) ** 2).mean(dim=(2, 3, 4))
     assert mse.max().item() < 1e-5
-    if deterministic:
-        eng.set_deterministic(True)
+    eng.set_deterministic(bool(deterministic))
     losses = eng.loss_backward(H.LOSS_W, smooth_mi=smooth, mi_alpha=0.2)
     assert abs(losses["total"] - float(z["loss_total"])) < 2e-5, (losses["total"], float(z["loss_total"]))
     for k in ("rec", "states", "entropy", "dir_kl", "mi", "state_kl"):
@@ -129,7 +128,7 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=False):
         worst_h, worst_o = max(worst_h, (g - g64).abs().max().item() / s), max(worst_o, (g32 - g64).abs().max().item() / s)
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
-    assert rel_h <= (max(2 * rel_o, 5e-3) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+    assert rel_h <= (max(2 * rel_o, grad_floor) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
     assert worst_h <= max(5 * worst_o, 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
     # reference's own gradient summaries (loose: same conditioning caveat)
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
@@ -397,7 +396,7 @@ def pretraining_case(lib, dev, name="pre_main_s4", fwd_tol=2e-4):
         g = eng.grad_view(n).cpu().double()
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
-    assert rel_h <= max(5 * rel_o, 3e-2), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+    assert rel_h <= max(2 * rel_o, 5e-3), ("relative L2 gradient error vs fp64", rel_h, rel_o)      # (the default backward is the bit-reproducible one: round 5)
 
 
 def rollout_case(name, lib, dev, tol=2e-4, fold=True):
@@ -535,6 +534,7 @@ def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False, reps=
     eng.forward_full(obs, c["gt"], c["tau"], noise, training=True, fetch_outputs=False)
     w1 = dict(H.LOSS_W, perceptual=1.0) if perceptual else dict(H.LOSS_W)
     rel = lambda a, b: ((a - b).double().norm() / b.double().norm()).item()
+    eng.set_deterministic(False)
     eng.loss_backward(w1, smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
     g_atomic = eng.grads.clone()
     eng.set_deterministic(True)
@@ -551,7 +551,6 @@ def deterministic_case(lib, dev, c, seed=3, perceptual=False, tight=False, reps=
     assert lin == 0.0 or (not tight and lin < 1e-6), ("deterministic backward not linear in the loss weights", lin)
     noise_atomic = rel(g_atomic, gs[0])
     assert noise_atomic < 1e-3, ("deterministic vs atomic gradients", noise_atomic)
-    eng.set_deterministic(False)
     return dict(atomic_vs_deterministic=noise_atomic, linearity=lin)
 
 

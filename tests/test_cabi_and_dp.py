@@ -170,6 +170,26 @@ def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
         assert k in res
 
 
+def test_bench_world8_through_the_launch_script_on_the_simulator(tmp_path):
+    """`bash tools/launch_dp.sh 8 2 1` -- the exact command line the driver's scaling run uses (torch.distributed.run, one process per GPU, 127.0.0.1) -- with the
+    script swapped for its simulator twin (tests/dp_sim_bench.py: gloo, tiny workload): eight ranks rendezvous, every rank takes part in the MI / centroid reductions and the bucketed
+    gradient all-reduce, the line is printed once with n_gpus 8, the ranks the communicator really spans (rccl_ranks_seen) 8, weak scaling, global batch 8.  No hardware scaling
+    curve exists (one GPU per lease): this is what can be checked without one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "bench8.json"
+    env = dict(os.environ, CADDY_DP_SCRIPT="tests/dp_sim_bench.py", CADDY_DP_SIM_OUT=str(out), MASTER_PORT=str(29600 + os.getpid() % 300), OMP_NUM_THREADS="1",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "launch_dp.sh"), "8", "2", "1"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["n_gpus"] == 8 and res["rccl_ranks_seen"] == 8 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp8"
+    assert res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1 and res["roofline"] is not None
+    assert res["value"] == pytest.approx(8 * 1 * 1e3 / res["ms_per_step"])      # whole-job clips/s over all ranks
+
+
 def _trainer_worker(rank, world, port, out, skew=0.0):
     import time
     import torch.distributed as dist

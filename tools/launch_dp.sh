@@ -4,5 +4,6 @@
 N=${1:-8}; K=${2:-10}; W=${3:-3}
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-if [ "$N" = "1" ]; then exec python bench.py --gpus 1 --steps $K --warmup $W; fi
-exec python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port ${MASTER_PORT:-29511} bench.py --gpus $N --steps $K --warmup $W
+SCRIPT=${CADDY_DP_SCRIPT:-bench.py}      # (tests: tests/dp_sim_bench.py runs the same control flow on the host simulator over gloo)
+if [ "$N" = "1" ]; then exec python $SCRIPT --gpus 1 --steps $K --warmup $W; fi
+exec python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port ${MASTER_PORT:-29511} $SCRIPT --gpus $N --steps $K --warmup $W
