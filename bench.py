@@ -35,7 +35,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 MFMA16_DENSE_PEAK_TFLOPS = 2500.0 # same guide: bf16 / f16 dense MFMA (v_mfma_f32_32x32x16_{f16,bf16})
 SPLIT_PRODUCTS = 3                # conv_hx: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the 16-bit pipe -> 3 MFMA FLOPs per algorithmic FLOP
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "profiles/r04_pmc_traffic_{workload}{suffix}.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh <workload>)
+PMC_FILE = "profiles/r05_pmc_traffic_{workload}{suffix}.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh <workload>)
 HX_FAMILIES = ("k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx", "k_conv_hx<128, 8 waves>")
 VGG_CONVS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2), (256, 256, 2), (256, 512, 3),
              (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]      # (Cin, Cout, number of 2x2 max-pools before): conv1_1 .. conv5_1
@@ -106,9 +106,22 @@ def cpu_baseline(wl, perceptual=True):
             p.grad = None
         P["centroid_estimator.estimated_centroids"] = P["centroid_estimator.estimated_centroids"].detach()
     dt = sum(times[1:]) / len(times[1:])
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port", "host_physical_cores": physical, "host_logical_cpus": logical,
-            "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}): oracle forward + losses"
-                      + (" incl. VGG19 perceptual" if perceptual else "") + f" + backward; 1 warm-up + 2 timed iterations ({times[1]:.1f} s, {times[2]:.1f} s)"}
+    res = {"value": 1.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port", "host_physical_cores": physical, "host_logical_cpus": logical,
+           "sample": f"1 clip (B=1, T={wl['seq_len']}, {wl['height']}x{wl['width']}): oracle forward + losses"
+                     + (" incl. VGG19 perceptual" if perceptual else "") + f" + backward; 1 warm-up + 2 timed iterations ({times[1]:.1f} s, {times[2]:.1f} s)"}
+    # ONE iteration of the workload's own batch (B clips through one forward / backward: BatchNorm over the batch, as the step the north star describes), no warm-up beyond the
+    # single-clip iterations above; bounded: skipped when the single-clip iteration already took more than 8 s
+    Bw = wl["batch"]
+    if Bw > 1 and dt < 8.0 and os.environ.get("CADDY_BENCH_CPU_BATCH", "1") != "0":
+        obs_b = torch.rand(Bw, wl["seq_len"], 3 * wl["stacking"], wl["height"], wl["width"]) * 2 - 1
+        t0 = time.time()
+        out = O.Oracle(d, P, training=True).forward_full(obs_b, wl["gt_init"], tau=wl["tau"])
+        total, _, _ = O.full_model_loss(out, obs_b, w, mi_ema=torch.full((d.K, d.K), 1.0 / d.K ** 2), vgg=V)
+        total.backward()
+        tb = time.time() - t0
+        res["batch_sample"] = {"value": Bw / tb, "unit": "clips/s", "batch": Bw, "seconds": tb,
+                               "sample": f"one iteration at the workload's batch (B={Bw}): the same oracle step on {Bw} clips at once, {tb:.1f} s"}
+    return res
 
 
 def rollout_fps(dev, frames=32):

@@ -200,6 +200,7 @@ int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 
 int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st);    // conv_head.hip: dgrad of the 7x7 head (3 -> C channels) on the split-bf16 matrix pipe (ConvArgs.precision == PREC_BF16X3, no wq)
 int conv_direct_try(const ConvArgs& a, hipStream_t st);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
 int conv_stream_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: HBM-bound 1x1 weight gradients, operands straight from global memory into the fp32 MFMA (1 = handled)
+int conv_head_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: weight gradient of the 7x7 FinalBlock head on the split-bf16 matrix pipe, taps on the M side (1 = handled)
 extern thread_local int g_last_wgrad_grouped;      // 1: the kernel the last conv_*_wgrad_try picked understands time-batched arguments (WgradArgs.group_n)
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching

@@ -942,6 +942,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs: k_wgrad_hx only
     g_last_wgrad_grouped = 0;
     { int rc = conv_stream_wgrad_try(a, st, dry); if (rc != 0) return rc < 0 ? rc : 0; }      // 1x1 layers: streaming kernel, both operands straight into the fp32 MFMA (conv_stream.hip)
+    { int rc = conv_head_wgrad_try(a, st, dry); if (rc != 0) return rc < 0 ? rc : 0; }        // 7x7 FinalBlock head: split bf16, taps on the M side (conv_stream.hip)
     if (conv_c4_wgrad_try(a, st, dry) == 1) return 0;       // 3-channel side: 16x16x4 MFMA (conv_narrow.hip)
     if (conv_thin_wgrad_try(a, st, dry) == 1) return 0;
     if (conv_narrow_wgrad_try(a, st, dry) == 1) return 0;   // 16-channel sides: 16x16x4 MFMA (conv_narrow.hip)

@@ -562,7 +562,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             fill_srcs(w.src, sg, nseg);
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
             w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
-            w.precision = (Lp->wq && prec_bwd != PREC_FP32) ? PREC_BF16X3 : PREC_FP32;
+            w.precision = ((Lp->wq || (Lp->pd.Cout <= 3 && Lp->pd.KS == 7)) && prec_bwd != PREC_FP32) ? PREC_BF16X3 : PREC_FP32;      // (7x7 FinalBlock head: split bf16 on conv_stream.hip's k_wgrad_head7)
             queue_wgrad(Lp, w, px_taps * Lp->pd.Cin * Lp->pd.Cout);
             bool bias_done = !Lp->dbias;
             bool any_aux = !bias_done;

@@ -188,3 +188,14 @@ def test_conv_hx_s16_tensors_small():
     """round 5: activations exchanged pre-split between k_conv_hx launches (ConvArgs.out_s16 / pool_s16 -> in_s16): bit-identical to the fp32 exchange, forward and dgrad chain"""
     K.hx_s16_chain_case(load_emu(), "cpu", N=1, H=16, W=16, C0=64, C1=128, C2=64)
     K.hx_s16_chain_case(load_emu(), "cpu", N=1, H=18, W=20, C0=64, C1=64, C2=128, pool=True)
+
+
+def test_streaming_weight_gradients_small():
+    """round 5 (conv_stream.hip): the 7x7 FinalBlock head's weight gradient on the split-bf16 matrix pipe with the taps on the M side (k_wgrad_head7: ragged tiles, 16 / 32 input
+    channels, time-batched groups, bit-reproducible slabs -- conv_case runs all of them) and the 1x1 identity-path weight gradients straight from global memory (k_wgrad_1x1)"""
+    lib = load_emu()
+    for kw in (dict(N=1, H=11, W=35, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1), dict(N=2, H=8, W=70, segs=[(16, 0)], Cout=3, KS=7, bias=True, act=1),
+               dict(N=3, H=6, W=9, segs=[(32, 0)], Cout=3, KS=7)):
+        K.conv_case(lib, "cpu", wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4, **kw)
+    for kw in (dict(N=2, H=20, W=24, segs=[(64, 0)], Cout=128, KS=1), dict(N=3, H=17, W=9, segs=[(32, 0)], Cout=65, KS=1), dict(N=2, H=40, W=40, segs=[(16, 0)], Cout=32, KS=1)):
+        K.conv_case(lib, "cpu", **kw)

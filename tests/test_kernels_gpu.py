@@ -221,3 +221,16 @@ def test_wgrad_hx(lib, kw):
 def test_conv_hx_s16_tensors(lib, kw):
     """round 5: activations exchanged pre-split between k_conv_hx launches (ConvArgs.out_s16 / pool_s16 -> in_s16): bit-identical to the fp32 exchange, forward and dgrad chain"""
     K.hx_s16_chain_case(lib, "cuda", **kw)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=2, H=64, W=64, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4),      # D's 7x7 head
+    dict(N=5, H=44, W=100, segs=[(32, 0)], Cout=3, KS=7, wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4),                        # ragged tiles, many samples
+    dict(N=2, H=32, W=48, segs=[(16, 0)], Cout=3, KS=7, bias=True, act=1, wgrad_precision=17, wgrad_tol=1e-4),                                           # reduced variant: 16 channels
+    dict(N=16, H=32, W=32, segs=[(64, 0)], Cout=128, KS=1),                                                                                             # A's identity path
+    dict(N=4, H=128, W=128, segs=[(16, 0)], Cout=32, KS=1),                                                                                             # E's first down-sampling block
+    dict(N=6, H=20, W=20, segs=[(64, 0)], Cout=65, KS=1),                                                                                               # E's last block (65 channels), Breakout state map
+])
+def test_streaming_weight_gradients(lib, kw):
+    """round 5 (conv_stream.hip): k_wgrad_head7 (7x7 head, split bf16, taps on the M side) and k_wgrad_1x1 (identity paths, operands straight from global memory)"""
+    K.conv_case(lib, "cuda", **kw)
