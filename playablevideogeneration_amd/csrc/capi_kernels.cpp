@@ -20,6 +20,7 @@ int caddy_k_bn_bwd_lazy(const TV* dout, const TV* x, const float* mean, const fl
 }
 int caddy_k_conv_wgrad(const WgradArgs* a, void* s) { return conv_wgrad_launch(*a, ST(s)); }
 int caddy_k_conv_pick_bn(int cout) { return conv_pick_bn(cout); }
+int caddy_k_conv_avgpool_ok(const ConvArgs* a) { return conv_avgpool_ok(*a); }
 int caddy_k_hx_pick_bn(int cout) { return hx_pick_bn(cout); }
 int caddy_k_hx_force_big(int v) { g_hx_big_override = v; return 0; }
 long caddy_k_hx_weight_bytes(const PackDesc* d, int seg, int rows_pad, int planes) { return (long)hx_weight_bytes(*d, seg, rows_pad, planes); }

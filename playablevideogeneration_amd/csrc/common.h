@@ -119,7 +119,12 @@ struct ConvArgs {
     int out_s16;            // `out` is written as S16 (no accumulate, no split-K)
     int pool_s16;           // `pool_out` is written as S16 (requires out_s16 semantics of the epilogue: set together with or without out_s16)
     int mask_s16, seed_s16; // `mask` / `seed_ref` are S16-f16 tensors
+    // AvgPool2d(2) of the result inside the epilogue (inference with folded BatchNorm: conv -> avg_pool2d(2) -> affine -> LeakyReLU, residual_block.py:52-56 /
+    // representation_network.py:39-41): `out` is the (N, H/2, W/2, Cout) map, bias / res / act are applied AFTER the pooling (H, W even).  Only the launches
+    // conv_avgpool_ok() accepts (k_conv_narrow: a window's four pixels are two accumulators of one lane x a DPP neighbour); the caller asks first.
+    int avgpool;
 };
+int conv_avgpool_ok(const ConvArgs& a);      // (out / out_sn / out_ld need not be set yet)
 // gates = [i | f | o | g] x C pre-activations (convolutional_lstm_cell.py:92-101): c' = sigm(f) c + sigm(i) tanh(g), h' = sigm(o) tanh(c'), hb = h' * scale + shift (the cell's
 // eval-mode BatchNorm, conv_dynamics_network.py); all tensors NHWC with their own sample / pixel pitches
 struct LstmFuse { const float* cprev; long cprev_sn; int cprev_ld; float* h; long h_sn; int h_ld; float* c; long c_sn; int c_ld; float* hb; long hb_sn; int hb_ld; const float* scale; const float* shift; int C; };
@@ -198,12 +203,14 @@ int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc,
 int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 1 = handled (thin-channel shape), 0 = not thin
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
 int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st);    // conv_head.hip: dgrad of the 7x7 head (3 -> C channels) on the split-bf16 matrix pipe (ConvArgs.precision == PREC_BF16X3, no wq)
-int conv_direct_try(const ConvArgs& a, hipStream_t st);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
+int conv_hx_avgpool_ok(const ConvArgs& a);
+int conv_direct_try(const ConvArgs& a, hipStream_t st, bool dry = false);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
 int conv_stream_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: HBM-bound 1x1 weight gradients, operands straight from global memory into the fp32 MFMA (1 = handled)
 int conv_head_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: weight gradient of the 7x7 FinalBlock head on the split-bf16 matrix pipe, taps on the M side (1 = handled)
 extern thread_local int g_last_wgrad_grouped;      // 1: the kernel the last conv_*_wgrad_try picked understands time-batched arguments (WgradArgs.group_n)
 int conv_narrow_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
 int conv_c4_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // dry: report the match without launching
 int conv_c4_fwd_try(const ConvArgs& a, hipStream_t st);       // conv_narrow.hip: 3-channel (pitch 4) input, 3x3 / 7x7, on 16x16x4 MFMA
-int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st);   // conv_narrow.hip: 1 = handled (3x3, 13..32 channels in, 5..32 out)
+int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st);   // conv_narrow.hip: 1 = handled (3x3, 5..32 channels in, 5..32 out)
+int conv_narrow_fwd_ok(const ConvArgs& a);                     // its shape test alone
 int conv_thin_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);   // N-tile (32/64/128) the launcher will use for this Cout

@@ -35,10 +35,13 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
     __shared__ ChunkRef tab[DIRECT_MAX_CHUNKS];
     __shared__ __attribute__((aligned(16))) float red[NW * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ConvArgs.avgpool: the 16 pixels are a 2 x 8 block (rows 2y, 2y + 1) whose 2x2 windows are averaged by the epilogue -> 4 pixels of row y of the (H/2, W/2) output
+    const bool AP = a.avgpool != 0;
+    const int rows = AP ? a.H >> 1 : a.H;
     int g = blockIdx.x;
-    const int n = g / (groups_x * a.H);
-    g -= n * groups_x * a.H;
-    const int y = g / groups_x, x0 = (g - y * groups_x) * 16;
+    const int n = g / (groups_x * rows);
+    g -= n * groups_x * rows;
+    const int y = g / groups_x, x0 = (g - y * groups_x) * (AP ? 8 : 16);
     const int co0 = blockIdx.y * 16;
     const int nchunks = a.Kq / DK, nsteps = nchunks * 9;
     // chunk -> source table (segments are padded to whole chunks in the packed weights)
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
     }
     __syncthreads();
     const int px = lane & 15, kg = lane >> 4;                 // B fragment: pixel column, k-group (8 channels); A fragment: output channel row px, same k-group
+    const int py = AP ? 2 * y + (px >> 3) : y, pxx = x0 + (AP ? (px & 7) : px);      // this lane's input-resolution pixel
     const _Float16* wq = reinterpret_cast<const _Float16*>(a.wq) + ((long)co0 + px) * (2 * DK) + kg * 8;
     const long wstep = (long)a.Cout_pad * (2 * DK);           // halves between consecutive (tap, chunk) tiles
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
             int s = s0 + NW * u; s = s < nsteps ? s : nsteps - 1;
             const int chunk = s / 9, tap = s - 9 * chunk;
             const ChunkRef r = tab[chunk];
-            const int yy = y + tap / 3 - 1, xx = x0 + px + tap % 3 - 1;
+            const int yy = py + tap / 3 - 1, xx = pxx + tap % 3 - 1;
             const int c = r.c0 + kg * 8;
             ok[u] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W; cc[u] = c; CC[u] = r.C;
             const float* p = r.base + (ok[u] ? ((long)yy * a.W + xx) * r.pl : 0L);
@@ -93,16 +97,36 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
     __syncthreads();
     if (wave != 0) return;
     float v[4];
+    int xx = x0 + px, OW = a.W;
+    if (AP) {      // lanes px < 4: pooled pixel x0 / 2 + px = the average of tile pixels {2 px, 2 px + 1} x {row 0, row 1}; each summed over the waves in order first
+        if (px >= 4) return;
+        const int l0 = (lane & 48) + 2 * px;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float t = red[lane * 4 + r];
+        for (int r = 0; r < 4; r++) {
+            float q[4];
 #pragma unroll
-        for (int w = 1; w < NW; w++) t += red[(w * 64 + lane) * 4 + r];
-        v[r] = t;
+            for (int j = 0; j < 4; j++) {
+                const int l = l0 + (j & 1) + 8 * (j >> 1);
+                float t = red[l * 4 + r];
+#pragma unroll
+                for (int w = 1; w < NW; w++) t += red[(w * 64 + l) * 4 + r];
+                q[j] = t;
+            }
+            v[r] = 0.25f * ((q[0] + q[1]) + (q[2] + q[3]));
+        }
+        xx = (x0 >> 1) + px; OW = a.W >> 1;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float t = red[lane * 4 + r];
+#pragma unroll
+            for (int w = 1; w < NW; w++) t += red[(w * 64 + lane) * 4 + r];
+            v[r] = t;
+        }
     }
-    const int xx = x0 + px, co = co0 + 4 * kg;
-    if (xx >= a.W || co >= a.Cout) return;
-    const long pix = (long)y * a.W + xx;
+    const int co = co0 + 4 * kg;
+    if (xx >= OW || co >= a.Cout) return;
+    const long pix = (long)y * OW + xx;
     float* o = a.out + (long)n * a.out_sn + pix * a.out_ld + co;
     const float* rp = a.res ? a.res + (long)n * a.res_sn + pix * a.res_ld + co : nullptr;
 #pragma unroll
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
 #define DIRECT_MAX_WORK 24576
 
 // 1 = handled.  Called by conv_hx_try for assigning split-f16 launches it would otherwise split over K (a.Kq, a.out_scale, a.Cout_pad set by the caller).
-int conv_direct_try(const ConvArgs& a, hipStream_t st) {
+int conv_direct_try(const ConvArgs& a, hipStream_t st, bool dry) {
     if (a.KS != 3 || !a.wq || a.precision != PREC_F16X3 || a.accumulate || a.mask || a.pool_out || a.skip_out || a.stats || a.seed_ref) return 0;
     if (a.act != 0 && a.act != 2 && a.act != 3) return 0;
     if ((a.out_ld & 3) || (a.out_sn & 3) || (a.res && ((a.res_ld & 3) || (a.res_sn & 3)))) return 0;
@@ -131,10 +155,12 @@ int conv_direct_try(const ConvArgs& a, hipStream_t st) {
     if (((uintptr_t)a.out | (uintptr_t)a.res) & 15) return 0;      // (float4 accesses: a channel-offset view with c0 % 4 != 0 stays on the tile kernel)
     const int nchunks = a.Kq / DK;
     if (nchunks < 1 || nchunks > DIRECT_MAX_CHUNKS) return 0;
-    const int gx = cdiv(a.W, 16);
-    const long groups = (long)a.N * a.H * gx, cob = cdiv(a.Cout, 16);
+    if (a.avgpool && ((a.H | a.W) & 1)) return 0;
+    const int gx = a.avgpool ? cdiv(a.W, 8) : cdiv(a.W, 16);
+    const long groups = (long)a.N * (a.avgpool ? a.H / 2 : a.H) * gx, cob = cdiv(a.Cout, 16);
     if (groups * cob * nchunks * 9 > DIRECT_MAX_WORK) return 0;
     if ((long)cob * 16 > a.Cout_pad) return 0;
+    if (dry) return 1;
     dim3 grid((unsigned)groups, (unsigned)cob);
     // (eight waves on the long reductions of R's 16x16 side branch -- 81 steps, 128 workgroups -- measured SLOWER: 13.7 us against ~8, roll-out 2068 -> 2014 frames/s)
     if (nchunks * 9 >= 36) hipLaunchKernelGGL((k_conv_direct<4, 3>), grid, dim3(256), 0, st, a, gx);

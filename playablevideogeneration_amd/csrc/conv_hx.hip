@@ -582,6 +582,16 @@ bool conv_src_lazy_ok(const ConvArgs& a) {
 thread_local int g_last_conv_stats_tiles = 0;
 thread_local int g_last_conv_direct = 0;
 
+// would an average-pooled launch (ConvArgs.avgpool) of this split-f16 layer run (on the latency kernel)?  `out` need not be set.
+int conv_hx_avgpool_ok(const ConvArgs& a0) {
+    ConvArgs a = a0;
+    if (a.KS != 3 || !a.wq || a.precision != PREC_F16X3 || !a.direct_ok || a.act == 1) return 0;
+    int kq = 0;
+    for (int s = 0; s < a.nsrc; s++) { if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0; kq += round_up(a.src[s].C, HX_KC); }
+    a.Kq = kq; a.Cout_pad = round_up(a.Cout, hx_pick_bn(a.Cout)); a.avgpool = 1;
+    return conv_direct_try(a, nullptr, true) == 1 ? 1 : 0;
+}
+
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
 int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
@@ -594,6 +604,11 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     a.Cout_pad = round_up(a.Cout, bn);      // (row padding of the packed weights: independent of the tile width chosen below)
     if (a.mask && a.accumulate) return -1;
     if (a.pool_out && (a.accumulate || a.mask)) return -1;
+    if (a.avgpool) {      // average-pooled epilogue: the latency kernel only (the caller asked conv_avgpool_ok)
+        if (!(a.direct_ok && conv_direct_try(a, st) == 1)) return -1;
+        g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1;
+        return 1;
+    }
     if ((long)a.H * a.W * a.out_ld >= (1L << 30) || (a.res && (long)a.H * a.W * a.res_ld >= (1L << 30))) return 0;      // (the epilogue addresses one sample with 32-bit byte offsets)
     const int nchunks = kq / HX_KC;
     // under-filled wide layers (R's gate / SameBlock convolutions on 16x16 .. 32x32 maps, A, D's first stage at batch 8): 64-channel tiles on the same

@@ -104,28 +104,51 @@ __global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, in
             int rem = (int)(tile - (long)n * tiles_x * tiles_y);
             int ty = rem / tiles_x;
             int y0 = ty * NTH, x0 = (rem - ty * tiles_x) * NTW;
+            // (bias, residual, LeakyReLU, accumulate) of channels c .. c+3 at pixel (y, x) of an OW-wide output map
+            auto emit = [&](int y, int x, int OW, int c, float (&v)[4]) {
+                float* o = a.out + (long)n * a.out_sn + ((long)y * OW + x) * a.out_ld;
+                if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
+                if (a.res) {
+                    const float* rp = a.res + (long)n * a.res_sn + ((long)y * OW + x) * a.res_ld + c;
+                    for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += rp[e];
+                }
+                if (a.act == 3) for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                if (c + 4 <= a.Cout) {
+                    float4 r = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+                    *reinterpret_cast<float4*>(o + c) = r;
+                } else {
+                    for (int e = 0; e < 4 && c + e < a.Cout; e++) o[c + e] = a.accumulate ? o[c + e] + v[e] : v[e];
+                }
+            };
+            if (a.avgpool) {      // 2x2 average: the wave's two rows are accumulators nt and nt + 2 of one lane, the column neighbour is lane ^ 1 (every lane takes part in the exchange)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + lp;
-                if (y >= a.H || x >= a.W) continue;
-                float* o = a.out + (long)n * a.out_sn + ((long)y * a.W + x) * a.out_ld;
+                for (int h = 0; h < 2; h++) {
+                    const int y = y0 + 2 * wave, x = x0 + 16 * h + lp;
 #pragma unroll
-                for (int m = 0; m < NT; m++) {
-                    int c = m * 16 + 4 * g;
-                    if (c >= a.Cout) continue;
-                    float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
-                    if (a.bias) for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += a.bias[c + e];
-                    if (a.res) {
-                        const float* rp = a.res + (long)n * a.res_sn + ((long)y * a.W + x) * a.res_ld + c;
-                        for (int e = 0; e < 4; e++) if (c + e < a.Cout) v[e] += rp[e];
+                    for (int m = 0; m < NT; m++) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float r = acc[h][m][e] + acc[h + 2][m][e];
+                            const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0xB1, 0xF, 0xF, true));      // quad_perm [1, 0, 3, 2]
+                            v[e] = 0.25f * (r + nb);
+                        }
+                        const int c = m * 16 + 4 * g;
+                        if (!(lp & 1) && y < a.H && x < a.W && c < a.Cout) emit(y >> 1, x >> 1, a.W >> 1, c, v);
                     }
-                    if (a.act == 3) for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-                    if (c + 4 <= a.Cout) {
-                        float4 r = make_float4(v[0], v[1], v[2], v[3]);
-                        if (a.accumulate) { float4 p = *reinterpret_cast<const float4*>(o + c); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
-                        *reinterpret_cast<float4*>(o + c) = r;
-                    } else {
-                        for (int e = 0; e < 4 && c + e < a.Cout; e++) o[c + e] = a.accumulate ? o[c + e] + v[e] : v[e];
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + lp;
+                    if (y >= a.H || x >= a.W) continue;
+#pragma unroll
+                    for (int m = 0; m < NT; m++) {
+                        int c = m * 16 + 4 * g;
+                        if (c >= a.Cout) continue;
+                        float v[4] = {acc[nt][m][0], acc[nt][m][1], acc[nt][m][2], acc[nt][m][3]};
+                        emit(y, x, a.W, c, v);
                     }
                 }
             }
@@ -136,11 +159,27 @@ __global__ __launch_bounds__(256) void k_conv_narrow(ConvArgs a, int tiles_x, in
 }  // namespace
 
 // returns 1 if handled, 0 if the shape does not qualify
+// shape test of k_conv_narrow (the output pointer / pitches need not be set: conv_avgpool_ok asks before the output exists).  Round 5: 5 .. 12 input channels too (the
+// observation_stacking > 1 stem: 12 -> 16; its K = 16 weight rows are zero beyond C and the loader zero-fills) -- 12 us instead of the vector-ALU kernel's 22 + 5 us at 256 x 256
+static bool narrow_shape_ok(const ConvArgs& a) {
+    if (a.nsrc != 1 || a.src[0].bcast || a.src[0].bn_scale || a.KS != 3 || (a.act != 0 && a.act != 3) || a.splitk > 1) return false;
+    if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 4 || a.Cout <= 4) return false;
+    if (a.src[0].C <= 12 && a.Cout < 16) return false;      // (thin input AND thin output: the stem's dgrad shapes stay on conv_thin.hip)
+    if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || a.Cout_pad < 16 * ((a.Cout + 15) / 16)) return false;
+    if (a.mask || a.pool_out || a.skip_out || a.in_s16 || a.out_s16) return false;
+    if ((long)a.N * a.H * a.W < 4096) return false;                    // tiny maps: the generic kernel's split-K paths do better
+    if (a.avgpool && ((a.H | a.W) & 1)) return false;
+    return true;
+}
+int conv_narrow_fwd_ok(const ConvArgs& a) { return narrow_shape_ok(a) ? 1 : 0; }
+int conv_avgpool_ok(const ConvArgs& a) {
+    if (a.wq && a.precision >= PREC_F16X3) return conv_hx_avgpool_ok(a);      // a split-operand layer: conv_fwd_launch tries k_conv_hx's launcher first (conv_direct.hip has the pooled epilogue)
+    ConvArgs b = a; b.avgpool = 1; b.splitk = 1;
+    return narrow_shape_ok(b) ? 1 : 0;
+}
+
 int conv_narrow_fwd_try(const ConvArgs& a, hipStream_t st) {
-    if (a.nsrc != 1 || a.src[0].bcast || a.KS != 3 || (a.act != 0 && a.act != 3) || a.splitk > 1) return 0;
-    if (a.Ktot > 32 || a.Cout > 32 || a.src[0].C <= 12 || a.Cout <= 4) return 0;
-    if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.out_ld & 3) || (a.out_sn & 3) || a.Cout_pad < 16 * ((a.Cout + 15) / 16)) return 0;
-    if ((long)a.N * a.H * a.W < 4096) return 0;                    // tiny maps: the generic kernel's split-K paths do better
+    if (!narrow_shape_ok(a) || (a.out_ld & 3) || (a.out_sn & 3)) return 0;
     const int tx = cdiv(a.W, NTW), ty = cdiv(a.H, NTH);
     const long ntiles = (long)a.N * tx * ty;
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);

@@ -276,6 +276,7 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st) {
     // IN <= 12 (stem, FinalBlock dgrad).  Wider inputs stay on the MFMA kernel: scalar v_fma_f32 peaks at half the packed/MFMA
     // fp32 rate, so the VALU path only wins when it avoids > 2x channel padding (measured: 32->64 @64x64: 482 us here vs 221 us on MFMA).
     if (a.src[0].C <= 12 && a.Ktot == 16 && a.act == 0) {
+        if (conv_narrow_fwd_ok(a)) return 0;      // 5 .. 12 channels -> >= 16: the 16x16x4 matrix-instruction kernel of conv_narrow.hip (round 5: 22 + 5 -> 12 us for the stacked-frame stem at 256 x 256)
         int groups = cdiv(a.Cout, 16);
         if (groups * 16 > a.Cout_pad || (long)a.N * groups > 65535) return 0;
         grid.z = a.N * groups;

@@ -519,18 +519,25 @@ int caddy_ctx::launch_conv_wgrad(const WgradArgs& a0, double flops, hipStream_t 
 T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into, bool nz_out, const T4* res) {
     int N = 0, H = 0, W = 0;
     for (int s = 0; s < nseg; s++) if (!segs[s].bcast) { N = segs[s].t.N; H = segs[s].t.H; W = segs[s].t.W; break; }
-    T4 out = into ? *into : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout));
     ConvArgs a{};
     fill_srcs(a.src, segs, nseg);
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
-    a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf; a.out = out.d;
+    a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf;
+    const bool range_ok = !layer_fallback[L.flag_idx];      // (a layer that reported |x| > 65504 stays on the exact-fp32 forward: caddy_f16_saturated)
+    if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
+    else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32 && range_ok) { a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
+    bool pooled = false;
+    if (pool_fuse) {      // conv_pool(): the 2x2 average (+ LeakyReLU) goes into the epilogue when the launch has one for it
+        a.act = pool_fuse == 2 ? 3 : 0;
+        if (!recording && !into && !res && conv_avgpool_ok(a)) { pooled = true; a.avgpool = 1; pool_fuse = 0; }
+        else a.act = actf;
+    }
+    T4 out = into ? *into : (pooled ? alloc(N, H / 2, W / 2, L.pd.Cout) : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout)));
+    a.out = out.d;
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     g_last_conv_lstm_fused = 0;
     if (lstm_fuse) { a.lstm = lstm_fuse; lstm_fuse = nullptr; }      // (set by lstm_step for the gate convolution of a roll-out cell)
-    const bool range_ok = !layer_fallback[L.flag_idx];      // (a layer that reported |x| > 65504 stays on the exact-fp32 forward: caddy_f16_saturated)
-    if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
-    else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32 && range_ok) { a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
     for (int s = 0; s < nseg; s++)
         if (segs[s].t.bn_scale && !conv_src_lazy_ok(a)) { fail = true; set_error("internal: lazily normalised input handed to a convolution that cannot apply it"); }
     TileStats* ts_slot = nullptr;
@@ -628,6 +635,13 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     return out;
 }
 
+// conv -> avg_pool2d(2) [-> LeakyReLU] of the BatchNorm-folded inference graph as ONE launch where the kernel can (conv_avgpool_ok), conv + pool2 otherwise
+T4 caddy_ctx::conv_pool(ConvL& L, const Seg* segs, int nseg, bool actf) {
+    pool_fuse = actf ? 2 : 1;
+    T4 o = conv(L, segs, nseg, 0, nullptr);
+    if (pool_fuse) { pool_fuse = 0; o = pool2(o, actf); }
+    return o;
+}
 T4 caddy_ctx::pool2(const T4& x, bool actf) {
     T4 o = x.nz ? alloc_nz(x.N, x.H / 2, x.W / 2, x.C) : alloc(x.N, x.H / 2, x.W / 2, x.C);   // conv -> pool -> BatchNorm chains stay first-touch
     RUN(pw_pool2(dv(x), dv(o), stream, actf ? 1 : 0));
@@ -747,8 +761,7 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
 T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into, bool nz2_out) {
     Seg sx{x, 0, true};
     if (fold) {      // roll-out: BatchNorms folded into the convs -- conv1' (+ pool) + LeakyReLU, then act(conv2'(a) + identity) in conv2's epilogue
-        T4 a1 = conv(R.conv1, &sx, 1, R.ds == 1 ? 3 : 0, nullptr);
-        if (R.ds == 2) a1 = pool2(a1, true);
+        T4 a1 = R.ds == 2 ? conv_pool(R.conv1, &sx, 1, true) : conv(R.conv1, &sx, 1, 3, nullptr);
         Seg sa{a1, 0, true};
         if (!R.has_down) return conv(R.conv2, &sa, 1, 3, into, false, &x);
         T4 idn = conv(R.down, &sx, 1, 0, nullptr);
@@ -774,8 +787,9 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into, bool nz2_out) {
 // RepresentationNetwork.forward (model/main_model/representation_network.py:32-58); output keeps the 65th (attention) channel
 T4 caddy_ctx::encode(const T4& obs_in, bool input_grad, const T4* into) {
     Seg so{obs_in, 0, input_grad};
-    T4 x = conv(e_stem, &so, 1, 0, nullptr, true);
-    x = pool2(x, fold);
+    T4 x;
+    if (fold) x = conv_pool(e_stem, &so, 1, true);
+    else { x = conv(e_stem, &so, 1, 0, nullptr, true); x = pool2(x, false); }
     // (outputs consumed by a residual block WITHOUT down-sampling path -- identity add + one conv -- get first-touch gradients: T4::nz2)
     if (!fold) x = bn_act(x, e_bn1, nullptr, nullptr, true, nullptr, false, !e_res[0].has_down);
     for (int i = 0; i < 5; i++) x = resblock(e_res[i], x, nullptr, !e_res[i + 1].has_down);

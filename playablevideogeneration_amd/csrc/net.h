@@ -239,6 +239,7 @@ struct caddy_ctx {
     // sums behind (ConvArgs.stats) and bn_forward() finalises from them instead of re-reading the tensor.  (2) bn_act(..., lazy_for): the single consumer is a
     // convolution that applies scale / shift / LeakyReLU while staging its input, so the normalised tensor is never written (T4::bn_*).
     bool want_stats = false;
+    int pool_fuse = 0;      // set by conv_pool() for the next conv(): 1 = average-pool the result, 2 = and apply LeakyReLU (cleared by conv() when its launch took the pooled epilogue)
     struct TileStats { const float* x = nullptr; float* part = nullptr; int tiles = 0, ldp = 0; };
     TileStats stats_ring[2]; int stats_next = 0;      // the two most recent producers (a residual block's conv2 and its 1x1 down-sampling conv feed one bn_act call)
     const TileStats* find_stats(const float* x) const { for (const TileStats& t : stats_ring) if (t.x == x && t.tiles > 0) return &t; return nullptr; }
@@ -246,6 +247,7 @@ struct caddy_ctx {
     long n_bn_lazy = 0, n_bn_tile_stats = 0, n_bn_calls = 0;      // since creation: BatchNorm calls applied lazily / finalised from conv-epilogue partial sums / all train-mode calls (caddy_debug_fusion_counts)
     bool lazy_ok(const ConvL& consumer, const T4& x) const;
     T4 pool2(const T4& x, bool act = false);
+    T4 conv_pool(ConvL& L, const Seg* segs, int nseg, bool act);
     T4 up2(const T4& x);
     T4 bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool act, const T4* into, bool nz_out = false, bool nz2_out = false,
               const ConvL* lazy_for = nullptr);   // nz_out: the output feeds exactly one conv; nz2_out: T4::nz2; lazy_for: that one conv (same H, W) -- candidate for the lazily applied form

@@ -149,6 +149,9 @@ static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int /*row_mask*/, in
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only ever applied to wave-uniform values */
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }      /* v_med3_f32 (a NaN drops out) */
 using std::max;
 #define __expf expf

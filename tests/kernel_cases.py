@@ -60,9 +60,10 @@ def make_pack(ws, segs, KS, lib):
 
 
 def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True, wgrad_precision=0, wgrad_tol=None,
-              res=False, oscale=False, dgrad_precision=None, dgrad_tol=None):
+              res=False, oscale=False, dgrad_precision=None, dgrad_tol=None, avgpool=False):
     """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd.
-    dgrad_precision = 17: ConvArgs.precision of the dgrad launches (split bf16: conv_head.hip's 7x7 head dgrad)."""
+    dgrad_precision = 17: ConvArgs.precision of the dgrad launches (split bf16: conv_head.hip's 7x7 head dgrad).
+    avgpool: ConvArgs.avgpool -- the launch writes avg_pool2d(conv, 2) with bias / residual / activation applied after the pooling (forward only)."""
     g = torch.Generator().manual_seed(seed)
     Cin = sum(c for c, _ in segs)
     xs = []
@@ -78,7 +79,11 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     osc = (torch.rand(Cout, generator=g) + 0.5) if oscale else None       # PackDesc.oscale: per-output-channel factor folded into the packed weights
     if oscale:
         y_ref = (y_ref - (b[None, :, None, None] if bias else 0)) * osc[None, :, None, None] + (b[None, :, None, None] if bias else 0)
-    r_in = torch.randn(N, Cout, H, W, generator=g) if res else None        # ConvArgs.res: residual input added before the activation
+    OH, OW = (H // 2, W // 2) if avgpool else (H, W)
+    if avgpool:
+        assert not check_bwd
+        y_ref = F.avg_pool2d(y_ref, 2)
+    r_in = torch.randn(N, Cout, OH, OW, generator=g) if res else None        # ConvArgs.res: residual input added before the activation
     if res:
         y_ref = y_ref + r_in
     if act == 1:
@@ -122,11 +127,14 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     split = torch.zeros(9 * N * H * W * round_up(Cout, 4), device=dev)     # slabs of the deterministic forward split-K
     a.split_scratch, a.split_cap = (split.data_ptr(), split.numel()) if use_aux else (None, 0)
     out_ld = round_up(Cout, 4) + 4
-    out = torch.full((N, H, W, out_ld), 9.0, device=dev)
-    a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), H * W * out_ld, out_ld, 0
+    out = torch.full((N, OH, OW, out_ld), 9.0, device=dev)
+    a.out, a.out_sn, a.out_ld, a.accumulate = out.data_ptr(), OH * OW * out_ld, out_ld, 0
     if res:
         r_d = nhwc(r_in, ld=round_up(Cout, 4) + 8, dev=dev)
-        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), H * W * r_d.shape[3], r_d.shape[3]
+        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), OH * OW * r_d.shape[3], r_d.shape[3]
+    if avgpool:
+        assert lib.caddy_k_conv_avgpool_ok(C.byref(a)) == 1
+        a.avgpool = 1
     assert lib.caddy_k_conv_fwd(C.byref(a), st) == 0
     sync(dev)
     y = to_nchw(out, Cout)
@@ -518,10 +526,11 @@ PREC_F16X3, PREC_BF16X3, PREC_F16X1, PREC_BF16X1 = 16, 17, 18, 19
 
 
 def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=False, act=0, mask=False, seed_w=0.0, accumulate=False, dgrad_seg=None,
-                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False, pool=False, skip_out=False, direct=False):
+                 split=False, seed=0, tol=None, big=-1, res=False, oscale=False, pool=False, skip_out=False, direct=False, avgpool=False):
     """conv_hx.hip: 3x3 convolution on the 16-bit MFMA with split operands, through caddy_k_pack_hx + caddy_k_conv_fwd.
     direct = True: ConvArgs.direct_ok -- small assigning launches go to the latency kernel (conv_direct.hip); the case asserts that it was taken (the untouched pad columns of
     the output and, with `split`, the untouched slab scratch tell).
+    avgpool = True (with direct): ConvArgs.avgpool -- the launch writes avg_pool2d(conv, 2) with bias / activation after the pooling (conv_direct.hip's 2 x 8-pixel groups).
     dgrad_seg = s: the dgrad form (input = dY with Cout channels, output = gradient of input segment s), reference = torch autograd.
     Reference: torch fp64 conv2d of the fp32 inputs (so that the split-f16 error itself is measured: tol ~ a few 1e-7 relative)."""
     lib.caddy_k_hx_weight_bytes.restype = C.c_long
@@ -576,10 +585,15 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     a.wq, a.precision = wq.data_ptr(), precision
     b_d = b.to(dev) if bias else None
     a.bias, a.act = (b_d.data_ptr() if bias else None), act
+    OH, OW = H, W
+    if avgpool:
+        assert direct and dgrad_seg is None and not (mask or accumulate or pool)
+        ref = F.avg_pool2d(ref, 2)
+        OH, OW = H // 2, W // 2
     if res:
-        r_in = torch.randn(N, out_c, H, W, generator=g)
+        r_in = torch.randn(N, out_c, OH, OW, generator=g)
         r_d = nhwc(r_in, ld=round_up(out_c, 4) + 8, dev=dev)
-        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), H * W * r_d.shape[3], r_d.shape[3]
+        a.res, a.res_sn, a.res_ld = r_d.data_ptr(), OH * OW * r_d.shape[3], r_d.shape[3]
         ref = ref + r_in.double()
     if act == 1:
         ref = torch.tanh(ref)
@@ -588,7 +602,7 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     elif act == 3:
         ref = F.leaky_relu(ref, 0.2)
     out_ld = round_up(out_c, 4) + 4
-    init = torch.randn(N, H, W, out_ld, generator=g)
+    init = torch.randn(N, OH, OW, out_ld, generator=g)
     out = init.clone().to(dev)
     if mask:
         mk = torch.randn(N, H, W, out_ld, generator=g)
@@ -607,9 +621,12 @@ def hx_conv_case(lib, dev, *, N, H, W, segs, Cout, precision=PREC_F16X3, bias=Fa
     if split:
         scr = torch.zeros(8 * N * H * W * round_up(out_c, 4), device=dev)
         a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()
-    a.out, a.out_sn, a.out_ld = out.data_ptr(), H * W * out_ld, out_ld
+    a.out, a.out_sn, a.out_ld = out.data_ptr(), OH * OW * out_ld, out_ld
     if direct:
         a.direct_ok = 1
+        if avgpool:
+            assert lib.caddy_k_conv_avgpool_ok(C.byref(a)) == 1
+            a.avgpool = 1
         if not split:                      # the slab scratch stays untouched when the latency kernel takes the launch
             scr = torch.full((8 * N * H * W * round_up(out_c, 4),), 3.25, device=dev)
             a.split_scratch, a.split_cap = scr.data_ptr(), scr.numel()

@@ -29,6 +29,7 @@ pytestmark = pytest.mark.emu
     dict(N=2, H=42, W=50, segs=[(32, 0)], Cout=24, KS=3, bias=True),           # narrow conv <2,2>, channel tail, bias; dgrad runs <2,2> as 24 -> 32
     dict(N=1, H=64, W=64, segs=[(20, 0)], Cout=16, KS=3),                      # narrow conv <2,1>; dgrad <1,2>; wgrad <2,1>
     dict(N=1, H=65, W=66, segs=[(16, 0)], Cout=29, KS=3),                      # narrow wgrad <1,2>, ragged tiles, channel tail
+    dict(N=2, H=48, W=52, segs=[(12, 0)], Cout=16, KS=3),                      # stacked-frame stem on k_conv_narrow<1,1> (round 5: 5..12 input channels, zero-filled K tail); dgrad / wgrad thin
     dict(N=1, H=16, W=40, segs=[(128, 0)], Cout=3, KS=3, bias=True, act=1),    # FinalBlock at 64x64 scale: dgrad = 3 -> 128 on k_conv_c4<3,4> x 2 groups
     dict(N=2, H=12, W=40, segs=[(3, 0)], Cout=16, KS=7),                       # 7x7 stem shape on k_conv_c4<7,1>
     dict(N=1, H=9, W=33, segs=[(3, 0)], Cout=40, KS=3, bias=True),             # k_conv_c4<3,2>, two output groups, channel tail
@@ -116,6 +117,8 @@ def test_conv_direct_latency_kernel_small():
     K.hx_conv_case(lib, "cpu", N=1, H=9, W=32, segs=[(32, False)], Cout=32, act=2, oscale=True, direct=True, seed=2)
     K.hx_conv_case(lib, "cpu", N=1, H=6, W=16, segs=[(64, False), (5, True), (64, False)], Cout=128, bias=True, act=3, direct=True, seed=3)
     K.hx_conv_case(lib, "cpu", N=1, H=4, W=16, segs=[(128, False), (9, True), (128, False)], Cout=40, bias=True, direct=True, seed=4)      # 81 steps
+    K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(32, False)], Cout=64, bias=True, act=3, oscale=True, direct=True, avgpool=True, seed=5)      # round 5: avg_pool2d(2) in the epilogue
+    K.hx_conv_case(lib, "cpu", N=2, H=6, W=26, segs=[(40, False)], Cout=20, bias=True, act=3, res=True, direct=True, avgpool=True, seed=6)         # ragged 8-pixel groups, tails
 
 
 def test_conv_hx_4x16_tiles_for_inference_small():
@@ -159,6 +162,10 @@ def test_folded_inference_epilogues_small():
     K.conv_case(lib, "cpu", N=2, H=40, W=52, segs=[(16, 0)], Cout=16, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)     # k_conv_narrow
     K.conv_case(lib, "cpu", N=2, H=24, W=24, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False)                      # 1x1 down-sample conv, folded, no activation
     K.conv_case(lib, "cpu", N=1, H=9, W=33, segs=[(12, 0)], Cout=16, KS=3, bias=True, oscale=True, check_bwd=False)                       # stacked-frame stem (thin-in kernel) keeps bias + scale
+    # round 5: avg_pool2d(2) inside k_conv_narrow's epilogue (conv -> pool -> affine -> LeakyReLU of the folded stem / down-sampling residual blocks); ragged tiles, odd pooled width
+    K.conv_case(lib, "cpu", N=2, H=40, W=52, segs=[(12, 0)], Cout=16, KS=3, bias=True, act=3, oscale=True, check_bwd=False, avgpool=True)
+    K.conv_case(lib, "cpu", N=1, H=64, W=66, segs=[(16, 0)], Cout=32, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False, avgpool=True)
+    K.conv_case(lib, "cpu", N=1, H=66, W=64, segs=[(32, 0)], Cout=29, KS=3, check_bwd=False, avgpool=True)
     K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True, act=3, res=True, oscale=True)
     K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(96, False)], Cout=64, bias=True, act=3, res=True, oscale=True, split=True)
 

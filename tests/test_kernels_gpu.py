@@ -124,6 +124,8 @@ def test_conv_hx_forward(lib, kw):
     dict(N=1, H=64, W=64, segs=[(32, False)], Cout=64, bias=True, act=3),                              # one 32-channel chunk: nine steps over four waves
     dict(N=1, H=16, W=16, segs=[(128, False), (9, True), (128, False)], Cout=128, bias=True, act=3),   # R's side branch on the 16x16 map
     dict(N=2, H=20, W=26, segs=[(40, False)], Cout=48, act=2, oscale=True, seed=3),                    # ragged width, tails
+    dict(N=1, H=64, W=64, segs=[(32, False)], Cout=64, bias=True, act=3, oscale=True, avgpool=True),   # round 5: E's second down-sampling block: conv -> avg-pool -> affine -> LeakyReLU in one launch
+    dict(N=2, H=20, W=26, segs=[(40, False)], Cout=48, bias=True, act=3, res=True, avgpool=True, seed=5),   # pooled, ragged 8-pixel groups (pooled width 13), residual at the pooled size
 ])
 def test_conv_direct_latency_kernel(lib, kw):
     """round 4: conv_direct.hip -- the one-launch form of small assigning split-f16 convolutions (batch-1 roll-out layers)"""
@@ -180,6 +182,11 @@ def test_folded_inference_epilogues(lib):
     K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=16, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False)     # k_conv_narrow
     K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False)                      # 1x1 down-sample
     K.conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(12, 0)], Cout=16, KS=3, bias=True, oscale=True, check_bwd=False)                      # stacked-frame stem
+    # round 5: avg_pool2d(2) + bias + LeakyReLU in k_conv_narrow's epilogue: the folded stem and the first down-sampling residual block of a roll-out frame
+    K.conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(12, 0)], Cout=16, KS=3, bias=True, act=3, oscale=True, check_bwd=False, avgpool=True)
+    K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=32, KS=3, bias=True, act=3, oscale=True, check_bwd=False, avgpool=True)
+    K.conv_case(lib, "cuda", N=2, H=66, W=68, segs=[(32, 0)], Cout=29, KS=3, res=True, check_bwd=False, avgpool=True)
+    K.conv_case(lib, "cuda", N=8, H=64, W=64, segs=[(12, 0)], Cout=16, KS=3)                                                                   # the stem's training launch (forward on k_conv_narrow, gradients thin)
     K.hx_conv_case(lib, "cuda", N=1, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=3, res=True, oscale=True, split=True)         # D residual block, slab split-K
     K.hx_conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(64, False)], Cout=32, bias=True, act=3, oscale=True)                               # D last UpBlock
     K.hx_conv_case(lib, "cuda", N=1, H=16, W=16, segs=[(256, False), (12, True)], Cout=128, bias=True, act=3, oscale=True, split=True)       # R's middle block
