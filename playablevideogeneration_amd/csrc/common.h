@@ -204,6 +204,7 @@ int conv_thin_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_thin.hip: 
 int conv_head_fwd_try(const ConvArgs& a, hipStream_t st);     // conv_head.hip: 3-channel image heads (3x3 / 7x7) on the split-f16 matrix pipe (ConvArgs.precision == PREC_F16X3)
 int conv_head_dgrad_try(const ConvArgs& a, hipStream_t st);    // conv_head.hip: dgrad of the 7x7 head (3 -> C channels) on the split-bf16 matrix pipe (ConvArgs.precision == PREC_BF16X3, no wq)
 int conv_hx_avgpool_ok(const ConvArgs& a);
+int conv1x1_lat_try(const ConvArgs& a, hipStream_t st, bool dry = false);   // conv_direct.hip: small 1x1 launches of inference passes (optionally average-pooled)
 int conv_direct_try(const ConvArgs& a, hipStream_t st, bool dry = false);                 // conv_direct.hip: latency-bound 3x3 launches (batch-1 roll-out), called by conv_hx_try
 int conv_stream_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: HBM-bound 1x1 weight gradients, operands straight from global memory into the fp32 MFMA (1 = handled)
 int conv_head_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);      // conv_stream.hip: weight gradient of the 7x7 FinalBlock head on the split-bf16 matrix pipe, taps on the M side (1 = handled)

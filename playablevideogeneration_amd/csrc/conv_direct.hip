@@ -141,7 +141,83 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
     if (co + 4 <= a.Cout) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
     else for (int r = 0; r < 4 && co + r < a.Cout; r++) o[r] = v[r];
 }
+
+// 1x1 convolutions of a batch-1 frame (the residual blocks' down-sampling paths: 16 -> 32 @128x128, 32 -> 64 @64x64, 64 -> 65 @32x32; ~2 - 8 MFLOP): the implicit-GEMM kernel
+// needs 8 - 9 us for them (+ 5 us for the avg-pool behind it).  Four lanes = one output pixel x four output channels, each lane a quarter of the input channels (exact fp32
+// FMAs in channel order, the four partial sums meet through two DPP exchanges in a fixed order); with ConvArgs.avgpool the lanes average the 2x2 input window first (a 1x1
+// convolution commutes with the pooling).  Weights: the packed fp32 rows wp[o][k] (BatchNorm scale folded in).
+__global__ __launch_bounds__(256) void k_conv1x1_lat(ConvArgs a, int C4o, int kspan) {
+    const bool AP = a.avgpool != 0;
+    const int OH = AP ? a.H >> 1 : a.H, OW = AP ? a.W >> 1 : a.W;
+    const long total = (long)a.N * OH * OW * C4o;
+    const long tidx = blockIdx.x * 256L + threadIdx.x;
+    const int kq = (int)(tidx & 3);
+    const bool valid = (tidx >> 2) < total;
+    const long idx = valid ? (tidx >> 2) : 0;       // (every lane of a quad takes part in the exchanges)
+    const int q = (int)(idx % C4o);
+    long pix = idx / C4o;
+    const int n = (int)(pix / ((long)OH * OW));
+    pix -= (long)n * OH * OW;
+    const int y = (int)(pix / OW), x = (int)(pix - (long)y * OW);
+    const ConvSrc s = a.src[0];
+    const float* xp = s.p + (long)n * s.sn + ((long)(AP ? 2 * y : y) * a.W + (AP ? 2 * x : x)) * s.ld;
+    const long dxo = s.ld, dyo = (long)a.W * s.ld;
+    const int co = 4 * q;
+    const float* w0 = a.wp + (long)co * a.Ktot;      // rows co .. co + 3 exist: Cout_pad is a multiple of 32
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int k1 = (kq + 1) * kspan < s.C ? (kq + 1) * kspan : s.C;
+#pragma unroll 4
+    for (int k = kq * kspan; k < k1; k += 4) {
+        float4 v = *reinterpret_cast<const float4*>(xp + k);
+        if (AP) {
+            const float4 b = *reinterpret_cast<const float4*>(xp + dxo + k), c = *reinterpret_cast<const float4*>(xp + dyo + k), d = *reinterpret_cast<const float4*>(xp + dyo + dxo + k);
+            v.x = 0.25f * ((v.x + b.x) + (c.x + d.x)); v.y = 0.25f * ((v.y + b.y) + (c.y + d.y)); v.z = 0.25f * ((v.z + b.z) + (c.z + d.z)); v.w = 0.25f * ((v.w + b.w) + (c.w + d.w));
+        }
+        if (k + 4 > s.C) { if (k + 1 >= s.C) v.y = 0.f; if (k + 2 >= s.C) v.z = 0.f; v.w = 0.f; }      // (channels beyond C are not ours to read as data: zero them)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float4 w = *reinterpret_cast<const float4*>(w0 + (long)r * a.Ktot + k);
+            acc[r] = fmaf(v.x, w.x, acc[r]); acc[r] = fmaf(v.y, w.y, acc[r]); acc[r] = fmaf(v.z, w.z, acc[r]); acc[r] = fmaf(v.w, w.w, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {      // (k-quarter 0 + 1) + (2 + 3): the same order in every lane
+        acc[r] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[r]), 0xB1, 0xF, 0xF, true));      // quad_perm [1, 0, 3, 2]
+        acc[r] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[r]), 0x4E, 0xF, 0xF, true));      // quad_perm [2, 3, 0, 1]
+    }
+    if (!valid || kq != 0) return;
+    const long opix = (long)y * OW + x;
+    float* o = a.out + (long)n * a.out_sn + opix * a.out_ld + co;
+    const float* rp = a.res ? a.res + (long)n * a.res_sn + opix * a.res_ld + co : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (co + r >= a.Cout) break;
+        float t = acc[r] + (a.bias ? a.bias[co + r] : 0.f);
+        if (rp) t += rp[r];
+        if (a.act == 3) t = t > 0.f ? t : 0.2f * t;
+        acc[r] = t;
+    }
+    if (co + 4 <= a.Cout) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else for (int r = 0; r < 4 && co + r < a.Cout; r++) o[r] = acc[r];
+}
 }  // namespace
+
+// 1 = handled: small exact-fp32 1x1 launches of inference passes (ConvArgs.direct_ok); `dry`: shape test only (out need not be set)
+int conv1x1_lat_try(const ConvArgs& a, hipStream_t st, bool dry) {
+    if (a.KS != 1 || a.nsrc != 1 || !a.direct_ok || a.src[0].bcast || a.src[0].bn_scale || (a.act != 0 && a.act != 3) || a.accumulate || a.mask || a.pool_out || a.skip_out || a.stats) return 0;
+    if (a.wq || a.precision != PREC_FP32 || a.splitk > 1 || a.in_s16 || a.out_s16 || !a.wp) return 0;
+    if ((a.src[0].ld & 3) || (a.src[0].sn & 3) || ((uintptr_t)a.src[0].p & 15) || (a.Ktot & 3) || a.src[0].C > 128 || a.src[0].C > a.Ktot) return 0;
+    if (a.avgpool && ((a.H | a.W) & 1)) return 0;
+    const int C4o = cdiv(a.Cout, 4);
+    if (4 * C4o > a.Cout_pad) return 0;
+    const long total = (long)a.N * (a.avgpool ? a.H / 2 : a.H) * (a.avgpool ? a.W / 2 : a.W) * C4o;
+    if (total > 65536) return 0;
+    if (dry) return 1;
+    if ((a.out_ld & 3) || (a.out_sn & 3) || ((uintptr_t)a.out & 15) || (a.res && ((a.res_ld & 3) || (a.res_sn & 3) || ((uintptr_t)a.res & 15)))) return 0;
+    const int kspan = (cdiv(a.src[0].C, 4) + 3) / 4 * 4;      // input channels per lane of a quad (a multiple of 4)
+    hipLaunchKernelGGL(k_conv1x1_lat, dim3((unsigned)cdiv(4 * total, 256)), dim3(256), 0, st, a, C4o, kspan);
+    return 1;
+}
 
 // workgroup-steps up to which re-reading the activations per 16-channel block (no LDS reuse) is cheaper than the tile kernel's launch + slab reduce
 #define DIRECT_MAX_WORK 24576

@@ -784,8 +784,10 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     g_last_conv_stats_tiles = 0;
     if (a.avgpool) {      // pooled epilogue: the caller has asked conv_avgpool_ok() -- the latency kernel for split-operand layers, k_conv_narrow otherwise
         if (a.wq && a.precision >= PREC_F16X3) return conv_hx_try(a, st) == 1 ? 0 : -1;
+        if (a.KS == 1) return conv1x1_lat_try(a, st) == 1 ? 0 : -1;
         return conv_narrow_fwd_try(a, st) == 1 ? 0 : -1;
     }
+    if (a.KS == 1 && a.direct_ok && conv1x1_lat_try(a, st) == 1) { g_last_conv_kernel = CK_FWD_128x32; return 0; }      // tiny 1x1 launches of a roll-out frame
     { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
     for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs are understood by k_conv_hx only: the caller must have materialised them
     if (a.pool_out || a.skip_out) return -1;      // fused max-pool / write-less epilogues exist in k_conv_hx only: the caller must not ask the other kernels for them

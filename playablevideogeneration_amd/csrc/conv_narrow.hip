@@ -175,6 +175,7 @@ int conv_narrow_fwd_ok(const ConvArgs& a) { return narrow_shape_ok(a) ? 1 : 0; }
 int conv_avgpool_ok(const ConvArgs& a) {
     if (a.wq && a.precision >= PREC_F16X3) return conv_hx_avgpool_ok(a);      // a split-operand layer: conv_fwd_launch tries k_conv_hx's launcher first (conv_direct.hip has the pooled epilogue)
     ConvArgs b = a; b.avgpool = 1; b.splitk = 1;
+    if (a.KS == 1) return conv1x1_lat_try(b, nullptr, true);
     return narrow_shape_ok(b) ? 1 : 0;
 }
 

@@ -524,8 +524,9 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     a.nsrc = nseg; a.N = N; a.H = H; a.W = W; a.KS = L.pd.KS; a.wp = L.wp; a.Ktot = L.pd.Ktot; a.Cout = L.pd.Cout; a.Cout_pad = L.pd.Cout_pad;
     a.bias = (fold && L.fold_bn) ? L.fold_bias : L.bias; a.act = actf;
     const bool range_ok = !layer_fallback[L.flag_idx];      // (a layer that reported |x| > 65504 stays on the exact-fp32 forward: caddy_f16_saturated)
-    if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; a.direct_ok = training ? 0 : 1; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
+    if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
     else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32 && range_ok) { a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
+    a.direct_ok = training ? 0 : 1;      // latency kernels (conv_direct.hip): inference passes only -- a training launch is 8 x larger and its summation order is what the parity bounds were calibrated on
     bool pooled = false;
     if (pool_fuse) {      // conv_pool(): the 2x2 average (+ LeakyReLU) goes into the epilogue when the launch has one for it
         a.act = pool_fuse == 2 ? 3 : 0;
@@ -764,8 +765,7 @@ T4 caddy_ctx::resblock(ResL& R, const T4& x, const T4* into, bool nz2_out) {
         T4 a1 = R.ds == 2 ? conv_pool(R.conv1, &sx, 1, true) : conv(R.conv1, &sx, 1, 3, nullptr);
         Seg sa{a1, 0, true};
         if (!R.has_down) return conv(R.conv2, &sa, 1, 3, into, false, &x);
-        T4 idn = conv(R.down, &sx, 1, 0, nullptr);
-        if (R.ds == 2) idn = pool2(idn);
+        T4 idn = R.ds == 2 ? conv_pool(R.down, &sx, 1, false) : conv(R.down, &sx, 1, 0, nullptr);
         return conv(R.conv2, &sa, 1, 3, into, false, &idn);
     }
     want_stats = R.ds == 1;                                   // (a pooled map's statistics are not the conv output's)

@@ -43,7 +43,7 @@ static constexpr size_t STACK = 256 * 1024;
 static constexpr int MAXT = 1024;
 
 struct WaveState { uint64_t slot[64]; float A[64], B[64]; float big[64 * 16]; int arrived; unsigned gen; int nlanes;
-                   uint32_t dppv[64][2]; unsigned long dppseq[64]; };      // DPP mailboxes: pairwise, usable under divergence (only the lanes of a quad must agree)
+                   uint32_t dppv[64][8]; unsigned long dppseq[64]; };      // DPP mailboxes (8 posts deep: a lane that alternates partners inside its quad runs up to two exchanges ahead of a partner that has not read yet), usable under divergence
 struct BlockState { int nthreads; int arrived; unsigned gen; WaveState waves[MAXT / 64]; };
 static thread_local BlockState t_blk;
 static thread_local void* t_sched_sp;
@@ -89,12 +89,12 @@ uint32_t dpp_exchange(uint32_t v, int src_lane) {
     WaveState& w = t_blk.waves[t_cur->lin >> 6];
     const int me = t_cur->lin & 63;
     const unsigned long s = w.dppseq[me];
-    w.dppv[me][s & 1] = v;
+    w.dppv[me][s & 7] = v;
     w.dppseq[me] = s + 1;
     t_progress++;
     if (src_lane == me || src_lane < 0 || src_lane >= w.nlanes) return v;
     while (w.dppseq[src_lane] <= s) yield();
-    return w.dppv[src_lane][s & 1];
+    return w.dppv[src_lane][s & 7];
 }
 void wave_gather2(float a, float b, float* A64, float* B64) {
     WaveState& w = t_blk.waves[t_cur->lin >> 6];

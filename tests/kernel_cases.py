@@ -60,7 +60,7 @@ def make_pack(ws, segs, KS, lib):
 
 
 def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, seed=0, check_bwd=True, tol=2e-5, precision=0, use_aux=True, wgrad_precision=0, wgrad_tol=None,
-              res=False, oscale=False, dgrad_precision=None, dgrad_tol=None, avgpool=False):
+              res=False, oscale=False, dgrad_precision=None, dgrad_tol=None, avgpool=False, direct_ok=False):
     """segs: list of (C, bcast).  Checks forward, dgrad (per spatial segment), wgrad against torch autograd.
     dgrad_precision = 17: ConvArgs.precision of the dgrad launches (split bf16: conv_head.hip's 7x7 head dgrad).
     avgpool: ConvArgs.avgpool -- the launch writes avg_pool2d(conv, 2) with bias / residual / activation applied after the pooling (forward only)."""
@@ -132,6 +132,7 @@ def conv_case(lib, dev, *, N, H, W, segs, Cout, KS, nw=1, bias=False, act=0, see
     if res:
         r_d = nhwc(r_in, ld=round_up(Cout, 4) + 8, dev=dev)
         a.res, a.res_sn, a.res_ld = r_d.data_ptr(), OH * OW * r_d.shape[3], r_d.shape[3]
+    a.direct_ok = 1 if direct_ok else 0          # inference launch: the latency kernels of conv_direct.hip may take it
     if avgpool:
         assert lib.caddy_k_conv_avgpool_ok(C.byref(a)) == 1
         a.avgpool = 1

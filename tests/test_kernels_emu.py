@@ -166,6 +166,10 @@ def test_folded_inference_epilogues_small():
     K.conv_case(lib, "cpu", N=2, H=40, W=52, segs=[(12, 0)], Cout=16, KS=3, bias=True, act=3, oscale=True, check_bwd=False, avgpool=True)
     K.conv_case(lib, "cpu", N=1, H=64, W=66, segs=[(16, 0)], Cout=32, KS=3, bias=True, act=3, res=True, oscale=True, check_bwd=False, avgpool=True)
     K.conv_case(lib, "cpu", N=1, H=66, W=64, segs=[(32, 0)], Cout=29, KS=3, check_bwd=False, avgpool=True)
+    # latency 1x1 kernel of inference passes (k_conv1x1_lat): plain, average-pooled (the down-sampling paths), channel tails on both sides
+    K.conv_case(lib, "cpu", N=1, H=12, W=20, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False, direct_ok=True, avgpool=True)
+    K.conv_case(lib, "cpu", N=2, H=9, W=11, segs=[(64, 0)], Cout=65, KS=1, bias=True, oscale=True, check_bwd=False, direct_ok=True)
+    K.conv_case(lib, "cpu", N=1, H=8, W=10, segs=[(30, 0)], Cout=19, KS=1, act=3, res=True, check_bwd=False, direct_ok=True, avgpool=True)
     K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True, act=3, res=True, oscale=True)
     K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(96, False)], Cout=64, bias=True, act=3, res=True, oscale=True, split=True)
 

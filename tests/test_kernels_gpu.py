@@ -187,6 +187,11 @@ def test_folded_inference_epilogues(lib):
     K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=32, KS=3, bias=True, act=3, oscale=True, check_bwd=False, avgpool=True)
     K.conv_case(lib, "cuda", N=2, H=66, W=68, segs=[(32, 0)], Cout=29, KS=3, res=True, check_bwd=False, avgpool=True)
     K.conv_case(lib, "cuda", N=8, H=64, W=64, segs=[(12, 0)], Cout=16, KS=3)                                                                   # the stem's training launch (forward on k_conv_narrow, gradients thin)
+    # the down-sampling paths' 1x1 convolutions on the latency kernel (k_conv1x1_lat), average-pooled where the block down-samples
+    K.conv_case(lib, "cuda", N=1, H=128, W=128, segs=[(16, 0)], Cout=32, KS=1, bias=True, oscale=True, check_bwd=False, direct_ok=True, avgpool=True)
+    K.conv_case(lib, "cuda", N=1, H=64, W=64, segs=[(32, 0)], Cout=64, KS=1, bias=True, oscale=True, check_bwd=False, direct_ok=True, avgpool=True)
+    K.conv_case(lib, "cuda", N=1, H=32, W=32, segs=[(64, 0)], Cout=65, KS=1, bias=True, oscale=True, check_bwd=False, direct_ok=True)
+    K.conv_case(lib, "cuda", N=2, H=18, W=22, segs=[(30, 0)], Cout=19, KS=1, act=3, res=True, check_bwd=False, direct_ok=True, avgpool=True)
     K.hx_conv_case(lib, "cuda", N=1, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=3, res=True, oscale=True, split=True)         # D residual block, slab split-K
     K.hx_conv_case(lib, "cuda", N=1, H=256, W=256, segs=[(64, False)], Cout=32, bias=True, act=3, oscale=True)                               # D last UpBlock
     K.hx_conv_case(lib, "cuda", N=1, H=16, W=16, segs=[(256, False), (12, True)], Cout=128, bias=True, act=3, oscale=True, split=True)       # R's middle block
