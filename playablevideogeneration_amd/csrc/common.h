@@ -189,7 +189,7 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t st);
 int conv_pick_bn(int cout);
 struct PackDesc;
 int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry = false);
-int conv_hx_try(const ConvArgs& a, hipStream_t st);
+int conv_hx_try(const ConvArgs& a, hipStream_t st, bool dry = false);      // dry: 1 = the launch would run here (nothing is launched)
 bool conv_hx_s16_ok(int N, int H, int W, int Cout);       // ... on a tile variant that reads / writes S16 tensors (ConvArgs.in_s16 / out_s16)?  (the same two well-filled variants)
 bool conv_hx_pool_ok(int N, int H, int W, int Cout);      // will conv_hx_try run this geometry on a tile variant with the fused max-pool epilogue?           // conv_hx.hip: 3x3 on the 16-bit MFMA with split operands (1 = handled)
 int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward form, else dgrad form of that input segment */, int precision, hipStream_t st);
@@ -197,6 +197,8 @@ size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
 extern int g_hx_big_override;
+int conv_split_reduce_pool_launch(const float* scr, long stride, int splits, int ldc, int N, int H, int W, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
+                                  const float* res, long res_sn, int res_ld, hipStream_t st);      // slab reduce + avg_pool2d(2) (+ bias / residual / activation at the pooled size)
 int conv_split_reduce_lstm_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, const float* bias, const LstmFuse& f, hipStream_t st);
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
                              const float* res, long res_sn, int res_ld, hipStream_t st, float* stats = nullptr, int stats_ld = 0, long stats_cap_tiles = 0, int accumulate = 0);

@@ -65,18 +65,17 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
     unsigned amax = 0u;                                      // largest staged magnitude as a bit pattern (NaN > inf > finite): f16 range guard, see conv_hx.hip
     for (int chunk = 0; chunk < nchunks; chunk++) {
         if (chunk > 0) __syncthreads();                     // every wave is done with the previous chunk's image and weights
-        // ---- weights of this chunk: packed fp32 [tap][Cout_pad][Ktot] -> split f16 (x 64: see HX_WSCALE), rows 0..2 + the zero row ----
-        for (int i = tid; i < TAPS * 4 * (HD_KC / 4); i += NT) {
-            const int q = i % (HD_KC / 4), rr = (i / (HD_KC / 4)) & 3, tap = i / (HD_KC / 4) / 4;
-            const int k = chunk * HD_KC + 4 * q;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < a.Cout && k < a.Ktot) w = *reinterpret_cast<const float4*>(a.wp + ((long)tap * a.Cout_pad + rr) * a.Ktot + k);
-            const float wv[4] = {w.x * HX_WSCALE, w.y * HX_WSCALE, w.z * HX_WSCALE, w.w * HX_WSCALE};
-            h4 hi, lo;
+        // ---- weights of this chunk: packed fp32 [tap][Cout_pad][Ktot] -> split f16 (x 64: see HX_WSCALE), rows 0..2 + the zero row.  All loads of a thread are issued before the
+        //      halo loads below and converted after them (round 5: a loop of load -> convert -> store cost a batch-1 frame's workgroups 7 dependent round trips) ----
+        constexpr int NWI = TAPS * 4 * (HD_KC / 4), NWL = (NWI + NT - 1) / NT;
+        float4 wreg[NWL];
 #pragma unroll
-            for (int e = 0; e < 4; e++) { hi[e] = (_Float16)wv[e]; lo[e] = (_Float16)(wv[e] - (float)hi[e]); }
-            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + 4 * q]) = hi;
-            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + HD_KC + 4 * q]) = lo;
+        for (int j = 0; j < NWL; j++) {
+            const int i = tid + NT * j;
+            const int q_ = i % (HD_KC / 4), rr = (i / (HD_KC / 4)) & 3, tap = i / (HD_KC / 4) / 4;
+            const int k = chunk * HD_KC + 4 * q_;
+            const bool okw = i < NWI && rr < a.Cout && k < a.Ktot;
+            wreg[j] = *reinterpret_cast<const float4*>(a.wp + (okw ? ((long)tap * a.Cout_pad + rr) * a.Ktot + k : 0L));
         }
         // ---- halo image of this chunk: thread = (pixel, channel quad q of 8); all loads of a thread are issued before the first conversion (clamped addresses, no branch
         //      around a load: a loop of load -> convert -> store leaves one load in flight per thread) ----
@@ -92,6 +91,19 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
             const int y = y0 - R + hy, x = x0 - R + hx;
             const bool ok = cok && p < HPX && y >= 0 && y < a.H && x >= 0 && x < a.W;
             ld[i] = *reinterpret_cast<const float4*>(base + (ok ? ((long)y * a.W + x) * s.ld : 0L));
+        }
+#pragma unroll
+        for (int j = 0; j < NWL; j++) {
+            const int i = tid + NT * j;
+            if (NWL * NT > NWI && i >= NWI) continue;
+            const int q_ = i % (HD_KC / 4), rr = (i / (HD_KC / 4)) & 3, tap = i / (HD_KC / 4) / 4;
+            const bool okw = rr < a.Cout && chunk * HD_KC + 4 * q_ < a.Ktot;
+            const float wv[4] = {okw ? wreg[j].x * HX_WSCALE : 0.f, okw ? wreg[j].y * HX_WSCALE : 0.f, okw ? wreg[j].z * HX_WSCALE : 0.f, okw ? wreg[j].w * HX_WSCALE : 0.f};
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { hi[e] = (_Float16)wv[e]; lo[e] = (_Float16)(wv[e] - (float)hi[e]); }
+            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + 4 * q_]) = hi;
+            *reinterpret_cast<h4*>(&Wl[(tap * 4 + rr) * WROW + HD_KC + 4 * q_]) = lo;
         }
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bn && cok) { sc = *reinterpret_cast<const float4*>(s.bn_scale + c); sh = *reinterpret_cast<const float4*>(s.bn_shift + c); }
@@ -272,6 +284,11 @@ int conv_head_fwd_try(const ConvArgs& a, hipStream_t st) {
     if (a.src[0].C < 16 || (a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.src[0].C & 3) || (a.Ktot & 3)) return 0;
     if (a.KS == 7) {
         const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 16);
+        if ((long)a.N * tx * ty < 200) {      // a batch-1 frame: 128 workgroups of 16 x 32 pixels leave half the chip idle -- 8 x 32 tiles (2.0 x halo instead of 1.6 x, but twice the workgroups and a
+                                              // chain half as long per workgroup: 22.4 -> 15 us per frame at 256 x 256)
+            const int ty8 = cdiv(a.H, 8);
+            hipLaunchKernelGGL((k_conv_head<7, 8, 32, 4>), dim3((unsigned)((long)a.N * tx * ty8)), dim3(256), 0, st, a, tx, ty8);
+        } else
         hipLaunchKernelGGL((k_conv_head<7, 16, 32, 8>), dim3((unsigned)((long)a.N * tx * ty)), dim3(512), 0, st, a, tx, ty);
     } else {
         const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 8);

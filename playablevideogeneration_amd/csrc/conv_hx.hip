@@ -582,18 +582,15 @@ bool conv_src_lazy_ok(const ConvArgs& a) {
 thread_local int g_last_conv_stats_tiles = 0;
 thread_local int g_last_conv_direct = 0;
 
-// would an average-pooled launch (ConvArgs.avgpool) of this split-f16 layer run (on the latency kernel)?  `out` need not be set.
+// would an average-pooled launch (ConvArgs.avgpool) of this split-f16 layer run here (latency kernel, or K-split tile launch + pooling slab reduce)?  `out` need not be set.
 int conv_hx_avgpool_ok(const ConvArgs& a0) {
     ConvArgs a = a0;
-    if (a.KS != 3 || !a.wq || a.precision != PREC_F16X3 || !a.direct_ok || a.act == 1) return 0;
-    int kq = 0;
-    for (int s = 0; s < a.nsrc; s++) { if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return 0; kq += round_up(a.src[s].C, HX_KC); }
-    a.Kq = kq; a.Cout_pad = round_up(a.Cout, hx_pick_bn(a.Cout)); a.avgpool = 1;
-    return conv_direct_try(a, nullptr, true) == 1 ? 1 : 0;
+    a.avgpool = 1;
+    return conv_hx_try(a, nullptr, true) == 1 ? 1 : 0;
 }
 
 // 1 = handled.  Requirements: 3x3, split weights present (a.wq, packed for a.precision with rows padded to hx_pick_bn(Cout)).
-int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
+int conv_hx_try(const ConvArgs& a0, hipStream_t st, bool dry) {
     ConvArgs a = a0;
     if (a.KS != 3 || !a.wq || a.precision < PREC_F16X3 || a.precision > PREC_BF16X1 || a.act == 1) return 0;      // (tanh: FinalBlocks, 3 output channels -- never an hx layer)
     int kq = 0;
@@ -604,10 +601,12 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     a.Cout_pad = round_up(a.Cout, bn);      // (row padding of the packed weights: independent of the tile width chosen below)
     if (a.mask && a.accumulate) return -1;
     if (a.pool_out && (a.accumulate || a.mask)) return -1;
-    if (a.avgpool) {      // average-pooled epilogue: the latency kernel only (the caller asked conv_avgpool_ok)
-        if (!(a.direct_ok && conv_direct_try(a, st) == 1)) return -1;
-        g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1;
-        return 1;
+    if (a.avgpool) {      // average-pooled result (the caller asked conv_avgpool_ok): the latency kernel's pooled epilogue, or -- below -- a K-split launch whose slab reduce pools
+        if ((a.H | a.W) & 1 || a.accumulate || a.mask || a.pool_out || a.skip_out || a.stats || a.lstm || a.precision != PREC_F16X3 || a.in_s16 || a.out_s16) return dry ? 0 : -1;
+        if (a.direct_ok && conv_direct_try(a, st, dry) == 1) {
+            if (!dry) { g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1; }
+            return 1;
+        }
     }
     if ((long)a.H * a.W * a.out_ld >= (1L << 30) || (a.res && (long)a.H * a.W * a.res_ld >= (1L << 30))) return 0;      // (the epilogue addresses one sample with 32-bit byte offsets)
     const int nchunks = kq / HX_KC;
@@ -639,7 +638,7 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     // launches use the caller's slab scratch + the fixed-order k_split_reduce (bit-reproducible forward), as k_conv_fwd does.
     // latency-bound assigning launches (batch-1 roll-out): one launch without slabs on conv_direct.hip
     g_last_conv_direct = 0;
-    if (a.direct_ok && blocks < 200 && conv_direct_try(a, st) == 1) { g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1; return 1; }
+    if (!dry && !a.avgpool && a.direct_ok && blocks < 200 && conv_direct_try(a, st) == 1) { g_last_conv_kernel = CK_HX_32; g_last_conv_stats_tiles = 0; g_last_conv_direct = 1; return 1; }
     a.splitk = 1; a.split_stride = 0;
     bool det_accum = false;
     float* real_out = a.out; long real_sn = a.out_sn; int real_ld = a.out_ld; const float* real_bias = a.bias; const int real_act = a.act;
@@ -681,6 +680,8 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
         else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty); \
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);                  \
     } while (0)
+    if (a.avgpool && !a.split_stride) return dry ? 0 : -1;      // (a whole-K tile launch has no pooled epilogue)
+    if (dry) return 1;
     const bool vgg_bwd = a.mask != nullptr;      // ReLU mask / L1 seed epilogue (VGG19 dgrad chain): split-bf16 instances with EP = 2
     const int io = (a.in_s16 ? 1 : 0) | ((a.out_s16 || a.pool_s16) ? 2 : 0);
     if (io) {      // S16 tensors at the boundary: the two well-filled tile variants only (conv_hx_s16_ok), whole-K workgroups, plain or VGG19 epilogues
@@ -733,6 +734,8 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st) {
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);
     if (a.split_stride && a.lstm && !det_accum && real_act == 0 && !real_res && !stats_req && a.Cout == 4 * a.lstm->C && (a.lstm->C & 3) == 0 && (a.out_ld & 3) == 0)
         conv_split_reduce_lstm_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, real_bias, *a.lstm, st);      // roll-out ConvLSTM cell: the reduce applies the cell update
+    else if (a.split_stride && a.avgpool)
+        conv_split_reduce_pool_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.N, a.H, a.W, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st);
     else if (a.split_stride) conv_split_reduce_launch(a.split_scratch, a.split_stride, a.splitk, a.out_ld, a.H * a.W, P, a.Cout, real_out, real_sn, real_ld, real_bias, real_act, real_res, a.res_sn, a.res_ld, st,
                                                  stats_req, stats_req_ld, stats_cap, det_accum ? 1 : 0);
     return 1;

@@ -353,6 +353,40 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* scr, long str
     }
 }
 
+// ... followed by avg_pool2d(2) (ConvArgs.avgpool of a K-split launch: the roll-out's conv -> pool -> affine -> LeakyReLU chains): one thread = one POOLED (pixel, channel quad);
+// the four pixels of its window are each summed over the slabs in slab order, then averaged; bias / residual / activation at the pooled size
+__global__ __launch_bounds__(256) void k_split_reduce_pool(const float* scr, long stride, int splits, int ldc, int N, int H, int W, int C, float* out, long out_sn, int out_ld,
+                                                           const float* bias, int act, const float* res, long res_sn, int res_ld) {
+    const int C4 = ldc >> 2, OH = H >> 1, OW = W >> 1;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C4; const int c = (int)(i - p * C4) * 4;
+        const int n = (int)(p / ((long)OH * OW)); p -= (long)n * OH * OW;
+        const int y = (int)(p / OW), x = (int)(p - (long)y * OW);
+        float4 s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float* q = scr + (((long)n * H + 2 * y + (j >> 1)) * W + 2 * x + (j & 1)) * ldc + c;
+            float4 v = *reinterpret_cast<const float4*>(q);
+            for (int z = 1; z < splits; z++) { const float4 w = *reinterpret_cast<const float4*>(q + z * stride); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+            s4[j] = v;
+        }
+        float4 v;
+        v.x = 0.25f * ((s4[0].x + s4[1].x) + (s4[2].x + s4[3].x)); v.y = 0.25f * ((s4[0].y + s4[1].y) + (s4[2].y + s4[3].y));
+        v.z = 0.25f * ((s4[0].z + s4[1].z) + (s4[2].z + s4[3].z)); v.w = 0.25f * ((s4[0].w + s4[1].w) + (s4[2].w + s4[3].w));
+        if (bias) { v.x += bias[c < C ? c : 0]; v.y += bias[c + 1 < C ? c + 1 : 0]; v.z += bias[c + 2 < C ? c + 2 : 0]; v.w += bias[c + 3 < C ? c + 3 : 0]; }
+        const long opix = (long)y * OW + x;
+        if (res) {
+            const float* rp = res + n * res_sn + opix * (long)res_ld + c;
+            v.x += rp[0]; if (c + 1 < C) v.y += rp[1]; if (c + 2 < C) v.z += rp[2]; if (c + 3 < C) v.w += rp[3];
+        }
+        if (act == 3) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
+        float* o = out + n * out_sn + opix * (long)out_ld + c;
+        if (c + 4 <= C) *reinterpret_cast<float4*>(o) = v;
+        else { if (c < C) o[0] = v.x; if (c + 1 < C) o[1] = v.y; if (c + 2 < C) o[2] = v.z; }
+    }
+}
+
 // the same for the gate convolution of a roll-out ConvLSTM cell (ConvArgs.lstm): the four gate quads of (pixel, channel quad) are summed over the slabs in the same fixed
 // order, then the cell update of k_map<FLstmFwd> is applied in place -- same expressions (results within 2 ulp: fma contraction) -- and the gate tensor itself is never written (only a backward pass
 // would read it).  One launch instead of k_split_reduce + the point-wise kernel.
@@ -853,6 +887,13 @@ int conv_split_reduce_lstm_launch(const float* scr, long stride, int splits, int
     const long thr = P * f.C;      // four lanes per (pixel, channel quad)
     hipLaunchKernelGGL(k_split_reduce_lstm, dim3((unsigned)(thr < 256L * 1024 ? cdiv(thr, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, HW, P, bias, f);
     g_last_conv_lstm_fused = 1;
+    return 0;
+}
+int conv_split_reduce_pool_launch(const float* scr, long stride, int splits, int ldc, int N, int H, int W, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
+                                  const float* res, long res_sn, int res_ld, hipStream_t st) {
+    const long items = (long)N * (H / 2) * (W / 2) * (ldc >> 2);
+    hipLaunchKernelGGL(k_split_reduce_pool, dim3((unsigned)(items < 256L * 1024 ? cdiv(items, 256) : 1024)), dim3(256), 0, st, scr, stride, splits, ldc, N, H, W, C, out, out_sn, out_ld, bias, act,
+                       res, res_sn, res_ld);
     return 0;
 }
 int conv_split_reduce_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, int C, float* out, long out_sn, int out_ld, const float* bias, int act,

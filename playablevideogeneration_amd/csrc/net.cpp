@@ -526,6 +526,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     const bool range_ok = !layer_fallback[L.flag_idx];      // (a layer that reported |x| > 65504 stays on the exact-fp32 forward: caddy_f16_saturated)
     if (L.wq && prec_fwd != PREC_FP32 && range_ok) { a.wq = L.wq; a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // (latency kernel: inference only -- training launches are 8 x larger or carry statistics epilogues, and their parity bounds were calibrated on the tile kernel's summation order)
     else if (L.pd.Cout <= 3 && L.pd.KS >= 3 && prec_fwd != PREC_FP32 && range_ok) { a.precision = PREC_F16X3; a.sat_flag = sat_flag + L.flag_idx; }      // FinalBlock heads: split f16 on conv_head.hip (weights split in the kernel)
+    a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
     a.direct_ok = training ? 0 : 1;      // latency kernels (conv_direct.hip): inference passes only -- a training launch is 8 x larger and its summation order is what the parity bounds were calibrated on
     bool pooled = false;
     if (pool_fuse) {      // conv_pool(): the 2x2 average (+ LeakyReLU) goes into the epilogue when the launch has one for it
@@ -536,7 +537,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     T4 out = into ? *into : (pooled ? alloc(N, H / 2, W / 2, L.pd.Cout) : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout)));
     a.out = out.d;
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
-    a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0; a.aux = conv_aux; a.split_scratch = conv_split; a.split_cap = conv_split_cap;
+    a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0;
     g_last_conv_lstm_fused = 0;
     if (lstm_fuse) { a.lstm = lstm_fuse; lstm_fuse = nullptr; }      // (set by lstm_step for the gate convolution of a roll-out cell)
     for (int s = 0; s < nseg; s++)
@@ -859,8 +860,8 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
 T4 caddy_ctx::dynamics(const T4& state, const T4& aux, const T4* into) {
     T4 x = lstm_step(0, state, aux, &r_c0);
     Seg s0[2] = {{x, 0, true}, {aux, 1, true}};
-    x = conv(r_c0, s0, 2, 0, nullptr, true);
-    x = pool2(x, fold);
+    if (fold) x = conv_pool(r_c0, s0, 2, true);      // (K-split launch: its slab reduce pools)
+    else { x = conv(r_c0, s0, 2, 0, nullptr, true); x = pool2(x, false); }
     if (!fold) x = bn_act(x, r_bn0, nullptr, nullptr, true, nullptr, true, false, &lstm[1].gates);      // -> ConvLSTM 1 gates conv only
     x = lstm_step(1, x, aux, &r_c1);
     Seg s1[2] = {{x, 0, true}, {aux, 1, true}};

@@ -119,6 +119,7 @@ def test_conv_direct_latency_kernel_small():
     K.hx_conv_case(lib, "cpu", N=1, H=4, W=16, segs=[(128, False), (9, True), (128, False)], Cout=40, bias=True, direct=True, seed=4)      # 81 steps
     K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(32, False)], Cout=64, bias=True, act=3, oscale=True, direct=True, avgpool=True, seed=5)      # round 5: avg_pool2d(2) in the epilogue
     K.hx_conv_case(lib, "cpu", N=2, H=6, W=26, segs=[(40, False)], Cout=20, bias=True, act=3, res=True, direct=True, avgpool=True, seed=6)         # ragged 8-pixel groups, tails
+    K.hx_conv_case(lib, "cpu", N=1, H=16, W=48, segs=[(128, False), (9, True)], Cout=200, bias=True, act=3, direct="tile4", split=True, avgpool=True, seed=7)      # too large for the latency kernel: K-split tile launch, the slab reduce pools
 
 
 def test_conv_hx_4x16_tiles_for_inference_small():

@@ -142,6 +142,8 @@ def test_lstm_cell_update_in_the_slab_reduce(lib):
     dict(N=1, H=128, W=128, segs=[(64, False)], Cout=64, bias=True, act=3),                  # D's 128x128 layers of a roll-out frame: 256 workgroups of 4x16 pixels, no K split
     dict(N=1, H=126, W=120, segs=[(128, False)], Cout=64, bias=True, act=3, res=True, seed=1),      # ragged rows / columns, 36 steps
     dict(N=1, H=64, W=64, segs=[(128, False)], Cout=128, bias=True, act=3, split=True, seed=2),      # still under-filled on 4x16 tiles: K split into slabs + fixed-order reduce
+    dict(N=1, H=32, W=32, segs=[(128, False), (12, True)], Cout=256, bias=True, act=3, split=True, avgpool=True, oscale=True, seed=3),      # round 5: R's first block of a roll-out frame -- the slab reduce of the K-split launch also pools
+    dict(N=1, H=18, W=52, segs=[(160, False)], Cout=200, bias=True, act=3, res=True, split=True, avgpool=True, seed=4),
 ])
 def test_conv_hx_4x16_tiles_for_inference(lib, kw):
     """round 4: inference launches too large for the latency kernel whose 8x16 grid would be split over K run on 4x16-pixel tiles instead (no slab reduce)"""
