@@ -175,47 +175,53 @@ __global__ void k_head_bwd1(HeadBufs h, HeadParams p, SampleCfg c, int NS, int f
     }
 }
 // ---- phase 2: per (b, t): fold pred/succ grads, abs, FC backward -> d_feat + FC weight grads ------------------------
-__global__ void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= B * T) return;
+// (round 5: one thread per (sample, feature) instead of per sample, one wave per parameter instead of one thread: the two launches were 86 + 92 us of serial loops on 2 - 4
+//  workgroups, twice per step on the BPTT chain)
+__global__ __launch_bounds__(256) void k_head_bwd2(HeadBufs h, HeadParams p, int B, int T) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)B * T * p.F) return;
+    const int n = (int)(idx / p.F), k = (int)(idx - (long)n * p.F);
     const int Da = p.Da;
-    int b = n / T, t = n - b * T;
-    float gm[8], gr[8];
+    const int b = n / T, t = n - b * T;
+    float acc = 0.f;
     for (int d = 0; d < Da; d++) {
         float gmu = h.d_sdist[(long)n * 2 * Da + d], gvar = h.d_sdist[(long)n * 2 * Da + Da + d];
         if (t >= 1) { int m = b * (T - 1) + t - 1; gmu += h.g_dmu[m * Da + d]; gvar += h.g_dvar[m * Da + d]; }
         if (t < T - 1) { int m = b * (T - 1) + t; gmu -= h.g_dmu[m * Da + d]; gvar += h.g_dvar[m * Da + d]; }
-        float raw = h.raw[n * Da + d];
-        gm[d] = gmu;
-        gr[d] = gvar * (raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f));
+        const float raw = h.raw[n * Da + d];
+        const float gr = gvar * (raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f));
+        if (k == 0) { h.g_mu[n * Da + d] = gmu; h.g_raw[n * Da + d] = gr; }
+        acc += p.Wm[d * p.F + k] * gmu + p.Wv[d * p.F + k] * gr;
     }
-    float* df = h.d_feat + (long)n * p.F;
-    for (int d = 0; d < Da; d++) { h.g_mu[n * Da + d] = gm[d]; h.g_raw[n * Da + d] = gr[d]; }
-    for (int k = 0; k < p.F; k++) {
-        float acc = 0.f;
-        for (int d = 0; d < Da; d++) acc += p.Wm[d * p.F + k] * gm[d] + p.Wv[d * p.F + k] * gr[d];
-        df[k] = acc;
-    }
+    h.d_feat[(long)n * p.F + k] = acc;
 }
-// FC parameter gradients: one thread per output loops over the samples in order (no atomics: bit-reproducible)
-__global__ void k_head_bwd3(HeadBufs h, HeadParams p, int NBT, int NS) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.Da * p.F) return;
-    int d = i / p.F, k = i - d * p.F;
-    float am = 0.f, av = 0.f;
-    for (int n = 0; n < NBT; n++) { float f = h.feat[(long)n * p.F + k]; am += h.g_mu[n * p.Da + d] * f; av += h.g_raw[n * p.Da + d] * f; }
-    p.dWm[i] += am; p.dWv[i] += av;
+// FC parameter gradients: one wave per output, lane l sums the samples l, l + 64, ... in order, the 64 partial sums meet in a fixed butterfly (no atomics: bit-reproducible)
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// (fp64 partial sums: mean_fc.bias' gradient is a cancelling sum of +-1e-4 terms that ends near 3e-8 on the reference's golden cases -- in fp32 its value is the summation order)
+__global__ __launch_bounds__(256) void k_head_bwd3(HeadBufs h, HeadParams p, int NBT, int NS) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= p.Da * p.F) return;           // (wave-uniform)
+    const int d = i / p.F, k = i - d * p.F;
+    double am = 0.0, av = 0.0;
+    for (int n = lane; n < NBT; n += 64) { const double f = h.feat[(long)n * p.F + k]; am += (double)h.g_mu[n * p.Da + d] * f; av += (double)h.g_raw[n * p.Da + d] * f; }
+    am = wave_sum_fixed(am); av = wave_sum_fixed(av);
+    if (lane == 0) { p.dWm[i] += (float)am; p.dWv[i] += (float)av; }
     if (i < p.Da) {                        // mean_fc / variance_fc biases
-        float bm = 0.f, bv = 0.f;
-        for (int n = 0; n < NBT; n++) { bm += h.g_mu[n * p.Da + i]; bv += h.g_raw[n * p.Da + i]; }
-        p.dbm[i] += bm; p.dbv[i] += bv;
+        double bm = 0.0, bv = 0.0;
+        for (int n = lane; n < NBT; n += 64) { bm += h.g_mu[n * p.Da + i]; bv += h.g_raw[n * p.Da + i]; }
+        bm = wave_sum_fixed(bm); bv = wave_sum_fixed(bv);
+        if (lane == 0) { p.dbm[i] += (float)bm; p.dbv[i] += (float)bv; }
     }
     if (i < p.K * p.Da) {                  // final_fc weight (K, Da) and bias from the d(logits) k_head_bwd1 finalised (K * Da <= 128 <= Da * F)
         const int kk = i / p.Da, dd = i - kk * p.Da;
-        float w = 0.f, b = 0.f;
-        for (int n = 0; n < NS; n++) { const float g = h.d_logits[n * p.K + kk]; w += g * h.dirs[n * p.Da + dd]; b += g; }
-        p.dWf[i] += w;
-        if (dd == 0) p.dbf[kk] += b;
+        double w = 0.0, bsum = 0.0;
+        for (int n = lane; n < NS; n += 64) { const double g = h.d_logits[n * p.K + kk]; w += g * (double)h.dirs[n * p.Da + dd]; bsum += g; }
+        w = wave_sum_fixed(w); bsum = wave_sum_fixed(bsum);
+        if (lane == 0) { p.dWf[i] += (float)w; if (dd == 0) p.dbf[kk] += (float)bsum; }
     }
 }
 
@@ -497,8 +503,8 @@ int head_sample(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int 
 }
 int head_backward(const HeadBufs& h, const HeadParams& p, const SampleCfg& c, int B, int T, int first_call, hipStream_t st) {
     hipLaunchKernelGGL(k_head_bwd1, dim3(cdiv((long)B * (T - 1), 64)), dim3(64), 0, st, h, p, c, B * (T - 1), first_call);
-    hipLaunchKernelGGL(k_head_bwd2, dim3(cdiv((long)B * T, 64)), dim3(64), 0, st, h, p, B, T);
-    hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 64)), dim3(64), 0, st, h, p, B * T, B * (T - 1));
+    hipLaunchKernelGGL(k_head_bwd2, dim3(cdiv((long)B * T * p.F, 256)), dim3(256), 0, st, h, p, B, T);
+    hipLaunchKernelGGL(k_head_bwd3, dim3(cdiv((long)p.Da * p.F, 4)), dim3(256), 0, st, h, p, B * T, B * (T - 1));
     return 0;
 }
 int loss_l1(const TV& gt, const TV& rec, const TV& drec, int f, int t_off, int Tobs, int Trec, float gscale, double* acc, float* gt_out, hipStream_t st) {

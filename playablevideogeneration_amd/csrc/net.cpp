@@ -808,6 +808,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     LstmL& L = lstm[i];
     const int B = x.N;
     bool persistent = !training && !recording && L.h.d == L.ph.d && L.h.d != nullptr;
+    const bool first_step = L.h.d == nullptr;      // h(t-1) = the learned initial state
     T4 hprev, cprev;
     if (L.h.d == nullptr) {   // lazily created from the learned initial state, repeated over the batch
         hprev = alloc(B, L.Hs, L.Ws, L.C); cprev = alloc(B, L.Hs, L.Ws, L.C);
@@ -824,7 +825,8 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
         }
     } else { hprev = L.h; cprev = L.c; }
     Seg sg[3] = {{x, 0, true}, {aux, 1, true}, {hprev, 0, true}};
-    sg[2].off_chain = true;
+    sg[2].off_chain = !first_step;      // (the first step's d(h) is read right behind its cell backward, by the batch sum into the initial state's gradient: off the chain it was enqueued
+                                        //  at that point and waited for -- 0.1 - 0.35 ms of idle main stream per ConvLSTM, profiles/r05_experiments.md)
     T4 hn, cn;
     if (persistent) { hn = L.ph; cn = L.pc; hn.N = B; cn.N = B; } else { hn = alloc(B, L.Hs, L.Ws, L.C); cn = alloc(B, L.Hs, L.Ws, L.C); }
     if (fold) {      // roll-out: the cell's eval-mode BatchNorm is a second output of the cell update; when the gate convolution is split over K its slab reduce applies

@@ -1,5 +1,6 @@
 """Whole-path parity cases (HIP engine vs oracle and vs reference golden vectors), shared by simulator and GPU tests."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -126,6 +127,8 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=True, grad_
         g = eng.grad_view(n).cpu().double()
         s = max(g64.abs().max().item(), 1e-9)
         worst_h, worst_o = max(worst_h, (g - g64).abs().max().item() / s), max(worst_o, (g32 - g64).abs().max().item() / s)
+        if os.environ.get("CADDY_TEST_VERBOSE") and (g - g64).abs().max().item() / s > 0.02:
+            print(f"  grad {n}: err {(g - g64).abs().max().item() / s:.4f} (oracle32 {(g32 - g64).abs().max().item() / s:.4f}), scale {s:.3e}")
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
     assert rel_h <= (max(2 * rel_o, grad_floor) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
