@@ -130,10 +130,12 @@ void make_conv(caddy_ctx* c, ConvL& L, const std::vector<std::string>& wn, const
         L.wpd[s] = (float*)c->persist.alloc((size_t)KS * KS * L.cd_pad[s] * L.kd * 4);
     }
     if (!bias.empty()) { L.bias = PP(c, bias); L.dbias = GP(c, bias); }
-    // split 16-bit operand forms (conv_hx.hip): wide 3x3 layers only -- narrow ones are HBM-bound on their own kernels
-    if (KS == 3 && d.Cin >= 32 && d.Cout >= 32) L.wq = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2));
+    // split 16-bit operand forms (conv_hx.hip): 3x3 layers with >= 16 channels on both sides.  (Round 5: the 16-channel layers too -- a half-filled 32-channel chunk / 16 of 32 tile
+    // columns on the 16-bit pipe still beat the exact-fp32 16x16x4 kernels of conv_narrow.hip, which ran at 28 - 40 % of a 16 x slower pipe: E/R/A/D step -0.6 ms, Breakout-160 -0.4 ms,
+    // roll-out 2598 -> 2618 frames/s in one call.  Layers with fewer channels on a side -- the stems, the heads -- keep their own kernels.)
+    if (KS == 3 && d.Cin >= 16 && d.Cout >= 16) L.wq = c->persist.alloc(hx_weight_bytes(d, -1, round_up(d.Cout, hx_pick_bn(d.Cout)), 2));
     for (int s = 0; s < d.nseg; s++)
-        if (KS == 3 && segC[s] >= 32 && d.Cout >= 32) L.wqd[s] = c->persist.alloc(hx_weight_bytes(d, s, round_up(segC[s], hx_pick_bn(segC[s])), 2));
+        if (KS == 3 && segC[s] >= 16 && d.Cout >= 16) L.wqd[s] = c->persist.alloc(hx_weight_bytes(d, s, round_up(segC[s], hx_pick_bn(segC[s])), 2));
     L.flag_idx = (int)c->convs.size();
     if (L.flag_idx >= CADDY_VGG_FLAG0) { set_error("internal: too many convolution layers for the range-guard flag table"); c->fail = true; L.flag_idx = 0; }
     c->convs.push_back(&L);

@@ -100,6 +100,19 @@ def test_conv_hx_f16_range_guard_small():
     K.hx_saturation_case(load_emu(), "cpu")
 
 
+def test_conv_hx_16_channel_layers_small():
+    """round 5: the split-operand kernels also take the 3x3 layers with 16 channels on a side (E's first residual blocks, D's last stage: half-filled 32-channel chunk, 16 of 32
+    tile columns): forward, dgrad to a 16-channel input, and the weight gradients on k_wgrad_hx"""
+    lib = load_emu()
+    K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(16, False)], Cout=16, bias=True)
+    K.hx_conv_case(lib, "cpu", N=2, H=9, W=17, segs=[(16, False)], Cout=32, act=3, seed=1)
+    K.hx_conv_case(lib, "cpu", N=1, H=10, W=20, segs=[(16, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True, seed=2)
+    K.hx_conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(32, False)], Cout=16, precision=K.PREC_BF16X3, dgrad_seg=0, seed=3)
+    K.conv_case(lib, "cpu", N=2, H=7, W=18, segs=[(16, 0)], Cout=16, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=4)
+    K.conv_case(lib, "cpu", N=1, H=8, W=16, segs=[(16, 0)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=5)
+    K.conv_case(lib, "cpu", N=1, H=6, W=20, segs=[(32, 0)], Cout=16, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=6)
+
+
 def test_conv_hx_narrow_output_tiles_small():
     """64- and 32-channel output tiles on 8x16-pixel tiles (under-filled launches) and their dgrad forms"""
     K.hx_conv_case(load_emu(), "cpu", N=1, H=10, W=20, segs=[(40, False)], Cout=48, bias=True)

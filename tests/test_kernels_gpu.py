@@ -118,6 +118,17 @@ def test_conv_hx_forward(lib, kw):
     K.hx_conv_case(lib, "cuda", **kw)
 
 
+def test_conv_hx_16_channel_layers(lib):
+    """round 5: 3x3 layers with 16 channels on a side on the split-operand kernels (E's first residual blocks on all B x T frames, D's last stage): forward, dgrad, weight gradients"""
+    K.hx_conv_case(lib, "cuda", N=8, H=128, W=128, segs=[(16, False)], Cout=16, bias=True)
+    K.hx_conv_case(lib, "cuda", N=8, H=128, W=128, segs=[(16, False)], Cout=32, act=3, seed=1)
+    K.hx_conv_case(lib, "cuda", N=8, H=128, W=128, segs=[(16, False)], Cout=32, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True, seed=2)
+    K.hx_conv_case(lib, "cuda", N=2, H=66, W=70, segs=[(32, False)], Cout=16, precision=K.PREC_BF16X3, dgrad_seg=0, seed=3)
+    K.conv_case(lib, "cuda", N=8, H=64, W=64, segs=[(16, 0)], Cout=16, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=4)
+    K.conv_case(lib, "cuda", N=4, H=64, W=64, segs=[(16, 0)], Cout=32, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=5)
+    K.conv_case(lib, "cuda", N=2, H=33, W=40, segs=[(32, 0)], Cout=16, KS=3, wgrad_precision=17, wgrad_tol=1e-4, seed=6)
+
+
 @pytest.mark.parametrize("kw", [
     dict(N=1, H=32, W=32, segs=[(64, False)], Cout=64, bias=True, act=3, res=True),                    # E residual block conv of a roll-out frame (BatchNorm folded)
     dict(N=1, H=32, W=32, segs=[(64, False), (9, True)], Cout=65, bias=True),                          # channel tails + broadcast action input

