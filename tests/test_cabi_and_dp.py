@@ -190,7 +190,7 @@ def test_bench_world8_through_the_launch_script_on_the_simulator(tmp_path):
     assert res["value"] == pytest.approx(8 * 1 * 1e3 / res["ms_per_step"])      # whole-job clips/s over all ranks
 
 
-def _trainer_worker(rank, world, port, out, skew=0.0):
+def _trainer_worker(rank, world, port, out, skew=0.0, ens=1):
     import time
     import torch.distributed as dist
     from tests.test_host_api_emu import _config, _make_model
@@ -200,6 +200,10 @@ def _trainer_worker(rank, world, port, out, skew=0.0):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = _config()
     cfg["logging"] = {"save_root_directory": out}
+    if ens > 1:
+        import random
+        cfg["model"]["action_network"]["ensamble_size"] = ens
+        random.seed(1000 + 17 * rank)      # every rank's own draws would differ: rank 0's must win
     m = _make_model(cfg)
     d = O.Dims.from_config(dict(cfg, model=dict(cfg["model"], architecture="model.reduced_model.model")))
     m.load_state_dict(O.make_params(d, seed=7))
@@ -207,13 +211,15 @@ def _trainer_worker(rank, world, port, out, skew=0.0):
     tr = smooth_mi_trainer.trainer(cfg, m, dataset=None, logger=None)
     tr.global_step = 20000
     obs = torch.rand(1, 4, 3, 32, 32, generator=torch.Generator().manual_seed(10 + rank)) * 2 - 1      # each rank: its own shard
-    for i in range(2):
+    members = []
+    for i in range(2 if ens == 1 else 4):
         torch.manual_seed(50 + 7 * rank + i)
         time.sleep(skew * ((rank * 3 + i) % world))      # ranks arrive at the collectives in a different order every step
         tr.compute_losses(m, (obs, None, None, None), 4)
+        members.append(m.last_member)
         time.sleep(skew * ((rank + 2 * i + 1) % world))
         tr.optimizer_step(m)
-    torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone()}, os.path.join(out, f"t{rank}.pt"))
+    torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone(), "members": members}, os.path.join(out, f"t{rank}.pt"))
     dist.barrier()
 
 
@@ -223,6 +229,23 @@ def test_trainer_mirror_is_data_parallel_aware_gloo_world2(tmp_path):
     port = 33500 + os.getpid() % 2000
     mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t0, t1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
+    assert torch.equal(t0["params"], t1["params"]) and torch.equal(t0["centroids"], t1["centroids"])
+
+
+def test_trainer_mirror_ensemble_under_data_parallel_gloo_world2(tmp_path):
+    """ensamble_size = 2 under torch.distributed (round 5): the reference's single process draws ONE action network per forward for all its replicas (model.py:152) -- here rank 0's
+    draw is broadcast.  The ranks seed Python's `random` differently, so without the broadcast they would train different members; with it every step uses the same member on both
+    ranks (both members get drawn over the four steps) and the replicas end bit-identical, per-member Adam state included"""
+    import random
+    import torch.multiprocessing as mp
+    port = 37500 + os.getpid() % 2000
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path), 0.0, 2), nprocs=2, join=True)
+    t0, t1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
+    assert t0["members"] == t1["members"]
+    random.seed(1000)
+    assert t0["members"] == [random.choice(range(2)) for _ in range(4)]       # rank 0's own sequence
+    random.seed(1017)
+    assert t0["members"] != [random.choice(range(2)) for _ in range(4)]       # (rank 1's would have differed: the case tests something)
     assert torch.equal(t0["params"], t1["params"]) and torch.equal(t0["centroids"], t1["centroids"])
 
 
