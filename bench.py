@@ -471,7 +471,7 @@ def run(a, dev, lib=None, backend="nccl"):
         if world == 1 and extra and not getattr(a, "no_plugin", False) and on_gpu:
             # (after the roll-out: the ROCm runtime multiplexes HIP streams onto 4 hardware queues; with this leg's streams -- prefetcher, side, decoder -- still alive
             #  in the process, the roll-out's graph stream shares a queue with one of them and ran at a quarter of its rate.  play.py is its own process.)
-            res["plugin"] = plugin_leg(wl, dev, a.steps, a.warmup, perc)
+            res["plugin"] = plugin_leg(wl, dev, max(a.steps, 12), a.warmup, perc)      # (>= 12 steps: an epoch's fixed costs -- first un-overlapped H2D copy, the last deferred loss read -- are not per-step costs)
             res["plugin"]["vs_engine_step"] = res["plugin"]["ms_per_step"] / ms_step
             log(f"plugin path: {res['plugin']['ms_per_step']:.1f} ms/step ({res['plugin']['vs_engine_step']:.3f} x the engine-level step)")
         if world == 1 and not a.no_cpu_baseline and on_gpu:
