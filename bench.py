@@ -303,13 +303,14 @@ def run(a, dev, lib=None, backend="nccl"):
     loss_w = dict(configs.LOSS_WEIGHTS, perceptual=configs.LOSS_WEIGHTS["perceptual"] if perc else 0.0)
     loss_w_erad = dict(configs.LOSS_WEIGHTS, perceptual=0.0)
     log("parameters initialised")
-    ranks_seen = 1
+    ranks_seen, dp_native = 1, False
     if world > 1:
         # global-batch centroid sums + MI joint matrix (tiny all-reduces) and the bucketed gradient all-reduce (CADDY_DP_OVERLAP=0: one flat all-reduce)
         eng.enable_data_parallel(overlap=os.environ.get("CADDY_DP_OVERLAP", "1") != "0")
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                                # what the communicator really spans (RCCL over xGMI on the GPU box)
         ranks_seen = int(one.item())
+        dp_native = bool(getattr(eng, "_dp_native", False))      # True: the three reductions are issued from C (csrc/dp_rccl.cpp), no Python on the per-step path
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = torch.rand(B, T, 3 * S, H, W, device=dev, generator=gen) * 2 - 1     # each rank owns its shard of the global batch
     step_no = [0]
@@ -454,7 +455,7 @@ def run(a, dev, lib=None, backend="nccl"):
                           "step": "forward_full_model + L1 / VGG19-perceptual / states / KL / MI losses + BPTT backward + grad all-reduce + Adam"
                                   + (" (VGG19: random-init weights)" if perc else
                                      (" (VGG19 perceptual term not applicable: frames below 64x64)" if too_small else " (VGG19 perceptual term DISABLED by --no-perceptual)"))},
-               "loss": losses["total"], "rccl_ranks_seen": ranks_seen,
+               "loss": losses["total"], "rccl_ranks_seen": ranks_seen, "dp_native": dp_native,
                "erad_only": {"ms_per_step": ms_erad, "clips_per_s": world * B * 1e3 / ms_erad, "what": "the same step with perceptual weight 0 and no VGG19 branch: E -> R -> A -> D forward + L1 / states / KL / MI losses + BPTT + Adam"},
                "exact_fp32_ms_per_step": ms_exact,
                "backward": "bit-reproducible (library default since round 5: slabs + fixed-order folds; two backward passes over one forward give bit-identical gradients)",

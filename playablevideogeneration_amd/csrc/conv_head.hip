@@ -170,6 +170,166 @@ __global__ __launch_bounds__(64 * NW) void k_conv_head(ConvArgs a, int tiles_x, 
     }
 }
 
+// ---- 7x7 head forward with the taps on the N side (round 6; model/layers/final_block.py:9-29, rendering_network.py:41) ----
+// k_conv_head<7> above puts the 3 output channels on the 16-row M side of v_mfma_f32_16x16x32_f16: 3 / 16 of every instruction is useful, 147 instructions per 16 pixels, and with
+// one 136-KB workgroup per CU nothing overlaps its staging (93 us alone / 122 us in the step per 8 frames of 256 x 256, for a layer whose HBM time is 9 us -- on the closed-loop
+// chain: D(t)'s frame feeds E(t + 1)).  Here one v_mfma_f32_32x32x16_f16 computes, for 32 consecutive HALO columns p of one image row,
+//       P[(dx, co)][p] += sum_{c in 16 channels} W[dy][dx][co][c] * X[y + dy][p][c]              (M = (dx, co) = 21 of 32 rows, N = 32 halo columns, K = 16 channels of tap row dy)
+// so an output row takes 7 tap rows x (C / 16) K-steps x 3 split products = 42 instructions per 26 output pixels (2.8 x fewer matrix cycles per pixel), and the result is the
+// shift-add  out[y][x][co] = sum_dx P[(dx, co)][x + dx]  of the seven column partials, done through a wave-private LDS tile in the epilogue (the trick k_wgrad_head7 /
+// k_head_dgrad7 use on their sides).  A workgroup owns 8 rows x 26 columns (halo 14 x 32 pixels: every halo column is a useful N column), a wave two output rows: the B fragment of
+// a halo row is read once and used by both rows' tap rows.  The split weight fragments (7 tap rows x K-steps x hi / lo = 112 registers) stay in registers across the tiles of a
+// persistent workgroup; LDS = 56 KB halo (the [k-block][plane][pixel][8 halves] arrays of k_conv_head, k-blocks skewed by 64 B so that the 8-byte staging stores of a wave cover all
+// banks) + 21 KB shift-add tiles: two workgroups per CU, one stages while the other multiplies.  Workgroup -> tile order keeps vertically adjacent tiles (6 of 14 halo rows
+// shared) on one XCD at the same time.  Same arithmetic class as k_conv_head: split f16 (weights x 64), three products, small terms first, fp32 accumulation.
+template <int NS>      // K-steps of 16 channels: 1 (C <= 16: the reduced model's head) or 2
+__global__ __launch_bounds__(256, 2) void k_conv_head7n(ConvArgs a, int tiles_x, int tiles_y, int chunk) {
+    constexpr int TH = 8, TWO = 26, R = 3, HH = TH + 2 * R, HWD = 32, HPX = HH * HWD;
+    constexpr int ARRB = HPX * 16;                 // bytes of one (k-block, plane) array: 16 B per pixel -- a multiple of 256
+    constexpr int KSTR = 2 * ARRB + 64;            // k-block stride: hi array, lo array, 64-byte skew
+    constexpr int SROW = 21 * 32;                  // floats of one output row's partial tile [m = (dx, co)][halo column]
+    static_assert(ARRB % 256 == 0, "array pitch");
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * KSTR];
+    __shared__ __attribute__((aligned(16))) float Ss[4 * 2 * SROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ConvSrc s = a.src[0];
+    // ---- A fragments: W[m = 3 dx + co][k = 8 (lane >> 5) + j] of tap row dy, K-step ks: packed fp32 [tap][Cout_pad][Ktot] -> split f16 (x 64), once per workgroup ----
+    h8 wh[7][NS], wl[7][NS];
+    {
+        const int m = lane & 31, kg = lane >> 5, dx = m / 3, co = m - 3 * dx;
+        const bool mok = m < 21 && co < a.Cout;
+        // (two batches of tap rows: all 28 float4 loads of a lane at once would hold 112 registers of fp32 weights beside the 112 of split fragments)
+#pragma unroll
+        for (int d0 = 0; d0 < 7; d0 += 4) {
+            float4 w0[4][NS], w1[4][NS];
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++)
+#pragma unroll
+                for (int ks = 0; ks < NS; ks++) {
+                    const int dy = d0 + dd < 7 ? d0 + dd : 6;
+                    const int k0 = 16 * ks + 8 * kg;
+                    const bool ok = mok && k0 < a.Ktot;
+                    const float* wp = a.wp + (ok ? ((long)(dy * 7 + dx) * a.Cout_pad + co) * a.Ktot + k0 : 0L);
+                    w0[dd][ks] = *reinterpret_cast<const float4*>(wp);
+                    w1[dd][ks] = *reinterpret_cast<const float4*>(wp + (ok ? 4 : 0));
+                }
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++)
+#pragma unroll
+                for (int ks = 0; ks < NS; ks++) {
+                    if (d0 + dd >= 7) continue;
+                    const bool ok = mok && 16 * ks + 8 * kg < a.Ktot;
+                    const float wv[8] = {w0[dd][ks].x, w0[dd][ks].y, w0[dd][ks].z, w0[dd][ks].w, w1[dd][ks].x, w1[dd][ks].y, w1[dd][ks].z, w1[dd][ks].w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float v = ok ? wv[e] * HX_WSCALE : 0.f;
+                        const _Float16 hi = (_Float16)v;
+                        wh[d0 + dd][ks][e] = hi; wl[d0 + dd][ks][e] = (_Float16)(v - (float)hi);
+                    }
+                }
+        }
+    }
+    const bool bn = s.bn_scale != nullptr;                   // lazily applied BatchNorm of the producer (ConvSrc.bn_*)
+    const float slope = s.bn_act ? 0.2f : 1.f;
+    const int q = tid & 7, hx = tid >> 3, c = 4 * q;         // staging: thread = (halo column, channel quad), one halo row per pass
+    const bool cok = c < s.C && c < 16 * NS;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bn && cok) { sc = *reinterpret_cast<const float4*>(s.bn_scale + c); sh = *reinterpret_cast<const float4*>(s.bn_shift + c); }
+    unsigned amax = 0u;                                      // f16 range guard (ConvArgs.sat_flag), see k_conv_head
+    const int per_img = tiles_x * tiles_y;
+    const long ntiles = (long)a.N * per_img;
+    // workgroup -> tiles: XCD j (= blockIdx & 7: workgroups go round-robin over the 8 XCDs) owns the tiles [j chunk, (j + 1) chunk) in row-major order and its workgroups walk
+    // them with a stride of gridDim / 8: at any time an XCD works on consecutive tile rows, whose halos overlap in its L2
+    const int slots = gridDim.x >> 3;
+    const long tend_ = (long)((blockIdx.x & 7) + 1) * chunk, tend = tend_ < ntiles ? tend_ : ntiles;
+    for (long tile = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3); tile < tend; tile += slots) {
+        const int n = (int)(tile / per_img);
+        const int rem = (int)(tile - (long)n * per_img);
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TWO;
+        // ---- halo: 14 rows x 32 columns x (4 NS) quads; all loads of a thread in flight before the first conversion ----
+        float4 ld[HH];
+        const int x = x0 - R + hx;
+        const bool xok = cok && x >= 0 && x < a.W;
+        const float* base = s.p + (long)n * s.sn + (cok ? c : 0);
+#pragma unroll
+        for (int i = 0; i < HH; i++) {
+            const int y = y0 - R + i;
+            const bool ok = xok && y >= 0 && y < a.H;
+            ld[i] = *reinterpret_cast<const float4*>(base + (ok ? ((long)y * a.W + x) * s.ld : 0L));
+        }
+        if (q < 4 * NS) {
+#pragma unroll
+            for (int i = 0; i < HH; i++) {
+                const int y = y0 - R + i;
+                const bool ok = xok && y >= 0 && y < a.H;
+                float v[4] = {ld[i].x, ld[i].y, ld[i].z, ld[i].w};
+                if (bn) {      // act(x * scale + shift); the zero padding applies to the NORMALISED tensor
+                    v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+                }
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float t = (ok && c + e < s.C) ? v[e] : 0.f;
+                    amax = max(amax, __float_as_uint(t) & 0x7fffffffu);
+                    t = __builtin_amdgcn_fmed3f(t, -HD_F16_MAX, HD_F16_MAX);
+                    hi[e] = (_Float16)t; lo[e] = (_Float16)(t - (float)hi[e]);
+                }
+                unsigned char* d = Xs + (q >> 1) * KSTR + (i * HWD + hx) * 16 + (q & 1) * 8;
+                *reinterpret_cast<h4*>(d) = hi;
+                *reinterpret_cast<h4*>(d + ARRB) = lo;
+            }
+        }
+        __syncthreads();
+        // ---- this wave's two output rows: halo rows 2 wave .. 2 wave + 7, each read once ----
+        f32x16 accA, accB;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { accA[e] = 0.f; accB[e] = 0.f; }
+        const unsigned char* bb = Xs + (lane >> 5) * KSTR + ((2 * wave) * HWD + (lane & 31)) * 16;
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+#pragma unroll
+            for (int ks = 0; ks < NS; ks++) {
+                const h8 xh = *reinterpret_cast<const h8*>(bb + 2 * ks * KSTR + rr * HWD * 16);
+                const h8 xl = *reinterpret_cast<const h8*>(bb + 2 * ks * KSTR + rr * HWD * 16 + ARRB);
+                // (small terms first; consecutive instructions alternate between the two accumulators where both rows use this halo row)
+                if (rr < 7) accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[rr][ks], xh, accA, 0, 0, 0);
+                if (rr > 0) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[rr - 1][ks], xh, accB, 0, 0, 0);
+                if (rr < 7) accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[rr][ks], xl, accA, 0, 0, 0);
+                if (rr > 0) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[rr - 1][ks], xl, accB, 0, 0, 0);
+                if (rr < 7) accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[rr][ks], xh, accA, 0, 0, 0);
+                if (rr > 0) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[rr - 1][ks], xh, accB, 0, 0, 0);
+            }
+        }
+        // ---- shift-add of the seven column partials: D[m][p] (m = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), p = lane & 31) -> LDS [row][m][p] -> out[x][co] = sum_dx D[3 dx + co][x + dx] ----
+        float* S = Ss + wave * 2 * SROW;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (m < 21) { S[m * 32 + (lane & 31)] = accA[e]; S[SROW + m * 32 + (lane & 31)] = accB[e]; }
+        }
+        __syncthreads();      // (also: every wave is done with the halo image -- the next tile's staging may overwrite it)
+        {
+            const int xo = lane & 31, row = lane >> 5;
+            const int y = y0 + 2 * wave + row, xg = x0 + xo;
+            if (xo < TWO && y < a.H && xg < a.W) {
+                const float* Sr = S + row * SROW + xo;
+                float* o = a.out + (long)n * a.out_sn + ((long)y * a.W + xg) * a.out_ld;
+                for (int cc = 0; cc < a.Cout; cc++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < 7; dx++) v += Sr[(3 * dx + cc) * 32 + dx];
+                    v = v * (1.0f / HX_WSCALE) + (a.bias ? a.bias[cc] : 0.f);
+                    if (a.act == 1) v = tanhf(v);
+                    o[cc] = v;
+                }
+            }
+        }
+    }
+    if (a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, amax > 0x7f800000u ? 3u : 1u);
+}
+
 // ---- dgrad of the 7x7 head (3 -> C channels as a convolution of dY with the flipped weights; model/layers/final_block.py:9-29 backward) on v_mfma_f32_16x16x32_bf16 ----
 // The 3-channel side is the REDUCTION here: K = 32 = one tap ROW of the 7x7 window = 4 tap pairs x 2 taps x (3 -> 4) channels (the eighth tap carries zero weights), so a
 // 16-pixel x 16-channel block takes 7 instructions per product instead of 49 v_mfma_f32_16x16x4_f32 (k_conv_c4<7>: 85 us per 8 frames of 256 x 256, half of it matrix-pipe
@@ -282,7 +442,14 @@ int conv_head_fwd_try(const ConvArgs& a, hipStream_t st) {
     if (a.precision != PREC_F16X3 || a.wq || a.nsrc != 1 || a.src[0].bcast || a.Cout > 3 || a.Cout < 1 || (a.KS != 3 && a.KS != 7)) return 0;
     if (a.accumulate || a.res || a.mask || a.pool_out || a.skip_out || a.stats || (a.act != 0 && a.act != 1)) return 0;
     if (a.src[0].C < 16 || (a.src[0].ld & 3) || (a.src[0].sn & 3) || (a.src[0].C & 3) || (a.Ktot & 3)) return 0;
-    if (a.KS == 7) {
+    if (a.KS == 7 && a.src[0].C <= 32 && a.Cout_pad >= a.Cout && (a.Ktot & 15) == 0) {      // taps on the N side (round 6)
+        const int tx = cdiv(a.W, 26), ty = cdiv(a.H, 8);
+        const long ntiles = (long)a.N * tx * ty;
+        const int chunk = (int)((ntiles + 7) / 8);
+        const int slots = chunk < 64 ? chunk : 64;                    // <= 512 persistent workgroups, two per CU
+        if (a.src[0].C <= 16) hipLaunchKernelGGL((k_conv_head7n<1>), dim3(8 * slots), dim3(256), 0, st, a, tx, ty, chunk);
+        else hipLaunchKernelGGL((k_conv_head7n<2>), dim3(8 * slots), dim3(256), 0, st, a, tx, ty, chunk);
+    } else if (a.KS == 7) {
         const int tx = cdiv(a.W, 32), ty = cdiv(a.H, 16);
         if ((long)a.N * tx * ty < 200) {      // a batch-1 frame: 128 workgroups of 16 x 32 pixels leave half the chip idle -- 8 x 32 tiles (2.0 x halo instead of 1.6 x, but twice the workgroups and a
                                               // chain half as long per workgroup: 22.4 -> 15 us per frame at 256 x 256)

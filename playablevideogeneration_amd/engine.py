@@ -203,8 +203,10 @@ class Engine:
         self._early = []                     # (offset, count, work) of the buckets already in flight
         if world == 1 and not force:
             return
-        if native is None:      # (CADDY_DP_NATIVE=0: the torch.distributed hooks even where RCCL is loadable)
-            native = (self.device.type == "cuda" and os.environ.get("CADDY_DP_NATIVE", "1") != "0"
+        if native is None:      # (CADDY_DP_NATIVE=0: the torch.distributed hooks even where RCCL is loadable; =force: the native path on any device type -- the simulator
+                                # tests drive csrc/dp_rccl.cpp through a stand-in library named by CADDY_RCCL_LIB)
+            mode = os.environ.get("CADDY_DP_NATIVE", "1")
+            native = ((self.device.type == "cuda" or mode == "force") and mode != "0"
                       and hasattr(self.lib, "caddy_dp_available") and self.lib.caddy_dp_available() == 1)
         if world > 1:      # every rank must take the same branch BEFORE anyone enters the unique-id broadcast / ncclCommInitRank: agree on the weakest rank's capability
             cap = torch.tensor([int(bool(native))], device=self.device if dist.get_backend(process_group) == "nccl" else "cpu", dtype=torch.int32)

@@ -24,5 +24,17 @@ def build_emu(force=False):
     return EMU_LIB
 
 
+FAKE_RCCL = os.path.join(EMU_DIR, "_build", "libfake_rccl.so")
+
+
+def build_fake_rccl():
+    """the shared-memory stand-in for librccl.so (tests/emu/fake_rccl.cpp) that the simulator build's dp_rccl.cpp loads through CADDY_RCCL_LIB"""
+    src = os.path.join(EMU_DIR, "fake_rccl.cpp")
+    if B._stale(FAKE_RCCL, [src]):
+        os.makedirs(os.path.dirname(FAKE_RCCL), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", FAKE_RCCL, src, "-lrt", "-lpthread"])
+    return FAKE_RCCL
+
+
 if __name__ == "__main__":
     print(build_emu(True))

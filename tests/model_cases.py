@@ -19,6 +19,10 @@ def noise_dict(rec, B, T, K, Da, gumbel=True):
             "eps_states_rec": rec[2 + g + n], "eps_dirs_rec": rec[3 + g + n].reshape(B * n, Da)}
 
 
+# full_case's bounds on the bit-reproducible backward (the default): worst per-parameter max error relative to that parameter's largest fp64 gradient, and the relative
+# deviation of sum |grad| from the reference's own summaries (z["grad_abs"]).  Written for the arrival-order backward as 1e-1 / 5e-2 (rounds 1 - 4).
+WORST_PARAM_FLOOR = 1e-1
+GRAD_ABS_TOL = 5e-2
 SIM_SPLIT = False      # simulator runs: exact-fp32 convolutions by default (the split-operand kernels are 4x slower to simulate; they have their own cases)
 
 
@@ -132,17 +136,96 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=True, grad_
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
     assert rel_h <= (max(2 * rel_o, grad_floor) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
-    assert worst_h <= max(5 * worst_o, 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
+    assert worst_h <= max(5 * worst_o, WORST_PARAM_FLOOR if deterministic else 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
     # reference's own gradient summaries (loose: same conditioning caveat)
+    worst_abs = 0.0
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
         got = eng.grad_view(str(n)).double().abs().sum().item()
-        assert abs(got - ga) <= 5e-2 * max(ga, 1e-4), (n, got, ga)
+        worst_abs = max(worst_abs, abs(got - ga) / max(ga, 1e-4))
+        assert abs(got - ga) <= GRAD_ABS_TOL * max(ga, 1e-4), (n, got, ga)
     sd = eng.state_dict()
     for k in z.files:
         if k.startswith("buf:"):
             assert np.allclose(sd[k[4:]].cpu().numpy(), z[k], atol=1e-4), k
     assert np.allclose(sd["centroid_estimator.estimated_centroids"].cpu().numpy(), z["centroids"], atol=1e-5)
-    return eng, dict(rel_l2_hip=rel_h, rel_l2_oracle32=rel_o, worst_hip=worst_h, worst_oracle32=worst_o)
+    return eng, dict(rel_l2_hip=rel_h, rel_l2_oracle32=rel_o, worst_hip=worst_h, worst_oracle32=worst_o, worst_grad_abs=worst_abs)
+
+
+def slope_flip_record(name, lib, dev, max_flips=4, candidates=24, done=5e-3):
+    """Element-level record of a gradient offset caused by LeakyReLU slope decisions.  LeakyReLU'(x) jumps from 0.2 to 1 at x = 0; a pre-activation that
+    the fp64 oracle puts within the forward round-off (~1e-6 of the tensor's scale) of zero can land on the other side in an fp32 forward, and through the train-mode BatchNorms of
+    a tiny batch that one slope shifts every upstream gradient by O(1e-2).  Procedure: (1) HIP gradients g of the golden case; (2) fp64 oracle with every LeakyReLU input
+    recorded; the `candidates` elements closest to zero relative to their tensor's rms; (3) greedy search: re-run the fp64 oracle with one candidate at a time forced onto the
+    OTHER slope (the forward changes by < 1e-6), keep the flip that brings the oracle's gradients closest to g, repeat up to max_flips times or until the relative L2 distance is
+    below `done`.  Returns the flips (call index of oracle._lrelu, tensor shape, flat index, fp64 value, tensor rms) and the distance before / after; asserts that the flips
+    explain the offset (after <= done and after <= before / 4) -- otherwise the offset would be a kernel error, not a slope decision."""
+    import torch.nn.functional as F
+    c, z = H.load_case(name)
+    d, P, obs = H.inputs_of(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"], gumbel=c.get("use_gumbel", True)), training=True, fetch_outputs=False)
+    eng.loss_backward(H.LOSS_W, smooth_mi=c.get("mi") != "plain", mi_alpha=0.2)
+    names = [n for n, _ in O.param_table(d) if O.is_trainable(n)]
+    g_hip = {n: eng.grad_view(n).cpu().double() for n in names}
+    orig = O._lrelu
+    seen = []
+
+    def run(flips, record=False):
+        calls = [0]
+
+        def lrelu(x):
+            k = calls[0]; calls[0] += 1
+            if record:
+                seen.append(x.detach())
+            y = F.leaky_relu(x, O.LRELU)
+            idx = [f for kk, f in flips if kk == k]
+            if idx:
+                m = torch.zeros(x.numel(), dtype=torch.bool); m[idx] = True
+                y = torch.where(m.view_as(x), torch.where(x > 0, O.LRELU * x, x), y)
+            return y
+        O._lrelu = lrelu
+        try:
+            P64, _ = _oracle_run(c, d, P, obs, torch.float64, nz.record)
+        finally:
+            O._lrelu = orig
+        num = den = 0.0
+        for n in names:
+            g64 = P64[n].grad if P64[n].grad is not None else torch.zeros_like(P64[n])
+            num += ((g_hip[n] - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
+        return (num / den) ** 0.5
+    before = run([], record=True)
+    cand = []
+    for k, x in enumerate(seen):
+        rms = x.pow(2).mean().sqrt().item() + 1e-30
+        r = (x.abs().flatten() / rms)
+        v, i = torch.topk(r, min(8, r.numel()), largest=False)
+        cand += [(v[j].item(), k, int(i[j]), x.flatten()[int(i[j])].item(), rms, tuple(x.shape)) for j in range(len(v))]
+    cand.sort()
+    cand = cand[:candidates]
+    flips, cur, chosen = [], before, []
+    for _ in range(max_flips):
+        if cur <= done:
+            break
+        best = None
+        for rel, k, i, val, rms, shape in cand:
+            if (k, i) in flips:
+                continue
+            e = run(flips + [(k, i)])
+            if best is None or e < best[0]:
+                best = (e, k, i, val, rms, shape, rel)
+        if best is None or best[0] >= cur:
+            break
+        cur = best[0]
+        flips.append((best[1], best[2]))
+        chosen.append(dict(lrelu_call=best[1], shape=best[5], flat_index=best[2], value_fp64=best[3], tensor_rms=best[4], value_over_rms=best[6], rel_l2_after=best[0]))
+    rec = dict(rel_l2_before=before, rel_l2_after=cur, flips=chosen)
+    assert cur <= done and cur <= before / 4, rec
+    return rec
 
 
 def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
@@ -177,9 +260,11 @@ def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
     assert abs(losses["perceptual_term"] - float(z["loss_perceptual_term"])) < 1e-4 * float(z["loss_perceptual_term"])
     assert abs(losses["total"] - float(z["loss_total"])) < 1e-4 * abs(float(z["loss_total"])), (losses["total"], float(z["loss_total"]))
     # parameter gradients after the full backward: the reference's own summaries (sum |g| per tensor).  Same conditioning caveat as full_case.
+    worst_abs = 0.0
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
         got = eng.grad_view(str(n)).double().abs().sum().item()
-        assert abs(got - ga) <= 5e-2 * max(ga, 1e-4), (n, got, ga)
+        worst_abs = max(worst_abs, abs(got - ga) / max(ga, 1e-4))
+        assert abs(got - ga) <= GRAD_ABS_TOL * max(ga, 1e-4), (n, got, ga)
     # Gradients w.r.t. the reconstructions.  The perceptual gradient is DISCONTINUOUS in its input (sign() of the feature L1, ReLU masks,
     # max-pool arg-max): fp32 round-off flips a handful of those decisions, each flip moving one image's gradient by O(1e-2) while all
     # other images agree to 1e-6.  Criteria: (a) per image, against the ORACLE evaluated at the engine's own reconstructions (identical
@@ -358,6 +443,48 @@ def oracle_case(lib, dev, c, fwd_tol=3e-4):
     losses = eng.loss_backward(H.LOSS_W)
     assert abs(losses["total"] - total.item()) < 1e-4 * max(1.0, abs(total.item()))
     assert torch.isfinite(eng.grads).all()
+
+
+def oracle_grad_case(lib, dev, c, fwd_tol=3e-4, grad_floor=5e-3, plain_mi=False):
+    """An ad-hoc geometry end to end WITHOUT a golden: all 20 outputs (action indices bit-exact), frame MSE, every loss term, and the gradients against an fp64 run of the oracle
+    with full_case's criterion -- relative L2 error <= max(2 x the fp32 oracle's own error, grad_floor), worst per-parameter error <= max(5 x the oracle's, 1e-1).  plain_mi: the
+    MutualInformationLoss of `training.trainer` (configs/03_tennis.yaml:61) instead of the smooth estimator."""
+    if plain_mi:
+        c = dict(c, mi="plain")
+    d, P, obs = H.inputs_of(c)
+    nz = O.Noise()
+    torch.manual_seed(H.NOISE_SEED)
+    with torch.no_grad():
+        oout = O.Oracle(d, {k: v.clone() for k, v in P.items()}, training=True).forward_full(obs, c["gt"], tau=c["tau"], noise=nz)
+        ema0 = None if plain_mi else torch.full((d.K, d.K), 1.0 / (d.K * d.K))
+        total, comp, _ = O.full_model_loss(oout, obs, H.LOSS_W, mi_ema=ema0, mi_alpha=0.2)
+    eng = make_engine(c, lib, dev)
+    eng.load_state_dict(P)
+    out = eng.forward_full(obs, c["gt"], c["tau"], noise_dict(nz.record, c["B"], c["T"], c["K"], c["Da"]), training=True)
+    _cmp(out, list(oout), fwd_tol, "vs oracle")
+    mse = ((out[0].cpu() - oout[0]) ** 2).mean(dim=(2, 3, 4)).max().item()
+    assert mse < 1e-5, mse
+    losses = eng.loss_backward(H.LOSS_W, smooth_mi=not plain_mi, mi_alpha=0.2)
+    assert abs(losses["total"] - total.item()) < 1e-4 * max(1.0, abs(total.item())), (losses["total"], total.item())
+    for k in ("rec", "states", "entropy", "dir_kl", "mi", "state_kl"):
+        tol = 1e-3 if k.endswith("_kl") else 1e-4
+        assert abs(losses[k] - comp[k].item()) < tol * max(1.0, abs(comp[k].item())), (k, losses[k], comp[k].item())
+    P64, _ = _oracle_run(c, d, P, obs, torch.float64, nz.record)
+    P32, _ = _oracle_run(c, d, P, obs, torch.float32, nz.record)
+    num_h = num_o = den = worst_h = worst_o = 0.0
+    for n, _ in O.param_table(d):
+        if not O.is_trainable(n):
+            continue
+        g64 = P64[n].grad if P64[n].grad is not None else torch.zeros_like(P64[n])
+        g32 = (P32[n].grad if P32[n].grad is not None else torch.zeros_like(P32[n])).double()
+        g = eng.grad_view(n).cpu().double()
+        s = max(g64.abs().max().item(), 1e-9)
+        worst_h, worst_o = max(worst_h, (g - g64).abs().max().item() / s), max(worst_o, (g32 - g64).abs().max().item() / s)
+        num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
+    rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+    assert rel_h <= max(2 * rel_o, grad_floor), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+    assert worst_h <= max(5 * worst_o, 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
+    return eng, dict(frame_mse=mse, rel_l2_hip=rel_h, rel_l2_oracle32=rel_o, worst_hip=worst_h, worst_oracle32=worst_o)
 
 
 def pretraining_case(lib, dev, name="pre_main_s4", fwd_tol=2e-4):

@@ -219,7 +219,8 @@ def _trainer_worker(rank, world, port, out, skew=0.0, ens=1):
         members.append(m.last_member)
         time.sleep(skew * ((rank + 2 * i + 1) % world))
         tr.optimizer_step(m)
-    torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone(), "members": members}, os.path.join(out, f"t{rank}.pt"))
+    torch.save({"params": m._flat[:m.n_train].clone(), "centroids": m.centroid_estimator.get_estimated_centroids().clone(), "members": members,
+                "native": bool(getattr(m.engine(1, 4), "_dp_native", False))}, os.path.join(out, f"t{rank}.pt"))
     dist.barrier()
 
 
@@ -258,3 +259,118 @@ def test_trainer_mirror_data_parallel_gloo_world4_skewed_ranks(tmp_path):
     ts = [torch.load(tmp_path / f"t{r}.pt") for r in range(4)]
     for t in ts[1:]:
         assert torch.equal(ts[0]["params"], t["params"]) and torch.equal(ts[0]["centroids"], t["centroids"])
+
+
+# ---- the library's NATIVE data-parallel path (csrc/dp_rccl.cpp) on more than one rank without a GPU: a shared-memory stand-in for librccl.so (tests/emu/fake_rccl.cpp) ----
+def _fake_rccl_env():
+    from tests.emu.build_emu import build_fake_rccl
+    return dict(CADDY_RCCL_LIB=build_fake_rccl(), CADDY_DP_NATIVE="force", FAKE_RCCL_TIMEOUT_S="120")
+
+
+def _native_worker(rank, world, port, out, kind, skew):
+    os.environ.update(_fake_rccl_env())
+    if kind == "step":
+        _dp_worker(rank, world, port, out)
+    else:
+        _trainer_worker(rank, world, port, out, skew)
+
+
+def test_native_dp_step_on_fake_rccl_world2(tmp_path):
+    """dp_rccl.cpp -- unique ids, ncclCommInitRank x 2 (one communicator per stream) behind the watchdog thread, the MI / centroid reductions on `comm`, the
+    R / D gradient buckets on `comm2` from inside the backward, caddy_allreduce_grads' gap arithmetic for the rest -- with TWO ranks, on the simulator, through a librccl stand-in that
+    fails on any collective whose order or size differs between the ranks.  Same assertions as the gloo twin: sum over ranks, identical replicas, bucketed == flat, MI matrix /
+    centroids equal to one process on the concatenated batch."""
+    import torch.multiprocessing as mp
+    port = 38500 + os.getpid() % 1000
+    mp.spawn(_native_worker, args=(2, port, str(tmp_path), "step", 0.0), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.allclose(r0["reduced"], r0["local"] + r1["local"], atol=1e-6) and not torch.equal(r0["local"], r1["local"])
+    assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["params"], r1["params"])
+    assert torch.equal(r0["reduced_overlap"], r1["reduced_overlap"])
+    assert torch.allclose(r0["reduced_overlap"], r0["reduced"], atol=1e-4 * r0["reduced"].abs().max().item())
+    assert torch.equal(r0["centroids"], r1["centroids"]) and torch.equal(r0["mi_ema"], r1["mi_ema"])
+    assert r0["hook_host_us"] == 0.0          # no Python callback on the per-step path: the worker took the native branch (it asserts caddy_dp_bucket_floats > half the gradient)
+
+
+def test_native_dp_trainer_on_fake_rccl_world4_skewed_ranks(tmp_path):
+    """the trainer mirror on the native path with four ranks that reach the collectives at different times (sleeps that differ per rank and per step): both communicators keep one
+    total order on every rank (the stand-in returns ncclInvalidUsage otherwise, a missing rank is a time-out) and the replicas end bit-identical"""
+    import torch.multiprocessing as mp
+    port = 39500 + os.getpid() % 1000
+    mp.spawn(_native_worker, args=(4, port, str(tmp_path), "trainer", 0.1), nprocs=4, join=True)
+    ts = [torch.load(tmp_path / f"t{r}.pt") for r in range(4)]
+    assert all(t["native"] for t in ts)                     # every rank's engine took the C path
+    for t in ts[1:]:
+        assert torch.equal(ts[0]["params"], t["params"]) and torch.equal(ts[0]["centroids"], t["centroids"])
+
+
+def test_bench_world8_native_path_on_fake_rccl(tmp_path):
+    """`tools/launch_dp.sh 8` with bench.run() on the NATIVE path: eight processes, 16 communicators' worth of rendezvous, every collective of the two timed steps, the profiled step
+    and the erad leg through dp_rccl.cpp (`dp_native` in the JSON line; nobody fell back to the hooks)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "bench8.json"
+    env = dict(os.environ, CADDY_DP_SCRIPT="tests/dp_sim_bench.py", CADDY_DP_SIM_OUT=str(out), MASTER_PORT=str(29900 + os.getpid() % 90), OMP_NUM_THREADS="1",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **_fake_rccl_env())
+    r = subprocess.run(["bash", os.path.join(root, "tools", "launch_dp.sh"), "8", "2", "1"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "using the torch.distributed hooks" not in r.stderr      # nobody fell back
+    res = json.load(open(out))
+    assert res["n_gpus"] == 8 and res["rccl_ranks_seen"] == 8 and res["config"]["parallelism"] == "dp8" and res["dp_native"] is True
+
+
+def _misuse_worker(rank, world, name, out):
+    import ctypes
+    from tests.emu.build_emu import build_fake_rccl
+    os.environ["FAKE_RCCL_TIMEOUT_S"] = "20"
+    lib = ctypes.CDLL(build_fake_rccl())
+
+    class Uid(ctypes.Structure):
+        _fields_ = [("b", ctypes.c_char * 128)]
+    uid = Uid(); uid.b = name.encode()
+    comm = ctypes.c_void_p()
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+    assert lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+    lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    buf = (ctypes.c_float * 8)(*[float(rank + 1)] * 8)
+    rc1 = lib.ncclAllReduce(buf, buf, 8, 7, 0, comm, None)                        # same call on both ranks: 1 + 2
+    first = list(buf)
+    rc2 = lib.ncclAllReduce(buf, buf, 8 if rank == 0 else 4, 7, 0, comm, None)    # the ranks disagree about the collective
+    torch.save({"rc1": rc1, "first": first, "rc2": rc2}, os.path.join(out, f"m{rank}.pt"))
+
+
+def test_fake_rccl_detects_mismatched_collectives(tmp_path):
+    """the stand-in itself: a matching all-reduce sums in rank order, a collective whose size differs between the ranks is ncclInvalidUsage (5) on every rank, not a silent reduction"""
+    import torch.multiprocessing as mp
+    name = f"/caddy_fake_rccl_test_{os.getpid()}"
+    mp.spawn(_misuse_worker, args=(2, name, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
+    assert m0["rc1"] == m1["rc1"] == 0 and m0["first"] == m1["first"] == [3.0] * 8
+    assert m0["rc2"] == m1["rc2"] == 5
+
+
+def test_dp_init_watchdog_turns_a_missing_rank_into_an_error(tmp_path):
+    """caddy_dp_init with world 2 and only ONE rank calling it: ncclCommInitRank (the stand-in blocks like the real rendezvous) never returns; the watchdog thread of dp_rccl.cpp
+    gives up after CADDY_DP_INIT_TIMEOUT_S and the call returns -3 with a message naming the rank -- in a subprocess, because the blocked helper thread is detached by design"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes as C, os, time, torch\n"
+        "from tests.emu.loader import load_emu\n"
+        "from playablevideogeneration_amd.engine import Engine\n"
+        "lib = load_emu()\n"
+        "e = Engine(variant='reduced', batch=1, seq_len=3, height=16, width=16, stacking=1, actions=3, action_dim=1, hidden=64, device='cpu', lib=lib)\n"
+        "buf = C.create_string_buffer(256)\n"
+        "assert e.lib.caddy_dp_unique_id(buf) == 0\n"
+        "t0 = time.time()\n"
+        "rc = e.lib.caddy_dp_init(e.ctx, buf.raw, 2, 0, 1)\n"
+        "print('RC', rc, round(time.time() - t0, 1), e._err())\n"
+    )
+    env = dict(os.environ, CADDY_DP_INIT_TIMEOUT_S="2", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **_fake_rccl_env())
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC")]
+    assert line, (r.stdout[-500:], r.stderr[-2000:])
+    parts = line[0].split()
+    assert parts[1] == "-3" and float(parts[2]) < 30 and "did not return within 2 s on rank 0 of 2" in line[0]

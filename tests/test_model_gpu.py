@@ -18,7 +18,8 @@ def lib():
 
 @pytest.mark.parametrize("name", ["full_reduced_s1", "full_main_s1", "full_main_s4_hard"])
 def test_full_model_parity(lib, name):
-    M.full_case(name, lib, "cuda")
+    _, info = M.full_case(name, lib, "cuda")
+    print(name, info)
 
 
 @pytest.mark.parametrize("name", ["full_reduced_s1", "full_main_s1", "full_main_s4_hard"])
@@ -39,7 +40,16 @@ def test_full_model_parity_config_branches(lib, name):
     (1.2e-2 overall, run-to-run identical; CADDY_TEST_VERBOSE=1 prints them): one slope decision in A on this golden's 8 frames of tiny maps, spread over the network by its
     train-mode BatchNorms.  The kernels themselves agree with fp64 to 2e-6 / 1e-4 at those shapes (test_conv_hx_16_channel_layers), single-step graphs to 2e-5 per parameter
     (test_single_step_gradients_tight) and the BAIR-geometry gradients stay inside their bound.)"""
-    M.full_case(name, lib, "cuda", grad_floor=2e-2 if name in ("full_main_s1_nogumbel", "full_reduced_s1_novar") else 5e-3)
+    _, info = M.full_case(name, lib, "cuda", grad_floor=2e-2 if name in ("full_main_s1_nogumbel", "full_reduced_s1_novar") else 5e-3)
+    print(name, info)
+
+
+@pytest.mark.parametrize("name", ["full_reduced_s1_novar", "full_main_s1_nogumbel"])
+def test_gradient_offset_of_the_2e2_floor_goldens_is_a_slope_decision(lib, name):
+    """The two goldens whose gradient bound sits on a 2e-2 floor: show, element by element, that the offset IS LeakyReLU slope decisions on pre-activations inside the forward
+    round-off of zero -- the fp64 oracle re-run with exactly those elements on the other slope must reproduce the HIP gradients to the tight bound (see slope_flip_record)."""
+    rec = M.slope_flip_record(name, lib, "cuda")
+    print(name, rec)
 
 
 def test_single_step_gradients_tight(lib):
@@ -93,6 +103,28 @@ def test_baseline_config0_vs_oracle(lib):
 def test_tennis_rollout_256_vs_oracle(lib):
     """BASELINE.json configs[3]: Tennis hyper-parameters (main model, S=4, Da=5) at 256x256, 32-frame roll-out, every frame vs the oracle"""
     print(M.rollout_oracle_case(lib, "cuda", dict(variant="main", K=7, Da=5, Ch=128, S=4, H=256, W=256), steps=32))
+
+
+TENNIS_NATIVE = dict(variant="main", K=7, Da=5, Ch=128, S=4, H=96, W=256, tau=0.9)      # configs/03_tennis.yaml:16,29,33,47,114: 256 x 96 frames, state 12 x 32, hidden 128, 5-d action space, stacking 4
+
+
+@pytest.mark.parametrize("batch", [6, 2])
+def test_tennis_native_geometry_vs_oracle(lib, batch):
+    """The reference's OWN Tennis geometry (configs/03_tennis.yaml: crop [0, 0, 256, 96], state_resolution [12, 32], observation_stacking 4, action_space_dimension 5,
+    batch_size 6, observations_count_start 7, trainer = training.trainer i.e. the plain MutualInformationLoss): state maps 12 x 32 -> 6 x 16 leave ragged 8 x 16 pixel tiles in
+    both directions at once (12 = 8 + 4 rows; 6 rows) and odd pooled widths in A.  gt = 3 of T = 7 so that four steps run closed-loop.  All 20 outputs, action indices, every
+    loss term and the fp64 gradient bound of the golden cases."""
+    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=batch, T=7, gt=3), plain_mi=True)
+    print(info)
+    torch.cuda.empty_cache()
+
+
+def test_tennis_native_geometry_smooth_mi_and_rollout(lib):
+    """the same frames with the smooth MI estimator (training.smooth_mi_trainer) at the YAML's gt = 6, and a 16-frame roll-out at 256 x 96 (play.py path), every frame vs the oracle"""
+    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=2, T=7, gt=6))
+    print(info)
+    print(M.rollout_oracle_case(lib, "cuda", TENNIS_NATIVE, steps=16))
+    torch.cuda.empty_cache()
 
 
 def test_single_step_gradients_tight_128(lib):

@@ -1,4 +1,4 @@
-"""Is the training step host-bound?  Host enqueue time of one E/R/A/D step (no device wait inside) vs its device time:  python tools/host_time.py"""
+"""Is the training step host-bound?  Host enqueue time of one E/R/A/D step (no device wait inside) vs its device time:  python tools/host_time.py [workload]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,9 @@ from playablevideogeneration_amd import configs
 from playablevideogeneration_amd.engine import Engine
 from playablevideogeneration_amd.init import init_parameters
 
-wl = configs.WORKLOADS["bair256_t16_b8"]
+name = sys.argv[1] if len(sys.argv) > 1 else "bair256_t16_b8"
+wl = configs.WORKLOADS[name]
+print(name, flush=True)
 B, T, H, W, S, K, Da = wl["batch"], wl["seq_len"], wl["height"], wl["width"], wl["stacking"], wl["actions"], wl["action_dim"]
 dev = torch.device("cuda")
 eng = Engine(variant=wl["variant"], batch=B, seq_len=T, height=H, width=W, stacking=S, actions=K, action_dim=Da, hidden=wl["hidden"], device=dev)

@@ -9,16 +9,26 @@ import sqlite3
 import sys
 
 
+def hx_tile(name):
+    """(BN, waves) of a k_conv_hx<T, NPL, TH, TW, BN, WM, WN, D, EP, IO> instance from any spelling rocprofv3 produces: fully mangled
+    (..Li8ELi16ELi64ELi2ELi2E..), or half-demangled, where leading integers are eaten ("ELi1, ELi64E, 2, 2, 3, 0, 0" = TH 8, TW 16, BN 64, WM 2, WN 2;
+    "ELi16ELi64ELi4EL, int, E, 3, 0, 0" = BN 64, WM 4, WN 1 spelled "L, int, E").  BN is the first 32 / 64 / 128 (TH, TW are 4 / 8 / 16), WM and WN the two
+    tokens behind it."""
+    m = re.search(r"Li(32|64|128)E", name)
+    if not m:
+        return None, None
+    toks = re.findall(r"Li(\d+)E|(L, int, E)|, (\d+)", name[m.end():])
+    vals = [int(a or c) if (a or c) else 1 for a, b, c in toks]
+    if len(vals) < 2:
+        return int(m.group(1)), None
+    return int(m.group(1)), vals[0] * vals[1]
+
+
 def short(name):
-    if "k_conv_hx" in name:      # hipcc leaves these template kernels mangled in the trace (and rocprofv3 half-demangles some of them)
-        nums = [int(x) for x in re.findall(r"Li(\d+)E", name)]      # mangled: <T, NPL, TH, TW, BN, WM, WN, D> -> NPL, TH, TW, BN, WM, WN, D
-        if "k_conv_hxI" in name and len(nums) >= 6:
-            bn, waves = nums[3], nums[4] * nums[5]
-        else:
-            m = re.search(r"ELi16ELi(\d+)ELi(\d+)E\D*(\d+)", name)      # half-demangled: "...ELi16ELi128ELi4E, 2, 3>" = TW, BN, WM, then WN
-            if not m:
-                return "k_conv_hx<?>"
-            bn, waves = int(m.group(1)), int(m.group(2)) * int(m.group(3))
+    if "k_conv_hx" in name:      # hipcc leaves these template kernels mangled in the trace and rocprofv3 half-demangles the bf16 instances ("<bool _Accum, int, EL, ...>")
+        bn, waves = hx_tile(name)
+        if bn is None:
+            return "k_conv_hx<?>"
         return f"k_conv_hx<{bn}, 8 waves>" if (bn == 128 and waves == 8) else f"k_conv_hx<{bn}>"
     if "k_wgrad_hx" in name:
         return "k_wgrad_hx"
