@@ -211,6 +211,13 @@ int caddy_adam_step(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, f
  * drawn k times has been stepped k times); every other parameter uses `step`. */
 int caddy_set_action_member(caddy_ctx* ctx, int member);
 int caddy_adam_step_member(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int member_step, float grad_scale);
+/* The same step with torch.optim.Adam's per-parameter bookkeeping passed explicitly, for BOTH forms of optimizer.zero_grad() (training/trainer.py:584): member_step[k] (one per
+ * ensemble member; NULL = only the drawn member, with `step`) and s2h_step (state_to_hidden_state_layer, model.py:41-43) are the bias-correction counts of those ranges; 0 skips a
+ * range (its .grad is None: torch >= 2.0's set_to_none default for everything the last backward did not reach), > 0 steps it -- with the real gradient where the last pass produced
+ * one (the drawn member; state_to_hidden_state_layer after caddy_forward_pretraining), with a ZERO gradient otherwise (torch < 2.0, the reference's pinned 1.4.0: zero_grad()
+ * zero-fills, so a parameter that has had a gradient once keeps being decayed and its moments keep ageing).  The host mirror (trainer.py: training.zero_grad_semantics) keeps the counts. */
+int caddy_adam_step_ex(caddy_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const int* member_step, int s2h_step,
+                       float grad_scale);
 
 /* --- play.py roll-out: Model.start_inference (model.py:561-568) / Model.generate_next (model.py:570-607), eval mode.
  *     observation: (3S,H,W); variation: (Da) or NULL (= zeros, noise=False); frame_out: (3,H,W); obs_out: (3S,H,W) or NULL.

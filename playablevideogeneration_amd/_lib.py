@@ -30,7 +30,7 @@ class ConvArgs(C.Structure):
                 ("pool_out", C.c_void_p), ("pool_sn", C.c_long), ("pool_ld", C.c_int), ("skip_out", C.c_int),
                 ("stats", C.c_void_p), ("stats_ld", C.c_int), ("sat_flag", C.c_void_p), ("deterministic", C.c_int), ("direct_ok", C.c_int), ("lstm", C.c_void_p),
                 ("in_s16", C.c_int), ("out_s16", C.c_int), ("pool_s16", C.c_int), ("mask_s16", C.c_int), ("seed_s16", C.c_int),
-                ("avgpool", C.c_int)]      # S16 tensors (csrc/common.h): pre-split 16-bit operand pairs
+                ("avgpool", C.c_int), ("sat_out_next", C.c_int)]      # S16 tensors (csrc/common.h): pre-split 16-bit operand pairs
 
 
 class LstmFuse(C.Structure):      # csrc/common.h: cell update applied by the slab reduce of a roll-out gate convolution (ConvArgs.lstm)

@@ -123,6 +123,9 @@ struct ConvArgs {
     // representation_network.py:39-41): `out` is the (N, H/2, W/2, Cout) map, bias / res / act are applied AFTER the pooling (H, W even).  Only the launches
     // conv_avgpool_ok() accepts (k_conv_narrow: a window's four pixels are two accumulators of one lane x a DPP neighbour); the caller asks first.
     int avgpool;
+    // S16 OUTPUT range guard (SO launches, split f16): 1 = a value the epilogue had to clamp raises the word BEHIND *sat_flag -- the layer that will stage the tensor (VGG19 layer
+    // i + 1: its fall-back makes this launch write fp32 again) -- instead of this layer's own word, whose fall-back would leave the oversized values where they are
+    int sat_out_next;
 };
 int conv_avgpool_ok(const ConvArgs& a);      // (out / out_sn / out_ld need not be set yet)
 // gates = [i | f | o | g] x C pre-activations (convolutional_lstm_cell.py:92-101): c' = sigm(f) c + sigm(i) tanh(g), h' = sigm(o) tanh(c'), hb = h' * scale + shift (the cell's

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         else { if (general) HX_EPI(false, 2); else if (masked) HX_EPI(false, (E_MASK ? 1 : 0)); else HX_EPI(false, 0); }
 #undef HX_EPI
     }
-    if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag, amax_o > 0x7f800000u ? 3u : 1u);
+    if (SO && !is_bf16<T>::value && a.sat_flag != nullptr && amax_o > 0x477fe000u) atomicOr(a.sat_flag + (a.sat_out_next ? 1 : 0), amax_o > 0x7f800000u ? 3u : 1u);
     // ---- BatchNorm partial sums of this tile: the two 32-lane halves of a wave hold different pixel rows of one channel, the WM waves of a column
     // block different rows too -> shuffle, then LDS (the staging tiles are dead), one plain store per (tile, channel): no atomics, fixed order ----
     if (EP == 0 && a.stats != nullptr) {                      // (grid-uniform; the launcher only passes it with splitk == 1)

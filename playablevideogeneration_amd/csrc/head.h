@@ -6,7 +6,7 @@
 // LOSS_PERC_R0 + 6 r: perceptual_loss_r{r}; + 1 + l: perceptual_loss_r{r}_l{l} (l = 0 aliases the total, as in the reference -- perceptual.hip)
 enum { LOSS_TOTAL = 0, LOSS_REC, LOSS_STATES, LOSS_ENTROPY, LOSS_DIRKL, LOSS_MI, LOSS_STATEKL, LOSS_HIDDEN, LOSS_L1_R0, LOSS_L1_R1, LOSS_L1_R2,
        LOSS_PERCEPTUAL = 11, LOSS_PERCEPTUAL_TERM = 12, LOSS_F16_SATURATED = 13, LOSS_PERC_R0 = 16, LOSS_DIAG_0 = 40, LOSS_SLOTS = 56 };
-int loss_report_flag(const unsigned* flags, int n, double* slot, double* total, hipStream_t st);
+int loss_report_flag(unsigned* flags /* [live n | sticky n] */, int n, double* slot, double* total, hipStream_t st);
 int loss_diff_per_frame(const TV& a, int Ta, int a_off, const TV& b, int Tb, int C, int sq, double* acc, hipStream_t st);      // evaluation: per-frame sum |a - b| / (a - b)^2      // *slot = *flag != 0 (the f16 range guard of the split-f16 forward, common.h: ConvArgs.sat_flag)
 
 struct LossWeights { double rec, states, entropy, dir_kl, mi, state_kl, hidden, mi_entropy_lambda, perceptual; };

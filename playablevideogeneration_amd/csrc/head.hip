@@ -404,9 +404,11 @@ __global__ void k_loss_finalize(double* acc, LossWeights w, double n0, double n1
 }
 // f16 range guards of the forward pass (one word per layer, common.h: ConvArgs.sat_flag): slot = 1 if any layer clamped a value; a NaN among the clamped values makes the total NaN --
 // v_med3 turned it into a finite operand, the reference would have propagated it into every loss
-__global__ void k_report_flag(const unsigned* flags, int n, double* slot, double* total) {
+__global__ void k_report_flag(unsigned* flags, int n, double* slot, double* total) {
+    // flags[0 .. n): the words the forward kernels of THIS step raised; flags[n .. 2n): everything raised since the last poll (caddy_f16_saturated).  The step's bits are reported
+    // once and moved to the sticky half: a transient overflow marks one loss call, not every later one, and the poll still finds the layer.
     unsigned any = 0;
-    for (int i = threadIdx.x; i < n; i += 64) any |= flags[i];
+    for (int i = threadIdx.x; i < n; i += 64) { const unsigned f = flags[i]; any |= f; if (f) { flags[n + i] |= f; flags[i] = 0u; } }
     for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
     if (threadIdx.x == 0) { *slot = (any & 1u) ? 1.0 : 0.0; if (any & 2u) *total = __builtin_nan(""); }
 }
@@ -600,7 +602,7 @@ int loss_finalize(double* acc, const LossWeights& w, double n0, double n1, doubl
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, acc, w, n0, n1, n2, nstates, nhidden, l, lv ? 1 : 0);
     return 0;
 }
-int loss_report_flag(const unsigned* flags, int n, double* slot, double* total, hipStream_t st) {
+int loss_report_flag(unsigned* flags, int n, double* slot, double* total, hipStream_t st) {
     hipLaunchKernelGGL(k_report_flag, dim3(1), dim3(64), 0, st, flags, n, slot, total);
     return 0;
 }

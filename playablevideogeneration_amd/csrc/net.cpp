@@ -261,7 +261,7 @@ void build_layers(caddy_ctx* c) {
         for (auto& kv : bnd) { kv.first->dgamma_d = (float*)(pool + kv.second); kv.first->dbeta_d = kv.first->dgamma_d + round_up(kv.first->C, 4); }
     }
     c->red_scratch = (double*)c->persist.alloc(sizeof(double) * RED_MAX_BLOCKS * 2 * 1024);
-    c->sat_flag = (unsigned*)c->persist.alloc(sizeof(unsigned) * CADDY_N_FLAGS);
+    c->sat_flag = (unsigned*)c->persist.alloc(sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // [raised by the forward kernels since the last loss call | sticky until polled]
     c->wgrad_det_cap = 16L << 20;      // 64 MB: >= 3 copies of the largest packed weight gradient (ConvLSTM 1 gates, 9 x 1024 x 528), 256 of a 64 x 64 layer
     c->wgrad_det = (float*)c->persist.alloc(sizeof(float) * c->wgrad_det_cap);
     c->conv_aux = (float*)c->persist.alloc(CONV_AUX_BYTES);
@@ -502,7 +502,10 @@ int caddy_ctx::launch_conv_wgrad(const WgradArgs& a0, double flops, hipStream_t 
     if (deterministic) {
         // ONE scratch, zero-filled, filled and folded per launch: correct only while every weight-gradient launch of a backward pass goes to one stream (the side stream, or the caller's
         // under CADDY_STREAMS=0).  A second stream would silently corrupt gradients in exactly the mode that promises bit-reproducibility: refuse it loudly.
-        if (wgrad_det_owner_set && wgrad_det_owner != stream) { fail = true; set_error("internal: the deterministic weight-gradient scratch was used from two streams in one backward pass"); return -1; }
+        // (the bit-reproducible mode is the default now, so this must not fail a backward -- e.g. when no side stream could be created while the decoder stream is
+        //  active, or the caller moves the context to another stream between queued jobs): the scratch changes hands behind an event -- the new owner starts when everything the
+        //  previous owner has in flight on it is done.
+        if (wgrad_det_owner_set && wgrad_det_owner != stream) { hipEvent_t e = sev(); hipEventRecord(e, wgrad_det_owner); hipStreamWaitEvent(stream, e, 0); n_wgrad_det_handover++; }
         wgrad_det_owner = stream; wgrad_det_owner_set = true;
         a.det_slab = wgrad_det; a.det_cap = wgrad_det_cap;
     }
@@ -556,6 +559,24 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
         }
     }
     const double px_taps = 2.0 * N * H * W * L.pd.KS * L.pd.KS;     // algorithmic FLOPs = px_taps * Cin * Cout
+    if (pooled) {
+        //  conv_avgpool_ok() decided before `out` existed.  Should the launch decline after all (-1 from a launcher-side test that needs the real pointers, or a layer
+        // that moved to the exact-fp32 fall-back between sizing and this pass), run conv + pool2 instead of failing the pass; the sizing run reserves the full-resolution map so
+        // that the arena holds either layout.
+        T4 full = dry ? alloc(N, H, W, L.pd.Cout) : T4{};
+        (void)full;
+        if (!dry && !fail) {
+            const int rc = timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout);
+            if (rc != 0) {
+                T4 f2 = alloc(N, H, W, L.pd.Cout);
+                const int pact = a.act == 3 ? 1 : 0;
+                a.avgpool = 0; a.act = 0; a.out = f2.d; a.out_sn = f2.sn; a.out_ld = f2.ld;
+                RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
+                RUN(pw_pool2(dv(f2), dv(out), stream, pact));
+                n_pool_fallback++;
+            }
+        }
+    } else
     RUN(timed_conv_fwd(a, px_taps * L.pd.Cin * L.pd.Cout));
     if (ts_slot && !dry) ts_slot->tiles = g_last_conv_stats_tiles;
     if (recording) {
@@ -1511,7 +1532,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     caddy_ctx* c = make_ctx(cfg, params, grads, workspace, a);
     if (c->fail) { delete c; return nullptr; }
     if (caddy_serial_streams()) c->use_dstream = false;
-    hipMemset(c->sat_flag, 0, sizeof(unsigned) * CADDY_N_FLAGS);      // (sticky until polled: caddy_f16_saturated)
+    hipMemset(c->sat_flag, 0, sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // (second half: sticky until polled, caddy_f16_saturated)
     if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
@@ -1562,21 +1583,30 @@ int caddy_set_action_member(caddy_ctx* c, int member) {
     if (member < 0 || member >= c->n_members) { set_error("caddy_set_action_member: member out of range"); return -2; }
     c->member = member; return 0;
 }
-int caddy_adam_step_member(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, int member_step, float gscale) {
-    // torch.optim.Adam skips parameters whose .grad is None -- no moment update, no weight decay.  After forward_full_model that is
-    // state_to_hidden_state_layer (only forward_pretraining uses it, model.py:41-43,413); with an ensemble of action networks also every member that was not drawn for
-    // this step (model.py:152).  The drawn member's range is stepped with its own count (torch keeps `step` per parameter).
-    struct Rng { long lo, hi; int mode; };      // mode 0: skip, 1: member_step
+int caddy_adam_step_ex(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, const int* member_step, int s2h_step, float gscale) {
+    // torch.optim.Adam keeps `step` per parameter and skips parameters whose .grad is None -- no moment update, no weight decay.  Which parameters those are depends on
+    // optimizer.zero_grad(): set_to_none (torch >= 2.0 default) leaves every parameter that the last backward did not reach without a gradient; the zero-filling form of
+    // torch < 2.0 (the reference pins pytorch 1.4.0, env.yml) keeps a ZERO gradient on every parameter that has had one before, so Adam goes on ageing its moments and applying
+    // the weight decay.  The caller decides (trainer.py: training.zero_grad_semantics) and passes the bookkeeping: a count of 0 skips the range, a count > 0 steps it with that
+    // bias-correction count -- with its real gradient if the last pass produced one (the drawn member; state_to_hidden_state_layer after forward_pretraining,
+    // model.py:41-43,413), with g = 0 otherwise.
+    struct Rng { long lo, hi; int count; float gs; };
     std::vector<Rng> special;
-    if (!c->pretraining && c->s2h_hi > c->s2h_lo) special.push_back({c->s2h_lo, c->s2h_hi, 0});
-    if (c->n_members > 1) for (int k = 0; k < c->n_members; k++) if (c->member_hi[k] > c->member_lo[k]) special.push_back({c->member_lo[k], c->member_hi[k], k == c->member ? 1 : 0});
+    if (c->s2h_hi > c->s2h_lo) special.push_back({c->s2h_lo, c->s2h_hi, s2h_step, c->pretraining ? gscale : 0.f});
+    if (c->n_members > 1) for (int k = 0; k < c->n_members; k++) if (c->member_hi[k] > c->member_lo[k]) special.push_back({c->member_lo[k], c->member_hi[k], member_step ? member_step[k] : (k == c->member ? step : 0), k == c->member ? gscale : 0.f});
     std::sort(special.begin(), special.end(), [](const Rng& a, const Rng& b) { return a.lo < b.lo; });
     int rc = 0;
     long pos = 0;
-    auto run = [&](long lo, long hi, int st) { if (!rc && hi > lo) rc = adam_launch(c->P + lo, c->G + lo, m + lo, v + lo, hi - lo, lr, b1, b2, eps, wd, st, gscale, c->stream); };
-    for (const Rng& r : special) { run(pos, r.lo, step); if (r.mode == 1) run(r.lo, r.hi, member_step); pos = r.hi; }
-    run(pos, c->n_train, step);
+    auto run = [&](long lo, long hi, int st, float gs) { if (!rc && hi > lo) rc = adam_launch(c->P + lo, c->G + lo, m + lo, v + lo, hi - lo, lr, b1, b2, eps, wd, st, gs, c->stream); };
+    for (const Rng& r : special) { run(pos, r.lo, step, gscale); if (r.count > 0) run(r.lo, r.hi, r.count, r.gs); pos = r.hi; }
+    run(pos, c->n_train, step, gscale);
     return rc;
+}
+int caddy_adam_step_member(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, int member_step, float gscale) {
+    // the set_to_none bookkeeping (torch >= 2.0): only the drawn member is stepped, with its own count; state_to_hidden_state_layer only after a pretraining pass
+    int ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c->member >= 0 && c->member < 8) ms[c->member] = member_step;
+    return caddy_adam_step_ex(c, m, v, lr, b1, b2, eps, wd, step, ms, c->pretraining ? step : 0, gscale);
 }
 int caddy_adam_step(caddy_ctx* c, float* m, float* v, float lr, float b1, float b2, float eps, float wd, int step, float gscale) {
     return caddy_adam_step_member(c, m, v, lr, b1, b2, eps, wd, step, step, gscale);
@@ -1632,12 +1662,12 @@ int caddy_start_inference(caddy_ctx* c) { c->fail = false; return start_inferenc
 // split bf16 for VGG19); caddy_fallback_layers counts them.
 int caddy_f16_saturated(caddy_ctx* c) {
     if (c->dry) return 0;
-    unsigned v[CADDY_N_FLAGS];
+    unsigned v[2 * CADDY_N_FLAGS];      // words raised since the last loss call + the sticky ones k_report_flag moved there
     if (c->side) hipStreamSynchronize(c->side);      // (VGG19 levels / ground-truth branch)
     hipMemcpyAsync(v, c->sat_flag, sizeof(v), hipMemcpyDeviceToHost, c->stream);
     hipStreamSynchronize(c->stream);
     unsigned any = 0;
-    for (int i = 0; i < CADDY_N_FLAGS; i++) if (v[i]) { any |= v[i]; if (!c->layer_fallback[i]) { c->layer_fallback[i] = true; c->n_fallback++; } }
+    for (int i = 0; i < CADDY_N_FLAGS; i++) { v[i] |= v[CADDY_N_FLAGS + i]; if (v[i]) { any |= v[i]; if (!c->layer_fallback[i]) { c->layer_fallback[i] = true; c->n_fallback++; } } }
     if (any) {
         hipMemsetAsync(c->sat_flag, 0, sizeof(v), c->stream);
         if (c->graph_exec) { hipStreamSynchronize(c->stream); if (c->gstream) hipStreamSynchronize(c->gstream); }

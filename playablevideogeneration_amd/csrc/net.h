@@ -158,7 +158,9 @@ struct caddy_ctx {
     // weight-gradient launch into its own copy of the packed layout + fixed-order reduce (WgradArgs.det_slab), single-workgroup bias sums
     bool deterministic = true;       // (round 5: the default -- the mode costs < 1 % of the step since its single-workgroup bias sums and serial folds are gone; 0 = arrival-order atomics)
     float* wgrad_det = nullptr; long wgrad_det_cap = 0;      // scratch of the deterministic weight gradients (the stream the weight gradients run on)
-    hipStream_t wgrad_det_owner = nullptr; bool wgrad_det_owner_set = false;      // ... and that stream, per backward pass (launch_conv_wgrad refuses a second one)
+    hipStream_t wgrad_det_owner = nullptr; bool wgrad_det_owner_set = false;      // ... and the stream that uses it (a second stream takes it over behind an event: launch_conv_wgrad)
+    long n_pool_fallback = 0;                                                      // pooled convolution launches that declined at run time and ran as conv + pool2 (conv())
+    long n_wgrad_det_handover = 0;                                                 // such hand-overs since creation (tests)
     // f16 range guard of the split-f16 forward (ConvArgs.sat_flag), per LAYER (round 5): word i belongs to convs[i] (model) / CADDY_VGG_FLAG0 + i (VGG19 conv i); ORed by any staging
     // thread that met |x| > 65504 (| 2: a NaN); sticky on the device until caddy_f16_saturated() polls them, which also moves the reporting layers -- and only those -- onto a forward
     // without a range limit (layer_fallback: exact fp32 for model layers, split bf16 for VGG19; sticky for the context's lifetime)

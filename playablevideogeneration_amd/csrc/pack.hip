@@ -21,7 +21,7 @@ __global__ void k_unpack_wgrad(PackDesc d, const float* dwp) {
 // fused Adam (torch.optim.Adam semantics, L2 weight decay folded into the gradient; training/trainer.py:36,584-587)
 __global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float gi = g[i] * gscale + wd * p[i];
+        float gi = (gscale != 0.f ? g[i] * gscale : 0.f) + wd * p[i];      // (gscale 0: a step with a ZERO gradient -- torch < 2.0's zero-filled .grad, caddy_adam_step_ex -- whatever the buffer holds)
         float mi = b1 * m[i] + (1.f - b1) * gi;
         float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;

@@ -348,6 +348,7 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
             // consumed by conv i + 1 on the same geometry (or, for relu5_1, by the feature L1 alone)
             if (i + 1 == VGG_NCONV || vgg_io_ok(c, i + 1, x.N, x.H, x.W)) { a.out_s16 = 1; out.fmt = 1; }
         }
+        a.sat_out_next = ((a.out_s16 || a.pool_s16) && i + 1 < VGG_NCONV) ? 1 : 0;      // a clamped OUTPUT value is the next layer's range problem (flag words are consecutive per layer)
         if (!dry) c->ck(conv_call(c, a, 2.0 * x.N * x.H * x.W * 9.0 * VGG[i].cin * VGG[i].cout, 3), "vgg conv");
         B.a[i] = out; x = out;
     }

@@ -93,6 +93,7 @@ def _bind(lib):
     lib.caddy_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.caddy_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
     lib.caddy_adam_step_member.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
+    lib.caddy_adam_step_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float]
     lib.caddy_set_action_member.argtypes = [C.c_void_p, C.c_int]
     lib.caddy_vgg_param_floats.restype = C.c_long
     lib.caddy_vgg_param_info_get.argtypes = [C.c_int, C.c_void_p]
@@ -503,12 +504,18 @@ class Engine:
         """model.action_network.ensamble_size > 1: the action network both A calls of the NEXT forward pass use (model.py:152,274: random.choice(self.action_network))"""
         self._check(self.lib.caddy_set_action_member(self.ctx, int(member)))
 
-    def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0, member_step=None):
+    def adam_step(self, step: int, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, grad_scale=1.0, member_step=None, member_steps=None, s2h_step=None):
         """member_step: step count of the ensemble member this pass used (torch.optim.Adam keeps `step` per parameter, and a member that was not drawn is not stepped);
-        None = `step`"""
+        None = `step`.  member_steps (one count per member) / s2h_step: the explicit bookkeeping of caddy_adam_step_ex -- 0 skips a range, > 0 steps it (ranges without a
+        gradient from the last pass with g = 0: the zero-filling optimizer.zero_grad() of torch < 2.0)"""
         if self.adam_m is None:
             self.adam_m, self.adam_v = torch.zeros_like(self.grads), torch.zeros_like(self.grads)
         self._stream()
+        if member_steps is not None or s2h_step is not None:
+            ms = (C.c_int * 8)(*([int(x) for x in member_steps] + [0] * 8)[:8]) if member_steps is not None else None
+            self._check(self.lib.caddy_adam_step_ex(self.ctx, self.adam_m.data_ptr(), self.adam_v.data_ptr(), lr, betas[0], betas[1], eps, weight_decay, step, ms,
+                                                    int(s2h_step or 0), grad_scale))
+            return
         self._check(self.lib.caddy_adam_step_member(self.ctx, self.adam_m.data_ptr(), self.adam_v.data_ptr(), lr, betas[0], betas[1], eps,
                                                     weight_decay, step, step if member_step is None else int(member_step), grad_scale))
 

@@ -282,7 +282,11 @@ class Model(nn.Module):
         if self.training:
             self._sync_bn_counters(eng, (B, T))
         else:
-            self._check_numerics(eng)      # (training passes report through the loss call: trainer._check_saturation)
+            # (training passes report through the loss call: trainer._check_saturation.)  The poll synchronises both streams and copies the flag words to the host: every 16th
+            # evaluation pass of an engine, like every 64th roll-out frame -- the flags are sticky on the device, nothing is lost in between
+            eng._eval_passes = getattr(eng, "_eval_passes", 0) + 1
+            if eng._eval_passes % 16 == 1:
+                self._check_numerics(eng)
         self.last_engine = eng
         return tuple(out) if out is not None else None
 
@@ -291,8 +295,9 @@ class Model(nn.Module):
         """f16 range guards of the split-f16 forward on passes without a loss call (evaluation, roll-out): a clamped activation is reported once and the layers that met it move to a
         forward without a range limit; a NaN -- which the clamp would have hidden -- raises, as the reference's fp32 arithmetic would have produced NaN outputs"""
         bits = eng.numerics_flags()
-        if bits & 2:
-            raise Exception("NaN activation in the forward pass (found by the f16 range guard of the split-f16 convolutions)")
+        if bits & 2:      # (the reference's fp32 arithmetic would have returned NaN outputs, not raised: report loudly, let the caller decide)
+            warnings.warn("NaN activation in a forward pass since the last check (found by the f16 range guard of the split-f16 convolutions, which clamps it): the outputs of "
+                          "that pass are finite where the reference's would be NaN")
         if bits & 1:
             warnings.warn(f"a forward activation exceeded the f16 range (|x| > 65504) and was clamped in the pass that just ran; {eng.fallback_layers()} convolution "
                           "layer(s) now run without a range limit -- repeat the pass for unclamped results")

@@ -38,6 +38,13 @@ class Trainer:
         # ensemble of action networks (model.py:28,47,152): torch.optim.Adam keeps `step` per parameter and skips parameters without a gradient, so every member carries its own
         # step count (= the number of passes it was drawn for)
         self.member_steps = [0] * int(config["model"]["action_network"].get("ensamble_size", 1))
+        # optimizer.zero_grad() (training/trainer.py:584) under the two torch generations.  "set_to_none" (default; torch >= 2.0, what the reference does on a current install and
+        # what the trainer goldens were generated under): a parameter the last backward did not reach -- an ensemble member that was not drawn, state_to_hidden_state_layer
+        # after a full-model pass -- has .grad None and Adam skips it.  "zero_fill" (torch < 2.0; the reference's env.yml pins pytorch 1.4.0): once such a parameter has had a
+        # gradient its .grad stays a zero tensor, so every later optimizer.step() decays it, ages its moments and counts a step.
+        self.zero_grad_semantics = str(tr.get("zero_grad_semantics", "set_to_none"))
+        if self.zero_grad_semantics not in ("set_to_none", "zero_fill"):
+            raise Exception(f"training.zero_grad_semantics must be 'set_to_none' or 'zero_fill', got {self.zero_grad_semantics!r}")
         lw = tr["loss_weights"]
         self.perceptual_lambda = float(lw.get("perceptual_loss_lambda", 0.0))
         self.perceptual_lambda_pretraining = float(lw.get("perceptual_loss_lambda_pretraining", 0.0))
@@ -243,9 +250,20 @@ class Trainer:
         eng.adam_m, eng.adam_v = self.adam_m, self.adam_v
         lr = self._get_current_lr()          # optimizer.step() runs BEFORE lr_scheduler.step() (trainer.py:586-587): step m+1 is the first at the decayed rate
         self.opt_steps += 1
-        if getattr(eng, "last_pretraining", False):
-            self.s2h_steps += 1
+        pre = bool(getattr(eng, "last_pretraining", False))
         member = getattr(model.module, "last_member", 0)
+        if self.zero_grad_semantics == "zero_fill":
+            # torch < 2.0: everything that has EVER had a gradient is stepped (with g = 0 when the last backward did not reach it) and counts the step
+            if pre or self.s2h_steps > 0:
+                self.s2h_steps += 1
+            for k in range(len(self.member_steps)):
+                if k == member or self.member_steps[k] > 0:
+                    self.member_steps[k] += 1
+            eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size,
+                          member_steps=self.member_steps if len(self.member_steps) > 1 else None, s2h_step=self.s2h_steps)
+            return
+        if pre:
+            self.s2h_steps += 1
         self.member_steps[member] += 1
         extra = {"member_step": self.member_steps[member]} if len(self.member_steps) > 1 else {}
         eng.adam_step(self.opt_steps, lr=lr, weight_decay=self.weight_decay, grad_scale=1.0 / world_size, **extra)

@@ -224,7 +224,7 @@ def slope_flip_record(name, lib, dev, max_flips=4, candidates=24, done=5e-3):
         flips.append((best[1], best[2]))
         chosen.append(dict(lrelu_call=best[1], shape=best[5], flat_index=best[2], value_fp64=best[3], tensor_rms=best[4], value_over_rms=best[6], rel_l2_after=best[0]))
     rec = dict(rel_l2_before=before, rel_l2_after=cur, flips=chosen)
-    assert cur <= done and cur <= before / 4, rec
+    assert cur <= done and (not chosen or cur <= before / 4), rec      # (no flip needed when this build's forward round-off happens to fall on the oracle's side everywhere)
     return rec
 
 
@@ -445,9 +445,9 @@ def oracle_case(lib, dev, c, fwd_tol=3e-4):
     assert torch.isfinite(eng.grads).all()
 
 
-def oracle_grad_case(lib, dev, c, fwd_tol=3e-4, grad_floor=5e-3, plain_mi=False):
+def oracle_grad_case(lib, dev, c, fwd_tol=3e-4, grad_floor=5e-3, plain_mi=False, factor=2.0):
     """An ad-hoc geometry end to end WITHOUT a golden: all 20 outputs (action indices bit-exact), frame MSE, every loss term, and the gradients against an fp64 run of the oracle
-    with full_case's criterion -- relative L2 error <= max(2 x the fp32 oracle's own error, grad_floor), worst per-parameter error <= max(5 x the oracle's, 1e-1).  plain_mi: the
+    with full_case's criterion -- relative L2 error <= max(factor x the fp32 oracle's own error, grad_floor), worst per-parameter error <= max(5 x the oracle's, 1e-1).  plain_mi: the
     MutualInformationLoss of `training.trainer` (configs/03_tennis.yaml:61) instead of the smooth estimator."""
     if plain_mi:
         c = dict(c, mi="plain")
@@ -482,7 +482,7 @@ def oracle_grad_case(lib, dev, c, fwd_tol=3e-4, grad_floor=5e-3, plain_mi=False)
         worst_h, worst_o = max(worst_h, (g - g64).abs().max().item() / s), max(worst_o, (g32 - g64).abs().max().item() / s)
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
-    assert rel_h <= max(2 * rel_o, grad_floor), ("relative L2 gradient error vs fp64", rel_h, rel_o)
+    assert rel_h <= max(factor * rel_o, grad_floor), ("relative L2 gradient error vs fp64", rel_h, rel_o)
     assert worst_h <= max(5 * worst_o, 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
     return eng, dict(frame_mse=mse, rel_l2_hip=rel_h, rel_l2_oracle32=rel_o, worst_hip=worst_h, worst_oracle32=worst_o)
 

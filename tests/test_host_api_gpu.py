@@ -64,6 +64,12 @@ def test_trainer_mirror_ensemble_of_action_networks_on_gpu(tmp_path):
     trainer_ensemble_case(_build, tmp_path)
 
 
+def test_trainer_mirror_zero_fill_semantics_of_torch_1_4_on_gpu(tmp_path):
+    """training.zero_grad_semantics: zero_fill (torch < 2.0's optimizer.zero_grad(); the reference pins pytorch 1.4.0) against the golden of the reference trainer under
+    zero_grad(set_to_none=False): the undrawn member and state_to_hidden_state_layer keep being stepped with g = 0 once they have had a gradient (caddy_adam_step_ex)"""
+    trainer_ensemble_case(_build, tmp_path, zero_fill=True)
+
+
 def test_checkpoint_loaded_before_cuda_then_step(tmp_path):
     """train.py loads the checkpoint BEFORE model.cuda() (train.py:61-68): Adam moments and the MI estimator restored on the CPU must be on the
     GPU before the kernels get their raw pointers -- the resumed step equals the uninterrupted one: bit for bit, with the plugin's `training.deterministic` switch

@@ -34,12 +34,17 @@ def test_full_model_parity_atomic_backward(lib, name):
 def test_full_model_parity_config_branches(lib, name):
     """reference configuration branches outside the BAIR / Breakout YAMLs: the plain MutualInformationLoss of `training.trainer` (03_tennis.yaml,
     caddy_loss_cfg.mi_ema = NULL), use_gumbel: False, use_variations: False, ensamble_size: 2 (member 1 drawn by random.choice, model.py:152) -- forward, losses, gradients
-    against goldens of the reference itself.  (use_gumbel: False at this seed has a LeakyReLU pre-activation within the forward round-off of zero in D: the HIP forward and the
-    oracle take different slopes there and the whole upstream gradient shifts by 1e-2 -- measured 9.7e-3, run-to-run identical; see full_case's docstring -- hence its floor.
-    use_variations: False since round 5, when the 16-channel layers moved to the split-operand kernels: every parameter of the ACTION network -- and no other -- is 2.1 - 3.4 % off fp64
-    (1.2e-2 overall, run-to-run identical; CADDY_TEST_VERBOSE=1 prints them): one slope decision in A on this golden's 8 frames of tiny maps, spread over the network by its
-    train-mode BatchNorms.  The kernels themselves agree with fp64 to 2e-6 / 1e-4 at those shapes (test_conv_hx_16_channel_layers), single-step graphs to 2e-5 per parameter
-    (test_single_step_gradients_tight) and the BAIR-geometry gradients stay inside their bound.)"""
+    against goldens of the reference itself.  Two of them carry a 2e-2 floor on the relative L2 gradient error instead of 5e-3, because LeakyReLU'(x) jumps from 0.2 to 1 at
+    x = 0 and these tiny goldens (2 samples, 4 x 4 ... 8 x 8 maps, train-mode BatchNorm) each have one pre-activation that the fp64 oracle puts within the forward round-off of
+    zero; which side an fp32 forward lands on depends on its summation order.  The offset is NOT taken on trust: test_gradient_offset_of_the_2e2_floor_goldens_is_a_slope_decision
+    finds the element and shows that the fp64 oracle with that ONE element on the other slope reproduces the HIP gradients to the tight bound.  Element-level record (round 6,
+    MI355X, run-to-run identical):
+      full_reduced_s1_novar: 1.2005e-2 -> 2.26e-5 with one flip -- oracle._lrelu call 49 (action network, tensor (2, 65, 4, 4)), flat index 1252, fp64 value +1.12e-5 = 7.8e-6 of
+        the tensor's rms 1.43 (the split-operand forward of the 16-channel layers lands at <= 0 there); every parameter of the ACTION network and no other had been 2.1 - 3.4 % off;
+      full_main_s1_nogumbel: 9.7e-3 in rounds 3 - 5 (a pre-activation of D); with round 6's 7x7 head kernel the fed-back frames round differently, no decision flips and the
+        error is 2.2e-3 (oracle32: 1.8e-4) -- the floor stays at 2e-2 because any change of summation order can bring the flip back, and the slope-decision test then has to explain it.
+    The kernels themselves agree with fp64 to 2e-6 / 1e-4 at those shapes (test_conv_hx_16_channel_layers), single-step graphs to 2e-5 per parameter
+    (test_single_step_gradients_tight) and the BAIR-geometry gradients stay inside their bound."""
     _, info = M.full_case(name, lib, "cuda", grad_floor=2e-2 if name in ("full_main_s1_nogumbel", "full_reduced_s1_novar") else 5e-3)
     print(name, info)
 
@@ -113,15 +118,18 @@ def test_tennis_native_geometry_vs_oracle(lib, batch):
     """The reference's OWN Tennis geometry (configs/03_tennis.yaml: crop [0, 0, 256, 96], state_resolution [12, 32], observation_stacking 4, action_space_dimension 5,
     batch_size 6, observations_count_start 7, trainer = training.trainer i.e. the plain MutualInformationLoss): state maps 12 x 32 -> 6 x 16 leave ragged 8 x 16 pixel tiles in
     both directions at once (12 = 8 + 4 rows; 6 rows) and odd pooled widths in A.  gt = 3 of T = 7 so that four steps run closed-loop.  All 20 outputs, action indices, every
-    loss term and the fp64 gradient bound of the golden cases."""
-    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=batch, T=7, gt=3), plain_mi=True)
+    loss term and the fp64 gradient bound.  The bound: the golden cases use max(2 x the fp32 oracle's own distance to fp64, 5e-3); the oracle's distance is ONE sample of fp32
+    round-off through four closed-loop steps of train-mode BatchNorm (conditioning, not a constant), the HIP path is another sample with a different summation order and split
+    operands, and at this geometry the ratio was measured at 1.47 (B = 6: 8.5e-3 vs 5.8e-3), 2.03 (B = 2: 7.4e-3 vs 3.7e-3) and 1.40 (gt = 6, next test) -- so 3 x here; a wrong or
+    missing term in a kernel only these ragged tiles reach is O(0.1 - 1)."""
+    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=batch, T=7, gt=3), plain_mi=True, factor=3.0)
     print(info)
     torch.cuda.empty_cache()
 
 
 def test_tennis_native_geometry_smooth_mi_and_rollout(lib):
     """the same frames with the smooth MI estimator (training.smooth_mi_trainer) at the YAML's gt = 6, and a 16-frame roll-out at 256 x 96 (play.py path), every frame vs the oracle"""
-    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=2, T=7, gt=6))
+    eng, info = M.oracle_grad_case(lib, "cuda", dict(TENNIS_NATIVE, B=2, T=7, gt=6), factor=3.0)
     print(info)
     print(M.rollout_oracle_case(lib, "cuda", TENNIS_NATIVE, steps=16))
     torch.cuda.empty_cache()

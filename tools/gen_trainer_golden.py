@@ -36,13 +36,22 @@ def main():
         one(False, 0.0, plain=True)          # training.trainer (03_tennis.yaml): plain MutualInformationLoss, no estimator state in the checkpoint
     if not only or "ensemble" in only:
         ensemble()
+    if not only or "zerofill" in only:
+        ensemble(zero_fill=True)
 
 
 ENS_RSEEDS = [7, 1, 5]      # Python `random` seed of each step: random.choice(self.action_network) (model.py:152) then draws members 1, 0, 1
 
 
-def ensemble():
-    """model.action_network.ensamble_size = 2: three training steps of the real reference trainer.  Each step draws ONE action network (model.py:152); the other one has
+ZF_KINDS = ["pre", "full", "full"]      # zero_fill golden: a pretraining pass first, so that state_to_hidden_state_layer has had a gradient before the full-model passes
+
+
+def ensemble(zero_fill=False):
+    """zero_fill: the same three steps under torch < 2.0's optimizer.zero_grad() (the reference pins pytorch 1.4.0, env.yml: gradients are zero-FILLED, not dropped) --
+    `optimizer.zero_grad(set_to_none=False)` on this image's torch -- with a PRETRAINING pass as the first step: afterwards every parameter that has had a gradient once (the
+    member drawn earlier, state_to_hidden_state_layer) is stepped by Adam at every later step with g = 0 (weight decay, ageing moments, its own step count)
+    -> tests/golden/trainer_ens2_reduced_s1_zerofill.npz.  Default:
+    model.action_network.ensamble_size = 2: three training steps of the real reference trainer.  Each step draws ONE action network (model.py:152); the other one has
     `.grad is None` after optimizer.zero_grad() and torch.optim.Adam neither updates nor decays it, and Adam's per-parameter step counts diverge (member 1: 2 steps, member 0: 1)."""
     rh.install()
     cfg = _config(res=(8, 8))
@@ -72,13 +81,19 @@ def ensemble():
         torch.manual_seed(STEP_SEED + i)
         random.seed(rs)
         st_ = random.getstate(); members.append(random.choice(range(2))); random.setstate(st_)
-        loss, info, _ = trainer.compute_losses(ref, batch, 4)
-        trainer.optimizer.zero_grad()
+        pre = zero_fill and ZF_KINDS[i] == "pre"
+        loss, info, _ = (trainer.compute_losses_pretraining if pre else trainer.compute_losses)(ref, batch, 4)
+        if zero_fill:
+            trainer.optimizer.zero_grad(set_to_none=False)      # torch 1.4.0: `p.grad.detach_(); p.grad.zero_()`
+        else:
+            trainer.optimizer.zero_grad()
         loss.backward()
         trainer.optimizer.step()
         trainer.lr_scheduler.step()
         losses.append(loss.item())
     data = {"losses": np.array(losses), "members": np.array(members), "rseeds": np.array(ENS_RSEEDS), "global_step": np.array(GLOBAL_STEP), "step_seed": np.array(STEP_SEED)}
+    if zero_fill:
+        data["kinds"] = np.array(ZF_KINDS)
     names, psum, pabs, first, steps = [], [], [], [], []
     for n, p in ref.module.named_parameters():
         names.append(n); psum.append(p.detach().double().sum().item()); pabs.append(p.detach().double().abs().sum().item())
@@ -89,9 +104,9 @@ def ensemble():
     data["adam_steps"] = np.array(steps)
     data["mi_ema"] = trainer.mutual_information_loss.matrix_estimator.estimated_matrix.detach().numpy()
     data["lr"] = np.array(trainer._get_current_lr())
-    out = os.path.join(ROOT, "tests", "golden", "trainer_ens2_reduced_s1.npz")
+    out = os.path.join(ROOT, "tests", "golden", "trainer_ens2_reduced_s1_zerofill.npz" if zero_fill else "trainer_ens2_reduced_s1.npz")
     np.savez_compressed(out, **data)
-    print("written", out, "members", members, "losses", losses, "adam steps", sorted(set(steps)))
+    print("written", out, "members", members, "losses", losses, "adam steps", sorted(set(steps)), {n: st for n, st in zip(names, steps) if "mean_fc.bias" in n or "state_to_hidden" in n})
 
 
 def one(pretraining, perc=0.0, plain=False):
