@@ -80,27 +80,29 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
     const float xsl = sg.bn_act ? 0.2f : 1.f;
     float4 rx[WG_HH + 1], ry[WG_TH];
     float4 rxs, rxh;                                          // lazily applied BatchNorm of the X source (ConvSrc.bn_*): scale / shift of this thread's four channels, tile in flight
+    long bnoff = 0;                                           // ... their offset in the (scale, shift) tables (set by WG_LOAD_X; the values are requested later, WG_LOAD_BN)
     int fy0 = 0, fx0 = 0;                                     // origin of the tile in flight (set by WG_LOAD, consumed by WG_STORE one iteration later)
 
     // loads only (clamped addresses): the zero-padding / tail selects are applied by WG_STORE one tile later, so that nothing waits for these
     // loads while the current tile's MFMAs run
-#define WG_LOAD(tile_)                                                                                                              \
-    do {                                                                                                                            \
+#define WG_TILE_ORIGIN(tile_)                                                                                                      \
         int n_ = (tile_) / (tiles_x * tiles_y);                                                                                    \
         const int rem_ = (tile_) - n_ * tiles_x * tiles_y;                                                                         \
         const int ty_ = rem_ / tiles_x;                                                                                            \
-        fy0 = ty_ * WG_TH; fx0 = (rem_ - ty_ * tiles_x) * WG_TW;                                                                   \
-        const int xc_ = fx0 - 1 + p0, yx_ = fx0 + p0;           /* this thread's halo / tile column */                            \
-        const bool xv_ = cok && xc_ >= 0 && xc_ < a.W, yv_ = yok && yx_ < a.W;                                                     \
+        const int gy0_ = ty_ * WG_TH, gx0_ = (rem_ - ty_ * tiles_x) * WG_TW;
+#define WG_LOAD_X(tile_)                                                                                                            \
+    do {                                                                                                                            \
+        WG_TILE_ORIGIN(tile_)                                                                                                      \
+        fy0 = gy0_; fx0 = gx0_;                                                                                                    \
+        const int xc_ = fx0 - 1 + p0;                           /* this thread's halo column */                                    \
+        const bool xv_ = cok && xc_ >= 0 && xc_ < a.W;                                                                             \
         const int y6_ = fy0 - 1 + hy6, x6_ = fx0 - 1 + hx6;                                                                        \
         const bool v6_ = cok && p0 < 2 * WG_HH && y6_ >= 0 && y6_ < a.H && x6_ < a.W;                                              \
         const float* xp_ = sg.p;                                                                                                   \
-        const float* dyb_ = a.dy;                                                                                                  \
         long bo_ = cok ? cx : 0;                                                                                                   \
-        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * sgs; dyb_ += grp_ * a.dy_gs; bo_ += grp_ * sbgs; } \
+        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; xp_ += grp_ * sgs; bo_ += grp_ * sbgs; }     \
         bo_ += (long)(int)(((float)n_ + 0.5f) * inv_bn_gn) * sg.bn_gs;                                                             \
-        rxs = *reinterpret_cast<const float4*>(xbn ? sg.bn_scale + bo_ : sg.p);      /* (clamped to a valid address without BatchNorm) */ \
-        rxh = *reinterpret_cast<const float4*>(xbn ? sg.bn_shift + bo_ : sg.p);                                                    \
+        bnoff = bo_;                                                                                                               \
         const float* xb_ = xp_ + (long)n_ * sg.sn + (cok ? cx : 0);                                                                \
         const int xo_ = (fy0 - 1) * xrow + (xv_ ? xc_ * xpl : 0);                                                                   \
         _Pragma("unroll") for (int i = 0; i < WG_HH; i++) {                                                                        \
@@ -108,10 +110,25 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
             rx[i] = *reinterpret_cast<const float4*>(xb_ + (unsigned)((y_ >= 0 && y_ < a.H) ? xo_ + i * xrow : 0));               \
         }                                                                                                                          \
         rx[WG_HH] = *reinterpret_cast<const float4*>(xb_ + (unsigned)(v6_ ? y6_ * xrow + x6_ * xpl : 0));                         \
+    } while (0)
+    // (scale, shift) of the tile in flight: two L2-resident float4, clamped to a valid address without BatchNorm
+#define WG_LOAD_BN()                                                                                                                \
+    do {                                                                                                                            \
+        rxs = *reinterpret_cast<const float4*>(xbn ? sg.bn_scale + bnoff : sg.p);                                                  \
+        rxh = *reinterpret_cast<const float4*>(xbn ? sg.bn_shift + bnoff : sg.p);                                                  \
+    } while (0)
+    // the dY rows of the tile in flight: requested in the tail of the MFMA phase (the registers of the A fragments that are done serve them), consumed after the X rows
+#define WG_LOAD_Y(tile_, i0_, i1_)                                                                                                            \
+    do {                                                                                                                            \
+        WG_TILE_ORIGIN(tile_)                                                                                                      \
+        const int yx_ = gx0_ + p0;                              /* this thread's tile column */                                    \
+        const bool yv_ = yok && yx_ < a.W;                                                                                         \
+        const float* dyb_ = a.dy;                                                                                                  \
+        if (a.group_n > 0) { const int grp_ = n_ / a.group_n; n_ -= grp_ * a.group_n; dyb_ += grp_ * a.dy_gs; }                    \
         const float* yb_ = dyb_ + (long)n_ * a.dy_sn;               /* scalar */                                                   \
-        const int yo_ = fy0 * yrow + (yok ? yc : 0) + (yv_ ? yx_ * a.dy_ld : 0);                                                   \
-        _Pragma("unroll") for (int i = 0; i < WG_TH; i++)                                                                          \
-            ry[i] = *reinterpret_cast<const float4*>(yb_ + (unsigned)(fy0 + i < a.H ? yo_ + i * yrow : (yok ? yc : 0)));           \
+        const int yo_ = gy0_ * yrow + (yok ? yc : 0) + (yv_ ? yx_ * a.dy_ld : 0);                                                  \
+        _Pragma("unroll") for (int i = (i0_); i < (i1_); i++)                                                                      \
+            ry[i] = *reinterpret_cast<const float4*>(yb_ + (unsigned)(gy0_ + i < a.H ? yo_ + i * yrow : (yok ? yc : 0)));          \
     } while (0)
     // value -> (hi, lo) halves of four channels, stored at dst_ / dst_ + 64.  bf16: one packed conversion per pair, the high halves re-expanded by shift / mask (16 VALU
     // per float4 incl. the four selects; the generic form converts every high half twice)
@@ -178,32 +195,58 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
     const int yoff = prow * WG_PITCH + (RSPLIT ? 0 : wm * 32) + ccol;
     const int xoff = prow * WG_PITCH + wn * 32 + ccol;
 
+    // MFMA phase, halo-row-major (round 6).  The former order -- tile row r, tap (dy, dx): four fragment reads, three dependent MFMAs, the next tap's reads into the SAME registers --
+    // read every X fragment three times (halo row h serves (r, dy) = (h, 0), (h - 1, 1), (h - 2, 2)) and exposed one LDS round trip per tap: ~12 000 cycles per tile against
+    // 3456 of matrix work.  Now the A fragments of the wave's NR tile rows are read once and kept, the X fragments of halo row h / column shift dx are read once (two register
+    // sets: the next one is in flight while this one multiplies) and feed up to three taps -- independent accumulators back to back, no dependent pair adjacent: 88 instead
+    // of 160 fragment reads per tile and wave.
+    constexpr int NR = RSPLIT ? WG_TH / 2 : WG_TH, NH = NR + 2;
+    const int rbase = RSPLIT ? wm * NR : 0;                    // first tile row of this wave (wave-uniform)
+    const T* const ybase = Yt + rbase * (WG_TW * WG_PITCH) + yoff;
+    const T* const xbase = Xh + rbase * (WG_HW * WG_PITCH) + xoff;
+
     int tile = (int)blockIdx.z;
-    if (tile < ntiles) WG_LOAD(tile);
+    if (tile < ntiles) { WG_LOAD_X(tile); WG_LOAD_BN(); WG_LOAD_Y(tile, 0, WG_TH); }
     for (; tile < ntiles; tile += (int)gridDim.z) {
         WG_STORE();
         __syncthreads();
-        if (tile + (int)gridDim.z < ntiles) WG_LOAD(tile + (int)gridDim.z);
-#pragma unroll 1
-        for (int r = RSPLIT ? wm * (WG_TH / 2) : 0; r < (RSPLIT ? (wm + 1) * (WG_TH / 2) : WG_TH); r++) {
-            const T* yb = Yt + r * WG_TW * WG_PITCH + yoff;
-            const v8 ah = tr_frag<T>(yb, 0, 4 * WG_PITCH), al = tr_frag<T>(yb, 64, 4 * WG_PITCH + 64);
+        // next tile (unconditional, no branch inside the MFMA sequence: past the end the current tile is requested again, unused)
+        const int ntile = tile + (int)gridDim.z < ntiles ? tile + (int)gridDim.z : tile;
+        WG_LOAD_X(ntile);
+        v8 ah[NR], al[NR], bh[2], bl[2];
 #pragma unroll
-            for (int dy = 0; dy < 3; dy++)
+        for (int r = 0; r < NR; r++) { ah[r] = tr_frag<T>(ybase + r * (WG_TW * WG_PITCH), 0, 4 * WG_PITCH); al[r] = tr_frag<T>(ybase + r * (WG_TW * WG_PITCH), 64, 4 * WG_PITCH + 64); }
+        bh[0] = tr_frag<T>(xbase, 0, 4 * WG_PITCH); bl[0] = tr_frag<T>(xbase, 64, 4 * WG_PITCH + 64);
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) {
-                    const T* xb = Xh + ((r + dy) * WG_HW + dx) * WG_PITCH + xoff;
-                    const v8 bh = tr_frag<T>(xb, 0, 4 * WG_PITCH), bl = tr_frag<T>(xb, 64, 4 * WG_PITCH + 64);
+        for (int idx = 0; idx < NH * 3; idx++) {
+            const int h = idx / 3, dx = idx - 3 * h, cur = idx & 1;
+            if (idx + 1 < NH * 3) {
+                const int h1 = (idx + 1) / 3, dx1 = (idx + 1) - 3 * h1;
+                const T* xb = xbase + (h1 * WG_HW + dx1) * WG_PITCH;
+                bh[cur ^ 1] = tr_frag<T>(xb, 0, 4 * WG_PITCH); bl[cur ^ 1] = tr_frag<T>(xb, 64, 4 * WG_PITCH + 64);
+            }
+            // the rest of the next tile is requested as the A fragments retire (tile row r is last used by halo row r + 2): no register is held for it before
+            if (idx == (NH - 3) * 3) WG_LOAD_BN();
+            if (idx == (NH - 2) * 3) WG_LOAD_Y(ntile, 0, WG_TH / 2);
+            if (idx == (NH - 1) * 3) WG_LOAD_Y(ntile, WG_TH / 2, WG_TH);
+            // taps served by this fragment: dy = h - r for every tile row r of the wave with 0 <= dy <= 2; product-major so that consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const int r = h - dy;
+                    if (r < 0 || r >= NR) continue;
                     f32x16 c = acc[dy * 3 + dx];
-                    c = mfma16(al, bh, c);
-                    c = mfma16(ah, bl, c);
-                    c = mfma16(ah, bh, c);
+                    c = pr == 0 ? mfma16(al[r], bh[cur], c) : (pr == 1 ? mfma16(ah[r], bl[cur], c) : mfma16(ah[r], bh[cur], c));
                     acc[dy * 3 + dx] = c;
                 }
         }
         __syncthreads();
     }
-#undef WG_LOAD
+#undef WG_LOAD_X
+#undef WG_LOAD_Y
+#undef WG_LOAD_BN
+#undef WG_TILE_ORIGIN
 #undef WG_STORE
 #undef WG_SPLIT_STORE
 #undef WG_X_ELEM
