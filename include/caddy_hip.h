@@ -263,6 +263,12 @@ int caddy_debug_set_bn_paths(caddy_ctx* ctx, int small, int lazy, int epilogue_s
 /* tests / A-B runs: 0 keeps every VGG19 feature map of the perceptual loss (training/losses.py:379-491, model/layers/vgg.py:20-36) as an fp32 tensor; 1 (default) lets well-filled
  * layers exchange them pre-split for the 16-bit matrix pipe ("S16" tensors, csrc/common.h).  Same convolution results bit for bit; the feature L1 sees hi + lo (2^-22 relative). */
 int caddy_debug_set_vgg_s16(caddy_ctx* ctx, int on);
+/* tests / A-B runs (round 6): 0 keeps the gradient of every convolution output (the dY of model/layers/residual_block.py:49-68, same_block.py:34-47, up_block.py:31-45,
+ * convolutional_lstm_cell.py:92-101) as an fp32 tensor; 1 (default) lets the point-wise backward kernel that produces it write it pre-split (S16-bf16) where the dgrad, the weight
+ * gradient and the bias / broadcast-input sums that read it understand the format.  Same matrix operands bit for bit; the column sums see hi + lo (2^-17 relative).
+ * caddy_debug_s16_grad_count: how many gradient tensors of the last caddy_loss_backward travelled pre-split. */
+int caddy_debug_set_s16_grads(caddy_ctx* ctx, int on);
+long caddy_debug_s16_grad_count(caddy_ctx* ctx);
 int caddy_debug_set_pack_merged(caddy_ctx* ctx, int on);      /* tests: 0 = one (un)packing launch per layer and form instead of the job-table launch */
 int caddy_debug_dims(caddy_ctx* ctx, int i, int* nhwc4);
 int caddy_debug_get(caddy_ctx* ctx, int i, int grad, float* dst_nchw);

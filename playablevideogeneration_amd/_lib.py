@@ -13,7 +13,7 @@ CONV_BK = 16
 
 
 class TV(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("sn", C.c_long), ("ld", C.c_int)]
+    _fields_ = [("p", C.c_void_p), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("sn", C.c_long), ("ld", C.c_int), ("s16", C.c_int)]      # s16: csrc/common.h (pre-split gradient)
 
 
 class ConvSrc(C.Structure):
@@ -43,7 +43,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("src", ConvSrc * CONV_MAX_SRC), ("nsrc", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int),
                 ("dy", C.c_void_p), ("dy_sn", C.c_long), ("dy_ld", C.c_int), ("Cout", C.c_int), ("Cout_pad", C.c_int), ("Ktot", C.c_int),
                 ("dwp", C.c_void_p), ("slabs", C.c_int), ("group_n", C.c_int), ("src_gs", C.c_long * CONV_MAX_SRC), ("dy_gs", C.c_long), ("precision", C.c_int),
-                ("src_bn_gs", C.c_long * CONV_MAX_SRC), ("det_slab", C.c_void_p), ("det_cap", C.c_long), ("det_stride", C.c_long)]
+                ("src_bn_gs", C.c_long * CONV_MAX_SRC), ("det_slab", C.c_void_p), ("det_cap", C.c_long), ("det_stride", C.c_long), ("dy_s16", C.c_int)]
 
 
 class PackDesc(C.Structure):

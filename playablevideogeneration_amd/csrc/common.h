@@ -19,6 +19,11 @@ struct TV {
     int N, H, W, C;
     long sn;
     int ld;
+    // 1: an S16-bf16 tensor (see ConvArgs.in_s16: [hi x 32 | lo x 32] halves per 32-channel chunk, same geometry and footprint) -- round 6: the gradient of a convolution's
+    // output, written ONCE in that form by its point-wise producer (BatchNorm / pooling / ConvLSTM-cell backward) and copied instead of converted by the dgrad and weight-gradient
+    // launches that stage it.  Understood by the kernels that produce / read such gradients only (pointwise.hip: the functors with *_s16 in their comment); C a multiple of 32.
+    // (occupies what was tail padding: the struct's size and the offsets of the other members are unchanged)
+    int s16;
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -170,6 +175,7 @@ struct WgradArgs {
     float* det_slab;
     long det_cap;
     long det_stride;
+    int dy_s16;         // dy is an S16-bf16 tensor (TV::s16): k_wgrad_hx stages it with 16-byte copies; no other weight-gradient kernel understands it (Cout a multiple of 32)
 };
 // destination of a pixel split's flush (see WgradArgs.det_slab): exactly one workgroup adds to an element of a slab
 #define WGRAD_DST(a_, split_) ((a_).det_slab ? (a_).det_slab + (long)(split_) * (a_).det_stride : (a_).dwp)

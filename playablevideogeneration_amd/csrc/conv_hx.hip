@@ -669,22 +669,26 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st, bool dry) {
     // 4-wave variants: 3-deep register ring of weight tiles (with one step of prefetch the next tile has ~0.4 us to arrive from L2, less than its latency under load; measured,
     // E/R/A/D step: ring on launches of <= 256 / 512 / 1024 workgroups / always: 77.2 / 75.5 / 75.8 / 75.5 ms, batch-1 roll-out frame -3 %).  The single-product study
     // precisions (PREC_*X1, tools/bench_hx.py) keep one step of prefetch.
-#define HX_LAUNCH(T_, NPL_, EP_)                                                                                                  \
+#define HX_LAUNCH(T_, NPL_, EP_, IO_)                                                                                             \
     do {                                                                                                                          \
         constexpr int D_ = NPL_ == 2 ? 3 : 1;                                                                                     \
-        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_>), grid, dim3(512), 0, st, a, tx, ty);    \
-        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (th4) hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0>), grid, dim3(256), 0, st, a, tx, ty);       /* (plain epilogue only) */ \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);    \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty); \
-        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_>), grid, dim3(256), 0, st, a, tx, ty);                  \
+        if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_, IO_>), grid, dim3(512), 0, st, a, tx, ty);    \
+        else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (th4) hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0, IO_>), grid, dim3(256), 0, st, a, tx, ty);       /* (plain epilogue only) */ \
+        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);    \
+        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty); \
+        else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);                  \
     } while (0)
     if (a.avgpool && !a.split_stride) return dry ? 0 : -1;      // (a whole-K tile launch has no pooled epilogue)
     if (dry) return 1;
     const bool vgg_bwd = a.mask != nullptr;      // ReLU mask / L1 seed epilogue (VGG19 dgrad chain): split-bf16 instances with EP = 2
     const int io = (a.in_s16 ? 1 : 0) | ((a.out_s16 || a.pool_s16) ? 2 : 0);
-    if (io) {      // S16 tensors at the boundary: the two well-filled tile variants only (conv_hx_s16_ok), whole-K workgroups, plain or VGG19 epilogues
+    // round 6: a PRE-SPLIT input alone (the model's gradient tensors, written as S16-bf16 by their point-wise producers) is a property of the loader only: every split-bf16 tile
+    // variant has such an instance, with the full plain epilogue (accumulate, K split, slabs) -- handled by the general launch below
+    const bool ps_grad = io == 1 && a.precision == PREC_BF16X3 && !vgg_bwd && !a.pool_out && !a.skip_out;
+    if (ps_grad && (a.nsrc != 1 || (a.src[0].C & 31) || a.src[0].bcast || a.src[0].bn_scale)) return -1;
+    if (io && !ps_grad) {      // S16 tensors at the boundary: the two well-filled tile variants only (conv_hx_s16_ok), whole-K workgroups, plain or VGG19 epilogues
         const bool wide = big || (bn == 64 && !small_tiles);
         if (!wide || a.splitk != 1 || a.accumulate || a.res || a.stats || (a.precision != PREC_F16X3 && a.precision != PREC_BF16X3)) return -1;
         if (a.in_s16 && (a.nsrc != 1 || (a.src[0].C & 31) || a.src[0].bcast || a.src[0].bn_scale)) return -1;
@@ -722,13 +726,13 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st, bool dry) {
     switch (a.precision) {
         case PREC_F16X3:
             if (vgg_bwd) return -1;      // (masks exist on the gradient side only)
-            HX_LAUNCH(_Float16, 2, 0);
+            HX_LAUNCH(_Float16, 2, 0, 0);
             break;
         case PREC_BF16X3:
-            if (vgg_bwd) HX_LAUNCH(__bf16, 2, 2); else HX_LAUNCH(__bf16, 2, 0);
+            if (vgg_bwd) HX_LAUNCH(__bf16, 2, 2, 0); else if (ps_grad) HX_LAUNCH(__bf16, 2, 0, 1); else HX_LAUNCH(__bf16, 2, 0, 0);
             break;
-        case PREC_F16X1: HX_LAUNCH(_Float16, 1, 3); break;
-        default: HX_LAUNCH(__bf16, 1, 3); break;
+        case PREC_F16X1: HX_LAUNCH(_Float16, 1, 3, 0); break;
+        default: HX_LAUNCH(__bf16, 1, 3, 0); break;
     }
 #undef HX_LAUNCH
     g_last_conv_kernel = bn == 128 ? (big ? CK_HX_128_8W : CK_HX_128) : (bn == 64 ? CK_HX_64 : CK_HX_32);

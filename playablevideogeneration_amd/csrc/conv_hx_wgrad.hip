@@ -45,7 +45,10 @@ __device__ __forceinline__ typename Vec<T>::v8 tr_frag(const T* base, int off0, 
 // LDS-store / barrier phase of one workgroup runs under the MFMA phase of the other; 1: the unconstrained allocation, one workgroup per CU)
 // RSPLIT (layers of <= 32 output channels, round 4): the two wave rows split the tile's PIXEL rows instead of the output channels -- with the 64-channel block half empty
 // the wm = 1 waves multiplied zeros (D's last UpBlock conv 64 -> 32 @256x256, the largest weight gradient of the step); their partial sums meet in the final atomics.
-template <typename T, int OCC, bool RSPLIT>
+// YS16 (round 6): dY arrives PRE-SPLIT (WgradArgs.dy_s16: [hi 32 | lo 32] bf16 halves per 32-channel chunk, written once by the gradient's point-wise producer).  The 64-channel
+// row segment of a pixel is the same 256 bytes at the same address as in the fp32 tensor: thread (pixel column p0, piece q) copies 16 bytes -- eight hi or eight lo halves of one
+// chunk -- to their place in the [hi 64 | lo 64] LDS row; no conversion (was ~20 VALU per float4, repeated by every input-channel block of the layer), same operands bit for bit.
+template <typename T, int OCC, bool RSPLIT, bool YS16>
 __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
     const bool xm1 = cx + 1 < sg.C, xm2 = cx + 2 < sg.C, xm3 = cx + 3 < sg.C;
     const bool ym1 = yc + 1 < a.Cout, ym2 = yc + 2 < a.Cout, ym3 = yc + 3 < a.Cout;
     const int hy6 = p0 >> 1, hx6 = WG_TW + (p0 & 1);          // pass 6
+    const int yl16 = p0 * WG_PITCH + ((q >> 2) & 1) * 64 + (q >> 3) * 32 + (q & 3) * 8;      // YS16: piece q = (chunk q >> 3, hi | lo (q >> 2) & 1, eight halves q & 3) of the pixel's 256 bytes
     const int xl = p0 * WG_PITCH + 4 * q, xl6 = (hy6 * WG_HW + hx6) * WG_PITCH + 4 * q;      // LDS element offsets (pass i: + i * WG_HW * WG_PITCH; dY: + i * WG_TW * WG_PITCH)
     static_assert(WG_TW == 16 && WG_HW == 18 && 2 * WG_HH <= 16, "loader passes: 16 columns per row pass, the two right-most columns of all rows in one more");
     // tile-invariant address parts (32-bit element offsets inside one sample: H * W * ld < 2^31)
@@ -178,6 +182,11 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_hx(WgradArgs a, int tiles_x,
         _Pragma("unroll") for (int i = 0; i < WG_TH; i++) {                                                                        \
             const bool ok_ = yv_ && fy0 + i < a.H;                                                                                 \
             float4 v_ = ry[i];                                                                                                     \
+            if (YS16) {     /* (Cout a multiple of 32: a piece is inside or outside as a whole) */                                 \
+                v_.x = ok_ ? v_.x : 0.f; v_.y = ok_ ? v_.y : 0.f; v_.z = ok_ ? v_.z : 0.f; v_.w = ok_ ? v_.w : 0.f;               \
+                *reinterpret_cast<float4*>(&Yt[yl16 + i * (WG_TW * WG_PITCH)]) = v_;                                               \
+                continue;                                                                                                          \
+            }                                                                                                                      \
             v_.x = ok_ ? v_.x : 0.f; v_.y = (ok_ && ym1) ? v_.y : 0.f; v_.z = (ok_ && ym2) ? v_.z : 0.f; v_.w = (ok_ && ym3) ? v_.w : 0.f; \
             WG_SPLIT_STORE(&Yt[xl + i * (WG_TW * WG_PITCH)], v_);                                                                  \
         }                                                                                                                          \
@@ -272,6 +281,7 @@ static bool wgrad_hx_applies(const WgradArgs& a) {
     if (a.KS != 3 || a.precision != PREC_BF16X3 || a.Cout < 32 || a.Ktot < 32 || a.W < 8 || a.H < 2) return false;
     for (int s = 0; s < a.nsrc; s++) if ((a.src[s].ld & 3) || (a.src[s].sn & 3)) return false;
     if ((a.dy_ld & 3) || (a.dy_sn & 3)) return false;
+    if (a.dy_s16 && (a.Cout & 31)) return false;
     return true;
 }
 bool wgrad_src_lazy_ok(const WgradArgs& a) { return wgrad_hx_applies(a); }      // k_wgrad_hx is the only weight-gradient kernel that applies ConvSrc.bn_*
@@ -294,8 +304,11 @@ int conv_hx_wgrad_try(const WgradArgs& a, hipStream_t st, bool dry) {
     // contributing lane per launch -- the plain flush is already order-free: no copies, no fold (the row-split layout of <= 32 output channels has two contributors per element)
     if (b.det_slab && g == 1 && a.Cout > 32) b.det_slab = nullptr;
     if (b.det_slab) { g = wgrad_det_begin(b, g, st); if (g <= 0) return -1; }
-    if (a.Cout <= 32) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, true>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
-    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, false>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    if (a.dy_s16) {
+        if (a.Cout <= 32) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, true, true>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+        else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, false, true>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    } else if (a.Cout <= 32) hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, true, false>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
+    else hipLaunchKernelGGL((k_wgrad_hx<__bf16, 2, false, false>), dim3(kt, ot, (unsigned)g), dim3(256), 0, st, b, tx, ty);
     if (b.det_slab) wgrad_det_end(b, g, st);
     return 1;
 }

@@ -823,6 +823,7 @@ int conv_fwd_launch(const ConvArgs& a0, hipStream_t st) {
     }
     if (a.KS == 1 && a.direct_ok && conv1x1_lat_try(a, st) == 1) { g_last_conv_kernel = CK_FWD_128x32; return 0; }      // tiny 1x1 launches of a roll-out frame
     { int rc = conv_hx_try(a, st); if (rc != 0) return rc < 0 ? rc : 0; }      // split 16-bit operands on the 16-bit matrix pipe (conv_hx.hip)
+    if (a.in_s16 || a.out_s16 || a.pool_s16) return -1;                      // pre-split tensors are understood by k_conv_hx only: never hand their bytes to a kernel that reads fp32
     for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs are understood by k_conv_hx only: the caller must have materialised them
     if (a.pool_out || a.skip_out) return -1;      // fused max-pool / write-less epilogues exist in k_conv_hx only: the caller must not ask the other kernels for them
     const bool generic_only = a.act == 2 || a.mask != nullptr;      // ReLU / masked epilogues exist in k_conv_fwd only (VGG19 perceptual loss)
@@ -986,6 +987,7 @@ static int conv_wgrad_launch1(const WgradArgs& a0, hipStream_t st, bool dry) {
     if (a.Cout_pad != round_up(a.Cout, bn)) return -1;
     if (a.group_n > 0 && a.N <= a.group_n) a.group_n = 0;
     if (conv_hx_wgrad_try(a, st, dry) == 1) return 0;       // wide 3x3 layers: split bf16 on the 16-bit matrix pipe (conv_hx.hip)
+    if (a.dy_s16) return -1;                                // a pre-split dY is understood by k_wgrad_hx only
     for (int s = 0; s < a.nsrc; s++) if (a.src[s].bn_scale) return -1;        // lazily normalised inputs: k_wgrad_hx only
     g_last_wgrad_grouped = 0;
     { int rc = conv_stream_wgrad_try(a, st, dry); if (rc != 0) return rc < 0 ? rc : 0; }      // 1x1 layers: streaming kernel, both operands straight into the fp32 MFMA (conv_stream.hip)

@@ -456,7 +456,7 @@ void caddy_ctx::queue_wgrad(ConvL* L, const WgradArgs& w, double flops) {
     if (!p) { pending.emplace_back(L, PendingW{}); p = &pending.back().second; }
     if (p->count > 0) {
         const WgradArgs& f = p->first;
-        bool ok = f.N == w.N && f.H == w.H && f.W == w.W && f.nsrc == w.nsrc && f.dy_sn == w.dy_sn && f.dy_ld == w.dy_ld && f.dwp == w.dwp;
+        bool ok = f.N == w.N && f.H == w.H && f.W == w.W && f.nsrc == w.nsrc && f.dy_sn == w.dy_sn && f.dy_ld == w.dy_ld && f.dwp == w.dwp && f.dy_s16 == w.dy_s16;
         long ds[CONV_MAX_SRC] = {0, 0, 0}, db[CONV_MAX_SRC] = {0, 0, 0};
         for (int s = 0; ok && s < w.nsrc; s++) {
             ok = f.src[s].sn == w.src[s].sn && f.src[s].ld == w.src[s].ld && f.src[s].C == w.src[s].C && f.src[s].bcast == w.src[s].bcast;
@@ -541,6 +541,20 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
     }
     T4 out = into ? *into : (pooled ? alloc(N, H / 2, W / 2, L.pd.Cout) : (nz_out ? alloc_nz(N, H, W, L.pd.Cout) : alloc(N, H, W, L.pd.Cout)));
     a.out = out.d;
+    if (recording && s16_grads && !into && !pooled && !res && out.nz && !out.nz2 && actf != 1) {
+        // may d(out) travel pre-split (GradFmt)?  One assigning writer; the weight gradient on k_wgrad_hx and every dgrad on k_conv_hx (the launchers' own conditions), the
+        // broadcast-input / bias sums on the S16-aware reductions
+        bool elig = L.pd.KS == 3 && prec_bwd != PREC_FP32 && L.wq && (L.pd.Cout & 31) == 0 && L.pd.Cout >= 32 && L.pd.Ktot >= 32 && W >= 8 && H >= 2 && (out.ld & 3) == 0 && (out.sn & 3) == 0;
+        for (int s = 0; s < nseg && elig; s++) {
+            if ((segs[s].t.ld & 3) || (segs[s].t.sn & 3)) elig = false;
+            if (segs[s].need_grad && !segs[s].bcast && !L.wqd[s]) elig = false;
+        }
+        if (elig) {
+            gfmts.push_back(GradFmt{true, 0});
+            out.gs = &gfmts.back();
+            if (!dbg.empty() && dbg.back().d == out.d) dbg.back().gs = out.gs;
+        }
+    }
     if (res) { a.res = res->d; a.res_sn = res->sn; a.res_ld = res->ld; }
     a.out_sn = out.sn; a.out_ld = out.ld; a.accumulate = 0;
     g_last_conv_lstm_fused = 0;
@@ -593,7 +607,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
             WgradArgs w{};
             fill_srcs(w.src, sg, nseg);
             w.nsrc = nseg; w.N = N; w.H = H; w.W = W; w.KS = Lp->pd.KS; w.dy = dzv.p; w.dy_sn = dzv.sn; w.dy_ld = dzv.ld;
-            w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0;
+            w.Cout = Lp->pd.Cout; w.Cout_pad = Lp->pd.Cout_pad; w.Ktot = Lp->pd.Ktot; w.dwp = Lp->dwp; w.slabs = 0; w.dy_s16 = dzv.s16;
             w.precision = ((Lp->wq || (Lp->pd.Cout <= 3 && Lp->pd.KS == 7)) && prec_bwd != PREC_FP32) ? PREC_BF16X3 : PREC_FP32;      // (7x7 FinalBlock head: split bf16 on conv_stream.hip's k_wgrad_head7)
             queue_wgrad(Lp, w, px_taps * Lp->pd.Cin * Lp->pd.Cout);
             bool bias_done = !Lp->dbias;
@@ -619,7 +633,7 @@ T4 caddy_ctx::conv(ConvL& L, const Seg* segs, int nseg, int actf, const T4* into
                 ConvArgs d{};
                 d.src[0] = ConvSrc{dzv.p, dzv.sn, dzv.ld, Lp->pd.Cout, Lp->kd, 0};
                 d.nsrc = 1; d.N = N; d.H = H; d.W = W; d.KS = Lp->pd.KS; d.wp = Lp->wpd[s]; d.Ktot = Lp->kd;
-                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux; d.deterministic = deterministic ? 1 : 0;
+                d.Cout = sg[s].t.C; d.Cout_pad = Lp->cd_pad[s]; d.bias = nullptr; d.act = 0; d.aux = conv_aux; d.deterministic = deterministic ? 1 : 0; d.in_s16 = dzv.s16;
                 if (Lp->wqd[s] && prec_bwd != PREC_FP32) { d.wq = Lp->wqd[s]; d.precision = PREC_BF16X3; }
                 else if (Lp->pd.Cout <= 3 && Lp->pd.KS == 7 && prec_bwd != PREC_FP32) d.precision = PREC_BF16X3;      // 7x7 FinalBlock head: split bf16 on conv_head.hip (weights split in the kernel)
                 const double dfl = px_taps * sg[s].t.C * Lp->pd.Cout;
@@ -670,7 +684,7 @@ T4 caddy_ctx::conv_pool(ConvL& L, const Seg* segs, int nseg, bool actf) {
 T4 caddy_ctx::pool2(const T4& x, bool actf) {
     T4 o = x.nz ? alloc_nz(x.N, x.H / 2, x.W / 2, x.C) : alloc(x.N, x.H / 2, x.W / 2, x.C);   // conv -> pool -> BatchNorm chains stay first-touch
     RUN(pw_pool2(dv(x), dv(o), stream, actf ? 1 : 0));
-    if (recording) tp->push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv(x), x.nz ? 1 : 0, stream)); });
+    if (recording) tp->push_back([=]() { RUN(pw_pool2_bwd(gv(o), gv_w(x, x.nz), x.nz ? 1 : 0, stream)); });
     return o;
 }
 T4 caddy_ctx::up2(const T4& x) {
@@ -733,14 +747,14 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
         if (!dry) n_bn_lazy++;
         T4 ag = alloc_nz(x.N, x.H, x.W, x.C);      // only its gradient half is used: d(loss) / d(normalised value), assigned by the consumer's dgrad
         T4 out = x;
-        out.g = ag.g; out.nz = true; out.nz2 = false;
+        out.g = ag.g; out.nz = true; out.nz2 = false; out.gs = nullptr;      // (its own gradient buffer: written in fp32 by the consumer's dgrad)
         out.bn_scale = s1.scale; out.bn_shift = s1.shift; out.bn_act = actf ? 1 : 0;
         if (recording) {
             BNL* b1 = &bn;
             tp->push_back([=]() {
                 const float* ls = actf ? s1.scale : nullptr;
                 RUN(pw_bn_bwd_reduce(gv(out), nullptr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream, ls, s1.shift));
-                RUN(pw_bn_bwd_apply(gv(out), nullptr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream, ls, s1.shift));
+                RUN(pw_bn_bwd_apply(gv(out), nullptr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv_w(x, x.nz), nullptr, nullptr, x.nz ? 1 : 0, stream, ls, s1.shift));
             });
         }
         return out;
@@ -765,14 +779,14 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
             const TV* omp = actf ? &om : nullptr;
             if (small) {
                 TV dres{}; if (has2) dres = gv(x2c);
-                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv(x), bn_dgamma(b1), bn_dbeta(b1), has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
+                RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv_w(x, x.nz), bn_dgamma(b1), bn_dbeta(b1), has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
                 return;
             }
             RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream));   // sums assigned; param grads fused
-            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv(x), nullptr, nullptr, x.nz ? 1 : 0, stream));
+            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv_w(x, x.nz), nullptr, nullptr, x.nz ? 1 : 0, stream));
             if (has2 && b2) {
                 RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, bn_dgamma(b2), bn_dbeta(b2), stream));
-                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv(x2c), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
+                RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv_w(x2c, x2c.nz), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
             } else if (has2) {
                 if (actf) RUN(pw_act_bwd_add(gv(out), dv(out), gv(x2c), stream, x2c.nz2 ? 1 : 0));      // identity path: first writer of d(x) when x is nz2
                 else RUN(pw_copy(gv(out), gv(x2c), x2c.nz2 ? 0 : 1, stream));
@@ -873,7 +887,7 @@ T4 caddy_ctx::lstm_step(int i, const T4& x, const T4& aux, const ConvL* next) {
     }
     T4 gates = conv(L.gates, sg, 3, 0, nullptr, true);      // d(gates) is assigned by the LSTM point-wise backward
     RUN(pw_lstm_fwd(dv(gates), dv(cprev), dv(hn), dv(cn), stream));
-    if (recording) tp->push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv(gates), gv(cprev), stream)); });
+    if (recording) tp->push_back([=]() { RUN(pw_lstm_bwd(dv(gates), dv(cprev), dv(cn), gv(hn), gv(cn), gv_w(gates, gates.nz), gv(cprev), stream)); });
     L.h = hn; L.c = cn;
     T4 hb = bn_act(hn, L.bn, nullptr, nullptr, false, nullptr, true, false, next);      // feeds exactly one conv (as its first segment, same resolution)
     if (recording) { ConvL* Lg = &L.gates;      // (reverse replay: first thing of this step's cell) d(h_t) also receives the NEXT step's gate-convolution dgrad, from the decoder stream
@@ -1075,7 +1089,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
     bool dry = c->dry;
     if (gt_init <= 0) { set_error("To forward the full model specify a number of ground truth observations > 0"); return -2; }
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);      // a forward without a backward in between: the side stream may still read the old observations
-    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gfmts.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = gt_init; c->tau = tau; c->pretraining = false;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -1155,7 +1169,7 @@ static int forward_pretraining(caddy_ctx* c, const float* obs, float tau, const 
     const int B = g.batch, T = g.seq_len, H = g.height, W = g.width, S = g.stacking;
     bool dry = c->dry;
     if (c->gt_prefetched && !dry) hipStreamWaitEvent(c->stream, c->gt_done, 0);
-    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
+    c->act.reset(); c->tape.clear(); c->tape2.clear(); c->tp = &c->tape; c->d_forked = false; for (BNL* b_ : c->bns) b_->pend.clear(); c->dbg.clear(); c->gfmts.clear(); c->gt_lo = c->gt_hi = 0; c->stats_ring[0] = c->stats_ring[1] = caddy_ctx::TileStats{};
     c->training = training != 0; c->recording = training != 0; c->gt_init = 0; c->tau = tau; c->pretraining = true;
     for (BNL* b : c->bns) b->eval_valid = false;
     for (int i = 0; i < 3; i++) { c->lstm[i].h.d = nullptr; c->lstm[i].c.d = nullptr; }
@@ -1534,6 +1548,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (caddy_serial_streams()) c->use_dstream = false;
     hipMemset(c->sat_flag, 0, sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // (second half: sticky until polled, caddy_f16_saturated)
     if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
+    if (const char* e = getenv("CADDY_S16_GRADS")) c->s16_grads = atoi(e) != 0;      // A/B aid: 0 = every model gradient as fp32 (round-5 form)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path
         if (!strcmp(e, "exact") || !strcmp(e, "0")) { c->prec_fwd = c->prec_bwd = PREC_FP32; c->vgg_precision = c->vgg_precision_bwd = PREC_FP32; }
@@ -1554,6 +1569,8 @@ int caddy_set_stream(caddy_ctx* c, void* s) { c->stream = (hipStream_t)s; return
 int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; return 0; }
 int caddy_debug_set_bn_paths(caddy_ctx* c, int small, int lazy, int epilogue_stats) { c->bn_small = small != 0; c->lazy_bn = lazy != 0; c->epi_stats = epilogue_stats != 0; return 0; }
 int caddy_debug_set_vgg_s16(caddy_ctx* c, int on) { c->vgg_s16 = on != 0; return 0; }
+int caddy_debug_set_s16_grads(caddy_ctx* c, int on) { c->s16_grads = on != 0; return 0; }
+long caddy_debug_s16_grad_count(caddy_ctx* c) { long n = 0; for (const GradFmt& g : c->gfmts) n += g.fmt ? 1 : 0; return n; }
 int caddy_debug_set_pack_merged(caddy_ctx* c, int on) { c->merged_pack = on != 0; c->pack_jobs.key = -1; for (auto& j : c->unpack_jobs) j.key = -1; return 0; }
 int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }
 int caddy_set_grads_ready_hook(caddy_ctx* c, caddy_grads_ready_hook hook, void* user) { c->grads_hook = hook; c->grads_user = user; return 0; }

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <deque>
 #include <functional>
 #include <string>
 #include <vector>
@@ -13,6 +14,10 @@
 #include "pointwise.h"
 #include "perceptual.h"
 
+// Format of a convolution output's GRADIENT (round 6), shared by every copy of its T4: `elig` is decided when the forward graph is built -- the gradient has one assigning writer and
+// every reader (dgrad, weight gradient, bias / broadcast-input sums) understands S16-bf16 (TV::s16) --, `fmt` by that writer when the tape is replayed: a point-wise producer that
+// knows the format (gv_w) writes the halves the matrix pipe will multiply, any other writer leaves fp32 and the readers convert as before.
+struct GradFmt { bool elig; int fmt; };
 struct T4 {            // activation + gradient views with identical geometry
     float* d; float* g;
     int N, H, W, C; long sn; int ld;
@@ -23,9 +28,16 @@ struct T4 {            // activation + gradient views with identical geometry
     // consuming convolution's staging (ConvSrc.bn_*); `g` is the gradient w.r.t. the logical (normalised) value
     const float* bn_scale = nullptr; const float* bn_shift = nullptr; int bn_act = 0;
     int fmt = 0;       // 1: `d` is an S16 tensor (common.h: pre-split 16-bit halves, same geometry / footprint) -- VGG19 feature maps only (perceptual.hip)
+    GradFmt* gs = nullptr;      // non-null: `g` may be written pre-split (see GradFmt); owned by caddy_ctx::gfmts, valid until the next forward pass
 };
-static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
-static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld}; }
+static inline TV dv(const T4& t) { return TV{t.d, t.N, t.H, t.W, t.C, t.sn, t.ld, 0}; }
+static inline TV gv(const T4& t) { return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld, t.gs ? t.gs->fmt : 0}; }      // as its writer left it
+// destination view for THE assigning writer of the whole gradient (`assigns`: it overwrites every element, no read-modify-write): pre-split when the consumer asked for it
+static inline TV gv_w(const T4& t, bool assigns) {
+    const int f = (t.gs && t.gs->elig && assigns) ? 1 : 0;
+    if (t.gs) t.gs->fmt = f;
+    return TV{t.g, t.N, t.H, t.W, t.C, t.sn, t.ld, f};
+}
 
 struct ParamEntry { std::string name; long offset; int ndim; int shape[4]; int kind; long numel; };
 
@@ -124,6 +136,8 @@ struct caddy_ctx {
     void end_forward();
     bool tape2_done = false;
     std::vector<T4> dbg;             // every alloc() of the current forward (debug introspection, caddy_debug_*)
+    std::deque<GradFmt> gfmts;       // gradient formats of this forward's convolution outputs (T4::gs points here: a deque keeps the addresses stable)
+    bool s16_grads = true;           // conv-output gradients pre-split by their producers where every reader understands it (CADDY_S16_GRADS=0: fp32 everywhere, the round-5 exchange)
     std::vector<ConvL*> convs;
     std::vector<BNL*> bns;
     // layers

@@ -42,6 +42,22 @@ __device__ __forceinline__ void st4(float* p, int c, int C, float4 v) {
     if (c + 4 <= C) *reinterpret_cast<float4*>(p) = v;
     else { if (c < C) p[0] = v.x; if (c + 1 < C) p[1] = v.y; if (c + 2 < C) p[2] = v.z; }
 }
+// ---- S16-bf16 gradient tensors (TV::s16): the channels c .. c + 3 (c a multiple of 4) of the pixel row `row` ----
+// split exactly as the loaders of k_conv_hx / k_wgrad_hx split a fp32 gradient (hi = bf16(v), lo = bf16(v - hi), round to nearest even): a consumer that copies these halves
+// multiplies the same operands as one that converts the fp32 tensor
+__device__ __forceinline__ void st4_s16(float* row, int c, float4 v) {
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]); lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    __bf16* h = reinterpret_cast<__bf16*>(row + (c & ~31)) + (c & 31);
+    *reinterpret_cast<bf16x4*>(h) = hi;
+    *reinterpret_cast<bf16x4*>(h + 32) = lo;
+}
+__device__ __forceinline__ float4 ld4_s16(const float* row, int c) {      // hi + lo (16 mantissa bits: what the matrix pipe sees of the gradient)
+    const __bf16* h = reinterpret_cast<const __bf16*>(row + (c & ~31)) + (c & 31);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(h), lo = *reinterpret_cast<const bf16x4*>(h + 32);
+    return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+}
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
@@ -116,8 +132,9 @@ struct FPool2Bwd {  // q indexes INPUT pixels; din (+)= dout/4; `assign`: first 
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((y >> 1) < dout.H && (x >> 1) < dout.W)          // odd sizes: the last row / column is not covered by any 2x2 window
             g = ld4<FULL>(dout.p + (long)n * dout.sn + ((long)(y >> 1) * dout.W + (x >> 1)) * dout.ld + c, c, dout.C);
-        float* o = din.p + (long)n * din.sn + (long)rem * din.ld + c;
-        st4<FULL>(o, c, din.C, assign ? 0.25f * g : ld4<FULL>(o, c, din.C) + 0.25f * g);
+        float* o = din.p + (long)n * din.sn + (long)rem * din.ld;
+        if (din.s16) { st4_s16(o, c, 0.25f * g); return; }      // (din_s16: assigning writer of a conv output's gradient)
+        st4<FULL>(o + c, c, din.C, assign ? 0.25f * g : ld4<FULL>(o + c, c, din.C) + 0.25f * g);
     }
 };
 struct FUp2 {  // bilinear x2, align_corners=False (up_block.py:35,43); q indexes OUTPUT pixels
@@ -181,8 +198,9 @@ struct FBnBwdApply {  // dx += gamma*invstd*(dz - s1/M - xhat*s2/M), dz = dout*l
         for (int e = 0; e < 4; e++) { bool ok = c + e < x.C; s1[e] = ok ? (float)(sums[2 * (c + e)] * invM) : 0.f; s2[e] = ok ? (float)(sums[2 * (c + e) + 1] * invM) : 0.f; }
         float4 xh = (xv - mu) * is;
         float4 g = ga * is * (dz - make_float4(s1[0], s1[1], s1[2], s1[3]) - xh * make_float4(s2[0], s2[1], s2[2], s2[3]));
-        float* o = dx.p + tv_off(dx, HW, q) + c;
-        st4<FULL>(o, c, dx.C, assign ? g : ld4<FULL>(o, c, dx.C) + g);      // assign: dx has no other writer (conv output consumed by this BatchNorm only)
+        float* o = dx.p + tv_off(dx, HW, q);
+        if (dx.s16) { st4_s16(o, c, g); return; }      // (dx_s16: assigning writer of a conv output's gradient)
+        st4<FULL>(o + c, c, dx.C, assign ? g : ld4<FULL>(o + c, c, dx.C) + g);      // assign: dx has no other writer (conv output consumed by this BatchNorm only)
     }
 };
 struct FActBwdAdd {  // dres (+)= dout * lrelu'(out)
@@ -227,10 +245,13 @@ struct FLstmBwd {
         float4 dcc = gc + gh * o4 * (one - tc * tc);
         float4 d_i = dcc * g4, d_f = dcc * cp, d_g = dcc * i4;
         float* dg = dgates.p + tv_off(dgates, HW, q) + c;
-        st4<FULL>(dg, c, C, d_i * i4 * (one - i4));
-        st4<FULL>(dg + C, c, C, d_f * f4 * (one - f4));
-        st4<FULL>(dg + 2 * C, c, C, d_o * o4 * (one - o4));
-        st4<FULL>(dg + 3 * C, c, C, d_g * (one - g4 * g4));
+        const float4 gi_ = d_i * i4 * (one - i4), gf_ = d_f * f4 * (one - f4), go_ = d_o * o4 * (one - o4), gg_ = d_g * (one - g4 * g4);      // (formed once: both stores see the same bits)
+        if (dgates.s16) {      // (dgates_s16: the gate convolution's dY; 4 C channels, C a multiple of 32)
+            float* row = dg - c;
+            st4_s16(row, c, gi_); st4_s16(row, C + c, gf_); st4_s16(row, 2 * C + c, go_); st4_s16(row, 3 * C + c, gg_);
+        } else {
+            st4<FULL>(dg, c, C, gi_); st4<FULL>(dg + C, c, C, gf_); st4<FULL>(dg + 2 * C, c, C, go_); st4<FULL>(dg + 3 * C, c, C, gg_);
+        }
         float* dp = dcprev.p + tv_off(dcprev, HW, q) + c;
         st4<FULL>(dp, c, C, ld4<FULL>(dp, c, C) + dcc * f4);
     }
@@ -300,7 +321,11 @@ struct FNhwcToNchw {
     template <bool FULL> __device__ void operator()(unsigned q, int) const {
         const long n = fdiv(q, HW); const long pix = q - n * HW.d;
         const float* i = s.p + n * s.sn + pix * s.ld;
-        for (int c = 0; c < s.C; c++) { float* o = dst + n * dst_sn + (long)c * HW.d + pix; *o = acc ? *o + i[c] : i[c]; }
+        for (int c = 0; c < s.C; c++) {
+            float v = i[c];
+            if (s.s16) { const __bf16* h = reinterpret_cast<const __bf16*>(i + (c & ~31)) + (c & 31); v = (float)h[0] + (float)h[32]; }      // (s_s16: debug read-out of a pre-split gradient)
+            float* o = dst + n * dst_sn + (long)c * HW.d + pix; *o = acc ? *o + v : v;
+        }
     }
 };
 
@@ -347,7 +372,8 @@ __global__ __launch_bounds__(256) void k_reduce(RedArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {      // loads only; rows past the end re-read the last pixel and are dropped below
                     const unsigned q = q0 + u * PT <= qlast ? q0 + u * PT : qlast;
-                    xv[u] = ld4<FULL>(a.x.p + tv_off(a.x, a.hw, q) + c, c, C);
+                    if (MODE == 3 && a.x.s16) xv[u] = ld4_s16(a.x.p + tv_off(a.x, a.hw, q), c);      // (x_s16: bias gradient = column sums of a pre-split dY)
+                    else xv[u] = ld4<FULL>(a.x.p + tv_off(a.x, a.hw, q) + c, c, C);
                     if (MODE == 1) dz[u] = ld4<FULL>(a.dout.p + tv_off(a.dout, a.hw, q) + c, c, C);
                     if (MODE == 1 && ACT == 1) om[u] = ld4<FULL>(a.outm.p + tv_off(a.outm, a.hw, q) + c, c, C);
                 }
@@ -582,8 +608,9 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(BnSmallBwd a) {
         if (q < P) {
             float4 xh = (ld4(a.x.p + tv_off(a.x, HW, q) + c, c, C) - mu) * is;
             float4 g = ga * is * (dz[i] - s1 - xh * s2);
-            float* o = a.dx.p + tv_off(a.dx, HW, q) + c;
-            st4(o, c, C, a.assign ? g : ld4(o, c, C) + g);
+            float* o = a.dx.p + tv_off(a.dx, HW, q);
+            if (a.dx.s16) st4_s16(o, c, g);      // (dx_s16)
+            else st4(o + c, c, C, a.assign ? g : ld4(o + c, c, C) + g);
             if (a.has_res) { float* r = a.dres.p + tv_off(a.dres, HW, q) + c; st4(r, c, C, a.res_assign ? dz[i] : ld4(r, c, C) + dz[i]); }
         }
     }
@@ -631,7 +658,8 @@ __global__ __launch_bounds__(256) void k_border_sums(TV dz, float* S) {   // S[n
     if (c < dz.C) {
         for (int p = pg; p < HW; p += 16) {
             int y = p / W, x = p - y * W;
-            float4 v = ld4(dz.p + (long)n * dz.sn + (long)p * dz.ld + c, c, dz.C);
+            const float* row = dz.p + (long)n * dz.sn + (long)p * dz.ld;
+            float4 v = dz.s16 ? ld4_s16(row, c) : ld4(row + c, c, dz.C);      // (dz_s16)
             T = T + v;
             if (y == 0) { R0 = R0 + v; if (x == 0) K00 = K00 + v; if (x == W - 1) K0L = K0L + v; }
             if (y == H - 1) { RL = RL + v; if (x == 0) KL0 = KL0 + v; if (x == W - 1) KLL = KLL + v; }

@@ -1028,3 +1028,155 @@ def hx_s16_chain_case(lib, dev, *, N, H, W, C0, C1, C2, pool=False, seed=0):
         g0_16 = run(DA, g1_16, C1, C0, H, W, PREC_BF16X3, bias=False, act=0, in_s16=1)
         assert torch.equal(g0_32.cpu(), g0_16.cpu())
     return err
+
+
+# ---- round 6: the gradient of a convolution output exchanged pre-split (TV::s16 / WgradArgs.dy_s16 / ConvArgs.in_s16 with split bf16) ----
+def s16_grad_case(lib, dev, *, N, H, W, Cin, Cout, seed=0, force_big=-1, producers=True):
+    """dY of a 3x3 convolution Cin -> Cout as an S16-bf16 tensor.  Producers (the point-wise backward kernels that assign a conv output's gradient: BatchNorm backward, its one-launch
+    form, average-pool backward, ConvLSTM cell backward) must write EXACTLY [bf16(v) | bf16(v - bf16(v))] of the value their fp32 form writes; readers must give BIT-IDENTICAL weight
+    gradients (k_wgrad_hx, also time-batched) and dgrads (every k_conv_hx tile variant the shape selects, accumulating + deterministic K split) to those of the fp32 tensor, and the
+    column / border sums the sums of hi + lo."""
+    assert Cout % 32 == 0
+    g = torch.Generator().manual_seed(seed)
+    st = stream(dev)
+    bf = torch.bfloat16
+    lib.caddy_k_hx_weight_bytes.restype = C.c_long
+
+    def tv16(buf, Cc):
+        t = tv(buf, Cc)
+        t.s16 = 1
+        return t
+
+    def check_s16(buf16, ref32, what):
+        hi, lo = s16_decode(buf16, ref32.shape[3], bf)
+        v = ref32.cpu()
+        assert torch.equal(hi, v.to(bf)), what + ": high halves"
+        assert torch.equal(lo, (v - v.to(bf).float()).to(bf)), what + ": low halves"
+
+    # gradient magnitudes over many binades (bf16 halves: no lower bound)
+    dy = torch.randn(N, Cout, H, W, generator=g) * torch.exp(torch.randn(N, Cout, 1, 1, generator=g) * 4.0 - 6.0)
+    if producers:
+        # (a) avg_pool2d(2) backward, assigning
+        if H % 2 == 0 and W % 2 == 0:
+            dpo = nhwc(torch.randn(N, Cout, H // 2, W // 2, generator=g), dev=dev)
+            d32, d16 = torch.full((N, H, W, Cout), 3.0, device=dev), torch.full((N, H, W, Cout), 3.0, device=dev)
+            assert lib.caddy_k_pool2_bwd_assign(C.byref(tv(dpo, Cout)), C.byref(tv(d32, Cout)), st) == 0
+            assert lib.caddy_k_pool2_bwd_assign(C.byref(tv(dpo, Cout)), C.byref(tv16(d16, Cout)), st) == 0
+            sync(dev)
+            check_s16(d16, d32, "pool2_bwd")
+        # (b) BatchNorm backward apply (assigning; LeakyReLU slope from the materialised output) and (c) its one-launch form
+        x = nhwc(torch.randn(N, Cout, H, W, generator=g), dev=dev)
+        om = nhwc(torch.randn(N, Cout, H, W, generator=g), dev=dev)
+        dout = nhwc(dy, dev=dev)
+        mean, invstd, gamma = (torch.randn(Cout, generator=g) * 0.1).to(dev), (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.rand(Cout, generator=g) + 0.5).to(dev)
+        sums = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+        assert lib.caddy_k_bn_bwd_reduce(C.byref(tv(dout, Cout)), C.byref(tv(om, Cout)), C.byref(tv(x, Cout)), P(mean), P(invstd), P(sums), st) == 0
+        d32, d16 = torch.full((N, H, W, Cout), 3.0, device=dev), torch.full((N, H, W, Cout), 3.0, device=dev)
+        for dst in (tv(d32, Cout), tv16(d16, Cout)):
+            assert lib.caddy_k_bn_bwd_apply_assign(C.byref(tv(dout, Cout)), C.byref(tv(om, Cout)), C.byref(tv(x, Cout)), P(mean), P(invstd), P(gamma), P(sums), C.byref(dst), st) == 0
+        sync(dev)
+        check_s16(d16, d32, "bn_bwd_apply")
+        if N * H * W <= 8192:
+            dg, db = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+            d32, d16 = torch.full((N, H, W, Cout), 3.0, device=dev), torch.full((N, H, W, Cout), 3.0, device=dev)
+            for dst in (tv(d32, Cout), tv16(d16, Cout)):
+                assert lib.caddy_k_bn_small_bwd_assign(C.byref(tv(dout, Cout)), C.byref(tv(om, Cout)), C.byref(tv(x, Cout)), P(mean), P(invstd), P(gamma), C.byref(dst), P(dg), P(db), None, st) == 0
+            sync(dev)
+            check_s16(d16, d32, "bn_small_bwd")
+        # (d) ConvLSTM cell backward: d(gates), 4 x Ch channels
+        if Cout % 128 == 0:
+            Ch = Cout // 4
+            gates = nhwc(torch.rand(N, Cout, H, W, generator=g), dev=dev)
+            cp, cn = nhwc(torch.randn(N, Ch, H, W, generator=g), dev=dev), nhwc(torch.randn(N, Ch, H, W, generator=g), dev=dev)
+            dh, dc = nhwc(torch.randn(N, Ch, H, W, generator=g) * 1e-3, dev=dev), nhwc(torch.randn(N, Ch, H, W, generator=g) * 1e-3, dev=dev)
+            d32, d16 = torch.full((N, H, W, Cout), 3.0, device=dev), torch.full((N, H, W, Cout), 3.0, device=dev)
+            for dst in (tv(d32, Cout), tv16(d16, Cout)):
+                dcp = torch.zeros(N, H, W, Ch, device=dev)
+                assert lib.caddy_k_lstm_bwd(C.byref(tv(gates, Cout)), C.byref(tv(cp, Ch)), C.byref(tv(cn, Ch)), C.byref(tv(dh, Ch)), C.byref(tv(dc, Ch)), C.byref(dst), C.byref(tv(dcp, Ch)), st) == 0
+            sync(dev)
+            check_s16(d16, d32, "lstm_bwd")
+    # ---- readers ----
+    dz32 = nhwc(dy, dev=dev)                                               # (N,H,W,Cout), ld = Cout
+    dz16 = s16_encode(dy.permute(0, 2, 3, 1).contiguous(), bf, dev)
+    hi, lo = s16_decode(dz16, Cout, bf)
+    dzv = (hi.float() + lo.float()).to(dev).contiguous()                   # what an S16 reader sees, as an fp32 tensor
+    # debug read-out
+    got = torch.zeros(N, Cout, H, W, device=dev)
+    assert lib.caddy_k_nhwc_to_nchw(C.byref(tv16(dz16, Cout)), P(got), Cout * H * W, 0, st) == 0
+    sync(dev)
+    assert torch.equal(got.cpu(), dzv.cpu().permute(0, 3, 1, 2))
+    # column sums (bias gradient): same kernel on hi + lo
+    o32, o16 = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    assert lib.caddy_k_colsum(C.byref(tv(dzv, Cout)), P(o32), st) == 0 and lib.caddy_k_colsum(C.byref(tv16(dz16, Cout)), P(o16), st) == 0
+    sync(dev)
+    mag = dzv.abs().sum(dim=(0, 1, 2)).cpu()                                # (float atomics between workgroups: arrival order -- bound relative to sum |v|, the sums themselves cancel)
+    assert ((o32.cpu() - o16.cpu()).abs() <= 1e-5 * mag + 1e-30).all(), "colsum"
+    # the convolution itself
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    w_d = w.contiguous().to(dev)
+    d = make_pack([w], [(0, Cin)], 3, lib)
+    d.w[0] = w_d.data_ptr()
+    x_in = nhwc(torch.randn(N, Cin, H, W, generator=g), dev=dev)
+    # border sums -> gradient of a broadcast input + bias: S16 tensor vs the fp32 tensor of hi + lo, bit for bit
+    wb = torch.randn(Cout, 8, 3, 3, generator=g)
+    wb_d = wb.contiguous().to(dev)
+    db_ = make_pack([wb], [(0, 8)], 3, lib)
+    db_.w[0] = wb_d.data_ptr()
+    res = []
+    for t in (tv(dzv, Cout), tv16(dz16, Cout)):
+        S, ga, dbias = torch.zeros(N * Cout * 9, device=dev), torch.zeros(N, 8, device=dev), torch.zeros(Cout, device=dev)
+        assert lib.caddy_k_bcast_input_grad(C.byref(t), C.byref(db_), 0, P(S), P(ga), 8, P(dbias), st) == 0
+        sync(dev)
+        res.append((S.cpu(), ga.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "border sums of an S16 gradient"
+    lib.caddy_k_hx_force_big(force_big)
+    try:
+        # weight gradient (bit-reproducible mode), plain and time-batched
+        wsz = 9 * d.Cout_pad * d.Ktot
+        det = torch.zeros(1 << 22, device=dev)
+        outs = []
+        for buf, s16 in ((dz32, 0), (dz16, 1)):
+            wa = WgradArgs()
+            wa.src[0] = ConvSrc(x_in.data_ptr(), H * W * x_in.shape[3], x_in.shape[3], Cin, round_up(Cin, CONV_BK), 0)
+            wa.nsrc, wa.N, wa.H, wa.W, wa.KS = 1, N, H, W, 3
+            wa.dy, wa.dy_sn, wa.dy_ld, wa.dy_s16 = buf.data_ptr(), H * W * Cout, Cout, s16
+            wa.Cout, wa.Cout_pad, wa.Ktot, wa.slabs, wa.precision = Cout, d.Cout_pad, d.Ktot, 0, PREC_BF16X3
+            dwp = torch.zeros(wsz, device=dev)
+            wa.dwp, wa.det_slab, wa.det_cap = dwp.data_ptr(), det.data_ptr(), det.numel()
+            assert lib.caddy_k_conv_wgrad(C.byref(wa), st) == 0
+            sync(dev)
+            outs.append(dwp)
+            if N % 2 == 0:
+                wa.group_n, wa.dy_gs = N // 2, (N // 2) * H * W * Cout
+                wa.src_gs[0] = (N // 2) * H * W * x_in.shape[3]
+                dwp2 = torch.zeros(wsz, device=dev)
+                wa.dwp = dwp2.data_ptr()
+                assert lib.caddy_k_conv_wgrad(C.byref(wa), st) == 0
+                sync(dev)
+                assert torch.equal(dwp2, dwp), "time-batched weight gradient"
+        assert torch.equal(outs[0], outs[1]), "weight gradient from a pre-split dY"
+        assert outs[0].abs().max().item() > 0
+        # dgrad: accumulating on top of ones, deterministic K split available
+        bn = lib.caddy_k_hx_pick_bn(Cin)
+        rows_pad = round_up(Cin, bn)
+        wq = torch.zeros(lib.caddy_k_hx_weight_bytes(C.byref(d), 0, rows_pad, 2), dtype=torch.uint8, device=dev)
+        assert lib.caddy_k_pack_hx(C.byref(d), P(wq), rows_pad, 0, PREC_BF16X3, st) == 0
+        scr = torch.zeros(9 * N * H * W * round_up(Cin, 4), device=dev)
+        for accumulate in (1, 0):
+            outs = []
+            for buf, s16 in ((dz32, 0), (dz16, 1)):
+                da = ConvArgs()
+                da.src[0] = ConvSrc(buf.data_ptr(), H * W * Cout, Cout, Cout, round_up(Cout, CONV_BK), 0)
+                da.nsrc, da.N, da.H, da.W, da.KS = 1, N, H, W, 3
+                da.wp, da.Ktot, da.Cout, da.Cout_pad = None, round_up(Cout, CONV_BK), Cin, round_up(Cin, lib.caddy_k_conv_pick_bn(Cin))
+                da.wq, da.precision, da.in_s16 = wq.data_ptr(), PREC_BF16X3, s16
+                gx = torch.ones((N, H, W, round_up(Cin, 4)), device=dev)
+                da.out, da.out_sn, da.out_ld, da.accumulate = gx.data_ptr(), H * W * gx.shape[3], gx.shape[3], accumulate
+                da.deterministic, da.split_scratch, da.split_cap = 1, scr.data_ptr(), scr.numel()
+                assert lib.caddy_k_conv_fwd(C.byref(da), st) == 0
+                sync(dev)
+                outs.append(gx)
+            assert torch.equal(outs[0], outs[1]), ("dgrad from a pre-split dY", accumulate)
+            assert (outs[0] - 1.0).abs().max().item() > 0
+    finally:
+        lib.caddy_k_hx_force_big(-1)

@@ -20,9 +20,16 @@ def noise_dict(rec, B, T, K, Da, gumbel=True):
 
 
 # full_case's bounds on the bit-reproducible backward (the default): worst per-parameter max error relative to that parameter's largest fp64 gradient, and the relative
-# deviation of sum |grad| from the reference's own summaries (z["grad_abs"]).  Written for the arrival-order backward as 1e-1 / 5e-2 (rounds 1 - 4).
-WORST_PARAM_FLOOR = 1e-1
-GRAD_ABS_TOL = 5e-2
+# deviation of sum |grad| from the reference's own summaries (z["grad_abs"]).  Written for the arrival-order backward as 1e-1 / 5e-2 (rounds 1 - 4); round 6: set to what the
+# deterministic backward shows on the MI355X (two boxes, bit-identical values) with 2 x head-room:
+#   worst per-parameter error   reduced_s1 1.37e-2, main_s1 9.8e-4, main_s4_hard 1.21e-2, plainmi 1.25e-2, nogumbel 5.6e-3 | novar 3.42e-2, ens2 3.96e-2
+#   worst sum |grad| deviation  2.2e-4, 1.3e-4, 9.98e-3, 2.3e-4, 2.7e-3 | novar 3.45e-2, ens2 5.7e-3
+# The three goldens right of the bar keep a looser pair: novar carries one documented LeakyReLU slope decision (test_gradient_offset_of_the_2e2_floor_goldens_is_a_slope_decision),
+# nogumbel had one in rounds 3 - 5 and can get it back with any change of summation order, ens2's undrawn member leaves the action head's tiny gradients dominated by round-off.
+# The host simulator (exact-fp32 kernels, other summation order) stays inside the same bounds.
+WORST_PARAM_FLOOR = 3e-2
+GRAD_ABS_TOL = 2e-2
+LOOSE_CASES = {"full_reduced_s1_novar": (7e-2, 7e-2), "full_main_s1_nogumbel": (7e-2, 7e-2), "full_reduced_s1_ens2": (8e-2, 2e-2)}      # (per-parameter floor, sum |grad| tolerance)
 SIM_SPLIT = False      # simulator runs: exact-fp32 convolutions by default (the split-operand kernels are 4x slower to simulate; they have their own cases)
 
 
@@ -77,7 +84,7 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=True, grad_
     slope is discontinuous at 0, so pre-activations within the ~1e-5 forward round-off of zero take the other slope
     (0.2 <-> 1) and shift the BatchNorm-backward means -- O(1e-3) relative, data dependent (verified element by element
     with the caddy_debug_* introspection API; single-step graphs, where no flip occurs, agree to 2e-5).  Criterion:
-    relative L2 error <= max(2 x fp32-oracle error, 5e-3) and per-parameter max error <= max(5 x, 1e-1) on the library's default, bit-reproducible backward (round 5; no
+    relative L2 error <= max(2 x fp32-oracle error, 5e-3) and per-parameter max error <= max(5 x, 3e-2; three goldens looser: LOOSE_CASES) on the library's default, bit-reproducible backward (round 5; no
     arrival-order atomics, so no run-to-run noise on top of the arithmetic's own error); a missing or wrong term in the backward graph shows up as O(0.1 - 1).
     deterministic=False (caddy_set_deterministic(0): fp32 atomics in arrival order): relative L2 error <= max(5 x fp32-oracle error, 3e-2).
     """
@@ -136,13 +143,14 @@ def full_case(name, lib, dev, fwd_tol=2e-4, prep=None, deterministic=True, grad_
         num_h += ((g - g64) ** 2).sum().item(); num_o += ((g32 - g64) ** 2).sum().item(); den += (g64 ** 2).sum().item()
     rel_h, rel_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
     assert rel_h <= (max(2 * rel_o, grad_floor) if deterministic else max(5 * rel_o, 3e-2)), ("relative L2 gradient error vs fp64", rel_h, rel_o)
-    assert worst_h <= max(5 * worst_o, WORST_PARAM_FLOOR if deterministic else 1e-1), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
+    param_floor, abs_tol = LOOSE_CASES.get(name, (WORST_PARAM_FLOOR, GRAD_ABS_TOL)) if deterministic else (1e-1, 5e-2)
+    assert worst_h <= max(5 * worst_o, param_floor), ("worst per-parameter gradient error vs fp64", worst_h, worst_o)
     # reference's own gradient summaries (loose: same conditioning caveat)
     worst_abs = 0.0
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
         got = eng.grad_view(str(n)).double().abs().sum().item()
         worst_abs = max(worst_abs, abs(got - ga) / max(ga, 1e-4))
-        assert abs(got - ga) <= GRAD_ABS_TOL * max(ga, 1e-4), (n, got, ga)
+        assert abs(got - ga) <= abs_tol * max(ga, 1e-4), (n, got, ga)
     sd = eng.state_dict()
     for k in z.files:
         if k.startswith("buf:"):
@@ -264,7 +272,7 @@ def perceptual_case(name, lib, dev, fwd_tol=2e-4, grad_tol=5e-3, prep=None):
     for n, ga in zip(z["grad_names"], z["grad_abs"]):
         got = eng.grad_view(str(n)).double().abs().sum().item()
         worst_abs = max(worst_abs, abs(got - ga) / max(ga, 1e-4))
-        assert abs(got - ga) <= GRAD_ABS_TOL * max(ga, 1e-4), (n, got, ga)
+        assert abs(got - ga) <= abs_tol * max(ga, 1e-4), (n, got, ga)
     # Gradients w.r.t. the reconstructions.  The perceptual gradient is DISCONTINUOUS in its input (sign() of the feature L1, ReLU masks,
     # max-pool arg-max): fp32 round-off flips a handful of those decisions, each flip moving one image's gradient by O(1e-2) while all
     # other images agree to 1e-6.  Criteria: (a) per image, against the ORACLE evaluated at the engine's own reconstructions (identical
@@ -867,3 +875,52 @@ def vgg_s16_ab_case(lib, dev, c, lam=1.0, force_big=False):
     info["param_grad_rel_l2"] = rel
     assert rel < 2e-2, rel      # (BPTT amplifies the few flipped decisions; the two forms are two fp32-class evaluations of the same function)
     return info
+
+
+def s16_grads_ab_case(lib, dev, c, seed=3, min_count=1, pretraining=False):
+    """Round 6: the gradients of the convolution outputs written PRE-SPLIT (S16-bf16) by their point-wise producers -- BatchNorm backward, average-pool backward, ConvLSTM cell
+    backward -- and copied by the dgrad / weight-gradient launches that stage them, against the fp32 exchange of the same library (caddy_debug_set_s16_grads), same inputs.  The
+    matrix operands are the same bit for bit (kernel-level: s16_grad_case); what differs is what the bias / broadcast-input column sums see (hi + lo: 2^-17 relative), which
+    reaches every parameter through the action network's backward: relative L2 of the flat gradient << the backward's own 16-bit-operand error (1e-5 class)."""
+    from playablevideogeneration_amd.init import init_parameters
+    B, T, K, Da, S, Hh, W = c["B"], c["T"], c["K"], c["Da"], c["S"], c["H"], c["W"]
+    lib.caddy_debug_set_s16_grads.argtypes = [C.c_void_p, C.c_int]
+    lib.caddy_debug_s16_grad_count.argtypes = [C.c_void_p]
+    lib.caddy_debug_s16_grad_count.restype = C.c_long
+    eng = make_engine(c, lib, dev)
+    init_parameters(eng, seed)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    obs = torch.rand(B, T, 3 * S, Hh, W, device=dev, generator=g) * 2 - 1
+    n = T - 1
+    noise = {"eps_states": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs": torch.randn(B * n, Da, device=dev, generator=g),
+             "gumbel_uniform": torch.rand(B * n, K, device=dev, generator=g),
+             "eps_states_rec": torch.randn(B * T, Da, device=dev, generator=g), "eps_dirs_rec": torch.randn(B * n, Da, device=dev, generator=g)}
+    saved = eng.params.clone()
+    res = []
+    for on in (0, 1, 1):
+        eng.params.copy_(saved)
+        lib.caddy_debug_set_s16_grads(eng.ctx, on)
+        if pretraining:
+            out = eng.forward_pretraining(obs, c["tau"], noise, training=True)
+        else:
+            out = eng.forward_full(obs, c["gt"], c["tau"], noise, training=True)
+        l = eng.loss_backward(dict(H.LOSS_W, **({"hidden": 1.0} if pretraining else {})), smooth_mi=True, mi_alpha=0.2, update_mi_ema=False)
+        res.append((out[0].clone(), l, eng.grads.clone(), int(lib.caddy_debug_s16_grad_count(eng.ctx))))
+    (f0, l0, g0, n0), (f1, l1, g1, n1), (f2, l2, g2, n2) = res
+    assert n0 == 0 and n1 >= min_count and n2 == n1, (n0, n1, n2)
+    assert torch.equal(f0, f1) and abs(l0["total"] - l1["total"]) <= 1e-12 * abs(l0["total"])
+    assert torch.isfinite(g1).all()
+    assert torch.equal(g1, g2), "bit-reproducible backward with pre-split gradients"
+    rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
+    worst = 0.0
+    for name, off, shape, kind in eng.table:
+        if kind != 0:
+            continue
+        k = 1
+        for s_ in shape:
+            k *= s_
+        a, b = g0[off:off + k].double(), g1[off:off + k].double()
+        if a.norm().item() > 0:
+            worst = max(worst, ((a - b).norm() / a.norm()).item())
+    assert rel < 1e-4 and worst < 1e-2, (rel, worst)
+    return {"pre_split_gradient_tensors": n1, "flat_gradient_rel_l2_vs_fp32_exchange": rel, "worst_parameter_rel_l2": worst}

@@ -224,3 +224,13 @@ def test_streaming_weight_gradients_small():
         K.conv_case(lib, "cpu", wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4, **kw)
     for kw in (dict(N=2, H=20, W=24, segs=[(64, 0)], Cout=128, KS=1), dict(N=3, H=17, W=9, segs=[(32, 0)], Cout=65, KS=1), dict(N=2, H=40, W=40, segs=[(16, 0)], Cout=32, KS=1)):
         K.conv_case(lib, "cpu", **kw)
+
+
+def test_s16_gradients_small():
+    """round 6: the gradient of a conv output exchanged pre-split (S16-bf16): producers write exactly the halves the loaders would form, weight gradients / dgrads (4 x 16, 8 x 16 and
+    16 x 16-pixel tile variants, 32 / 64 / 128 output channels, K split) are bit-identical to those of the fp32 tensor, border / column sums see hi + lo"""
+    lib = load_emu()
+    K.s16_grad_case(lib, "cpu", N=2, H=8, W=16, Cin=64, Cout=128)                       # 4 x 16 tiles (under-filled split-bf16 launch), K split
+    K.s16_grad_case(lib, "cpu", N=1, H=9, W=18, Cin=40, Cout=64, seed=1)                # ragged tiles, channel tail on the dgrad's output side
+    K.s16_grad_case(lib, "cpu", N=2, H=6, W=16, Cin=32, Cout=32, seed=2)                # <= 32 output channels of the weight gradient: row-split waves
+    K.s16_grad_case(lib, "cpu", N=1, H=16, W=16, Cin=128, Cout=64, seed=3, force_big=1, producers=False)      # 8-wave 16 x 16 x 128 tile

@@ -249,6 +249,22 @@ def test_conv_hx_s16_tensors(lib, kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(N=8, H=32, W=32, Cin=128, Cout=512),                                  # R's gate dgrad: 4 x 16 tiles, 256 workgroups
+    dict(N=8, H=16, W=16, Cin=256, Cout=1024, seed=1),                         # ... 16 x 16 maps: K split over slabs
+    dict(N=8, H=64, W=64, Cin=128, Cout=128, seed=2),                          # D residual block: 8 x 16 x 128 / 64-channel tiles
+    dict(N=8, H=128, W=128, Cin=64, Cout=64, seed=3),                          # 16 x 16 x 64, well-filled
+    dict(N=4, H=128, W=128, Cin=64, Cout=32, seed=4),                          # row-split weight gradient (<= 32 output channels)
+    dict(N=3, H=50, W=70, Cin=32, Cout=64, seed=5),                            # 32-channel dgrad tiles, ragged
+    dict(N=8, H=32, W=32, Cin=32, Cout=32, seed=6),                            # 8 x 16 x 32
+    dict(N=6, H=48, W=48, Cin=128, Cout=128, seed=7, force_big=1),             # 8-wave 16 x 16 x 128 tile
+])
+def test_pre_split_gradient_tensors(lib, kw):
+    """round 6: conv-output gradients as S16-bf16 tensors -- point-wise producers write exactly the loaders' halves; k_wgrad_hx and every split-bf16 k_conv_hx tile variant give
+    bit-identical results from them; border / column sums"""
+    K.s16_grad_case(lib, "cuda", **kw)
+
+
+@pytest.mark.parametrize("kw", [
     dict(N=2, H=64, W=64, segs=[(32, 0)], Cout=3, KS=7, bias=True, act=1, wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4),      # D's 7x7 head
     dict(N=5, H=44, W=100, segs=[(32, 0)], Cout=3, KS=7, wgrad_precision=17, wgrad_tol=1e-4, dgrad_precision=17, dgrad_tol=1e-4),                        # ragged tiles, many samples
     dict(N=2, H=32, W=48, segs=[(16, 0)], Cout=3, KS=7, bias=True, act=1, wgrad_precision=17, wgrad_tol=1e-4),                                           # reduced variant: 16 channels

@@ -163,3 +163,13 @@ def test_deterministic_backward_mode():
         M.deterministic_case(lib, "cpu", dict(variant="main", K=7, Da=2, Ch=128, S=2, B=1, T=3, H=32, W=48, gt=1, tau=0.7), reps=2)
     finally:
         M.SIM_SPLIT = False
+
+
+def test_pre_split_gradients_equal_the_fp32_exchange_small():
+    """round 6: conv-output gradients written pre-split (S16-bf16) by their point-wise producers vs the fp32 exchange of the same library, split-operand arithmetic, through the whole
+    driver (BatchNorm / pooling / ConvLSTM-cell producers, dgrad and weight-gradient readers, border / column sums)"""
+    M.SIM_SPLIT = True
+    try:
+        print(M.s16_grads_ab_case(load_emu(), "cpu", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=1, T=3, H=64, W=64, gt=1, tau=0.6)))
+    finally:
+        M.SIM_SPLIT = False

@@ -87,6 +87,15 @@ def test_perceptual_loss_parity_s16_every_layer(lib):
     print(info)
 
 
+def test_pre_split_gradients_vs_fp32_exchange(lib):
+    """round 6: the model's conv-output gradients written pre-split by their point-wise producers vs the fp32 exchange (same library, same inputs): a small reduced model, the
+    pretraining graph, and the BAIR geometry (main variant, 256 x 256, closed-loop steps)"""
+    print(M.s16_grads_ab_case(lib, "cuda", dict(variant="reduced", K=3, Da=1, Ch=64, S=1, B=2, T=3, H=64, W=80, gt=1, tau=0.6)))
+    print(M.s16_grads_ab_case(lib, "cuda", dict(variant="main", K=5, Da=2, Ch=128, S=1, B=2, T=4, H=128, W=128, gt=2, tau=0.6), pretraining=True))
+    print(M.s16_grads_ab_case(lib, "cuda", dict(variant="main", K=7, Da=2, Ch=128, S=1, B=4, T=6, H=256, W=256, gt=3, tau=0.4), min_count=100))
+    torch.cuda.empty_cache()
+
+
 def test_vgg_s16_feature_maps_vs_fp32_feature_maps(lib):
     """round 5: S16 feature maps (pre-split operand pairs written by the producing epilogue) vs fp32 feature maps, same library, same inputs: small frames with every launch
     forced well-filled, and 256x256 frames where the launcher picks"""
