@@ -294,6 +294,9 @@ int caddy_k_conv_pick_bn(int cout);
 /* split 16-bit operand form of a layer's weights for the 16-bit-MFMA convolution (conv_hx.hip): seg < 0 forward, else dgrad of that segment */
 int caddy_k_hx_pick_bn(int cout);
 int caddy_k_hx_force_big(int v);      /* tests: 1 / 0 force / forbid the 8-wave 16x16x128 tile variant, -1 automatic */
+int caddy_k_hx_set_bg(int mask);   /* tests / A-B runs: which under-filled k_conv_hx tile variants read their weight fragments straight from global memory (conv_hx.hip, template
+                                    * parameter BG; bit 0: 4x16x64, bit 1: 8x16x64, bit 2: 8x16x32 tiles; bit 3: also for workgroups that walk fewer than four 32-channel chunks); -1: the
+                                    * CADDY_HX_BG environment variable, default 7 */
 long caddy_k_hx_weight_bytes(const struct PackDesc* d, int seg, int rows_pad, int planes);
 int caddy_k_pack_hx(const struct PackDesc* d, void* wq, int rows_pad, int seg, int precision, void* stream);
 int caddy_k_pack_fwd(const struct PackDesc* d, float* wp, void* stream);

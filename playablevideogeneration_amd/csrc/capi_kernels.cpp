@@ -23,6 +23,7 @@ int caddy_k_conv_pick_bn(int cout) { return conv_pick_bn(cout); }
 int caddy_k_conv_avgpool_ok(const ConvArgs* a) { return conv_avgpool_ok(*a); }
 int caddy_k_hx_pick_bn(int cout) { return hx_pick_bn(cout); }
 int caddy_k_hx_force_big(int v) { g_hx_big_override = v; return 0; }
+int caddy_k_hx_set_bg(int mask) { g_hx_bg = mask; return 0; }
 long caddy_k_hx_weight_bytes(const PackDesc* d, int seg, int rows_pad, int planes) { return (long)hx_weight_bytes(*d, seg, rows_pad, planes); }
 int caddy_k_pack_hx(const PackDesc* d, void* wq, int rows_pad, int seg, int precision, void* s) { return pack_hx(*d, wq, rows_pad, seg, precision, ST(s)); }
 int caddy_k_pack_fwd(const PackDesc* d, float* wp, void* s) { return pack_fwd(*d, wp, ST(s)); }

@@ -205,7 +205,11 @@ int pack_hx(const PackDesc& d, void* wq, int rows_pad, int seg /* < 0: forward f
 size_t hx_weight_bytes(const PackDesc& d, int seg, int rows_pad, int planes);
 int hx_kq(const PackDesc& d, int seg);
 int hx_pick_bn(int cout);
+// Split 16-bit weight buffers ([tap][chunk][Cout_pad rows][planes x 32 channels], conv_hx.hip: pk_hx_elem): 16-byte piece index, inside its (tap, chunk) tile, of channels
+// 8 g .. 8 g + 7 (g = 0 .. 3) of plane 0 of row `row`; plane 1 is 64 pieces further.  Fragment-major inside every 32-row block: [K half g >> 1][plane][lane = 32 (g & 1) + row & 31].
+template <int NPL> __host__ __device__ __forceinline__ long hx_wq_piece(int row, int g) { return ((long)((row >> 5) * 2 + (g >> 1)) * NPL) * 64 + (g & 1) * 32 + (row & 31); }
 extern int g_hx_big_override;
+extern int g_hx_bg;      // conv_hx.hip: which under-filled tile variants take their weight fragments straight from global memory (bit mask; -1: CADDY_HX_BG or all)
 int conv_split_reduce_pool_launch(const float* scr, long stride, int splits, int ldc, int N, int H, int W, int C, float* out, long out_sn, int out_ld, const float* bias, int act,
                                   const float* res, long res_sn, int res_ld, hipStream_t st);      // slab reduce + avg_pool2d(2) (+ bias / residual / activation at the pooled size)
 int conv_split_reduce_lstm_launch(const float* scr, long stride, int splits, int ldc, int HW, long P, const float* bias, const LstmFuse& f, hipStream_t st);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
     __syncthreads();
     const int px = lane & 15, kg = lane >> 4;                 // B fragment: pixel column, k-group (8 channels); A fragment: output channel row px, same k-group
     const int py = AP ? 2 * y + (px >> 3) : y, pxx = x0 + (AP ? (px & 7) : px);      // this lane's input-resolution pixel
-    const _Float16* wq = reinterpret_cast<const _Float16*>(a.wq) + ((long)co0 + px) * (2 * DK) + kg * 8;
+    const _Float16* wq = reinterpret_cast<const _Float16*>(a.wq) + hx_wq_piece<2>(co0 + px, kg) * 8;      // (fragment-major piece order of the packed weights, common.h)
     const long wstep = (long)a.Cout_pad * (2 * DK);           // halves between consecutive (tap, chunk) tiles
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned amax = 0u;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_direct(ConvArgs a, int groups_
             xb[u] = *reinterpret_cast<const float4*>(p + (c + 4 < r.C ? c + 4 : 0));
             const _Float16* w = wq + ((long)tap * nchunks + chunk) * wstep;
             wh[u] = *reinterpret_cast<const h8*>(w);
-            wl[u] = *reinterpret_cast<const h8*>(w + DK);
+            wl[u] = *reinterpret_cast<const h8*>(w + 64 * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {

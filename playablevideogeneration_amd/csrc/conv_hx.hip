@@ -179,7 +179,15 @@ __device__ __forceinline__ void hx_epilogue(f32x16 (&acc)[TMt][TNt], float (&st1
 // IO (round 5): operand formats at the kernel boundary.  bit 0 (PS): the input segment is PRE-SPLIT ("S16", common.h) -- the staging is a plain 16-byte copy per lane, no
 // conversion, no range guard (the producer applied it).  bit 1 (SO): the epilogue writes `out` / `pool_out` as S16 of T -- split once per OUTPUT element instead of once
 // per staged halo element in every output-channel block of every consumer (the 512-channel VGG19 layers staged and converted each halo tile four times).
-template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, int EP = 0, int IO = 0>
+// BG (round 6): the under-filled tile variants with the WEIGHT fragments straight from global memory / L2 into registers.  A (tap, chunk) step of a 4 x 16 or 8 x 16-pixel tile
+// is 6 - 12 MFMAs per wave between two barriers (weight tile -> LDS -> barrier -> fragment reads), ~890 cycles measured against 190 - 380 of matrix work, and every wave read
+// A and B fragments of 32 x 32 outputs each: 4 LDS fragment reads per 3 MFMAs.  Here the two waves of a row pair (wm = 2 wr + kh) multiply the SAME 2 x (BM / WM) pixel rows, each
+// with one 16-channel half (kh) of every 32-channel step: the B fragment of (tap, chunk, kh) is one 16-byte load per lane and plane from the packed weights (a row's 16-byte
+// pieces ARE the fragments; D-deep register ring, no LDS, no barrier), the A fragments of twice the rows are read for half the channels -- 2 fragment reads + 1 load per 3 MFMAs,
+// no redundant weight traffic between the waves.  The halo image is double-buffered (the next chunk is stored while this one is multiplied): ONE barrier per 32-channel chunk
+// instead of ten.  After the loop the two waves exchange the halves of their partial tiles through LDS (partial of kh = 0 + partial of kh = 1: a fixed order) and continue with
+// the usual accumulator layout -- epilogues, BatchNorm partial sums, K split unchanged.
+template <typename T, int NPL, int TH, int TW, int BN, int WM, int WN, int D, int EP = 0, int IO = 0, int BG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_x, int tiles_y) {
     typedef typename Vec<T>::v8 v8;
     typedef typename Vec<T>::v4 v4;
@@ -204,8 +212,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     static_assert((WM * WN == 4 || WM * WN == 8) && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave layout");
     static_assert(TW == 16, "row <-> pixel map assumes 16-pixel tile rows");
     static_assert(D == 1 || D == 3, "9 taps per chunk: the ring depth must divide 9");
-    __shared__ __attribute__((aligned(16))) T As[HH_ * AROW];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BN * PITCH];
+    constexpr bool BGM = BG != 0;
+    constexpr int TMF = BGM ? 2 * TMt : TMt;                 // M tiles a wave multiplies (BG: the rows of its wave pair)
+    constexpr int ASZ = HH_ * AROW;
+    static_assert(!BGM || (NPL == 2 && (WM & 1) == 0 && D == 3 && EP == 0 && (IO & 2) == 0), "BG: split operands, wave row pairs, plain epilogue");
+    static_assert(!BGM || 2 * ASZ * (int)sizeof(T) >= WM * WN * TMt * TNt * 16 * 64 * 4, "BG: the exchange of the partial tiles fits into the halo buffers");
+    __shared__ __attribute__((aligned(16))) T As[(BGM ? 2 : 1) * ASZ];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BGM ? 8 : BN * PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // (staging steps are macros, not lambdas: a by-reference capture of the kernel-argument struct / register arrays forces them into
     //  scratch memory)
     float4 ra[NA];
+    int asto = 0;                                             // element offset of the halo buffer HX_STORE_A writes (BG: the buffer of the NEXT chunk)
     unsigned amax = 0u;                                       // split-f16 only: largest |x| this thread staged, as a bit pattern -- NaN > inf > finite (saturation guard, ConvArgs.sat_flag)
     float4 rsc, rsh;                                          // lazily applied BatchNorm of the producer (ConvSrc.bn_*): scale / shift of this thread's four channels, chunk in flight
 #define HX_SEG_OF(chunk_)                                                                                                          \
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 if (HPX % APP == 0 || p_ < HPX) {                                                                                  \
                     float4 v_ = ra[i];                                                                                             \
                     if (pixoff[i] < 0) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
-                    *reinterpret_cast<float4*>(&As[aoff[i]]) = v_;                                                                 \
+                    *reinterpret_cast<float4*>(&As[asto + aoff[i]]) = v_;                                                          \
                 }                                                                                                                  \
             }                                                                                                                      \
             break;                                                                                                                 \
@@ -313,8 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 hi_[0] = (T)x0_; hi_[1] = (T)x1_; hi_[2] = (T)x2_; hi_[3] = (T)x3_;                                                \
                 lo_[0] = (T)(x0_ - (float)hi_[0]); lo_[1] = (T)(x1_ - (float)hi_[1]);                                             \
                 lo_[2] = (T)(x2_ - (float)hi_[2]); lo_[3] = (T)(x3_ - (float)hi_[3]);                                             \
-                *reinterpret_cast<v4*>(&As[aoff[i]]) = hi_;                                                                       \
-                if (NPL == 2) *reinterpret_cast<v4*>(&As[aoff[i] + KC]) = lo_;                                                    \
+                *reinterpret_cast<v4*>(&As[asto + aoff[i]]) = hi_;                                                                \
+                if (NPL == 2) *reinterpret_cast<v4*>(&As[asto + aoff[i] + KC]) = lo_;                                             \
             }                                                                                                                      \
         }                                                                                                                          \
     } while (0)
@@ -334,8 +348,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     do {                                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                                          \
             const int idx_ = tid + NT * i;                                                                                        \
-            if ((BN * BROW16) % NT == 0 || idx_ < BN * BROW16) { const int row_ = idx_ / BROW16, c16_ = idx_ - row_ * BROW16;     \
-                                      *reinterpret_cast<u32x4*>(&Bs[buf_][row_ * PITCH + c16_ * 8]) = rb[set_][i]; }              \
+            if ((BN * BROW16) % NT == 0 || idx_ < BN * BROW16) {      /* piece idx_ of the tile in fragment-major order (pk_hx_elem) -> its place in the row-major LDS tile */ \
+                const int f_ = (idx_ >> 6) % (2 * NPL), l_ = idx_ & 63;                                                          \
+                *reinterpret_cast<u32x4*>(&Bs[buf_][((idx_ / (128 * NPL)) * 32 + (l_ & 31)) * PITCH + (f_ % NPL) * KC + (f_ / NPL) * 16 + (l_ >> 5) * 8]) = rb[set_][i]; } \
         }                                                                                                                          \
     } while (0)
     // weight tile of the flattened step index st_ = (chunk - ch0) * 9 + tap, if it exists
@@ -344,11 +359,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     do { int s__ = (st_); s__ = s__ < nsteps ? s__ : nsteps - 1; const int c__ = s__ / 9; HX_LOAD_B(set_, s__ - 9 * c__, ch0 + c__); } while (0)
 
     // ---- fragment addresses ----
-    int abase[TMt], bbase[TNt];
+    int abase[TMF], bbase[TNt];
 #pragma unroll
-    for (int i = 0; i < TMt; i++) {
-        const int m = wm * (BM / WM) + i * 32 + (lane & 31);
-        abase[i] = (m / TW) * AROW + (m % TW) * PITCH + (lane >> 5) * 8;
+    for (int i = 0; i < TMF; i++) {
+        const int m = (BGM ? (wm & ~1) : wm) * (BM / WM) + i * 32 + (lane & 31);
+        abase[i] = (m / TW) * AROW + (m % TW) * PITCH + (lane >> 5) * 8 + (BGM ? (wm & 1) * 16 : 0);
     }
 #pragma unroll
     for (int j = 0; j < TNt; j++) bbase[j] = (wn * (BN / WN) + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 8;
@@ -365,6 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     const int cper = (nchunks + a.splitk - 1) / a.splitk;
     const int ch0 = blockIdx.z * cper, ch1 = ch0 + cper < nchunks ? ch0 + cper : nchunks;
     const int nsteps = ch0 < ch1 ? (ch1 - ch0) * 9 : 0;
+    if constexpr (!BGM) {
     if (ch0 < ch1) {
         HX_LOAD_A(ch0);
 #pragma unroll
@@ -412,6 +428,117 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 bbuf ^= 1;
             }
         }
+    }
+    } else {
+    // ---- BG: weight fragments straight into a D-deep register ring, halo image double-buffered, one barrier per chunk ----
+    f32x16 accf[TMF][TNt];
+#pragma unroll
+    for (int i = 0; i < TMF; i++)
+#pragma unroll
+        for (int j = 0; j < TNt; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) accf[i][j][r] = 0.f;
+    // this lane's 16 bytes of the B fragment (32-row block (n0 + wn (BN / WN)) / 32 + j, K half kh = wm & 1, plane pl): 1 KB contiguous per fragment (pk_hx_elem's order)
+    const T* wqb = wq + ((long)((((n0 + wn * (BN / WN)) >> 5) * 2 + (wm & 1)) * NPL) * 64 + lane) * 8;
+    // ring depth = one chunk: the weights of R's gate convolutions (10 - 20 MB split) do not stay in an XCD's 4-MB L2, every workgroup of an XCD walks them in step, so each
+    // (tap, chunk) tile is a miss for all of them at once -- ~1 us from the memory-side cache against 0.08 - 0.16 us of matrix work per tap.  (Depth 3: 70.0 us for the 528 -> 1024
+    // gate convolution of a 16 x 16 map; see profiles/r06_experiments.md)
+    constexpr int DB = 9;
+    v8 fbr[DB][TNt][NPL];
+#ifndef HX_EXP
+#define HX_EXP 0      /* timing studies (tools/build_exp.sh; results are wrong with any bit set): 1 no halo conversion / store in the loop, 2 no weight loads, 4 no fragment reads, 8 no halo loads */
+#endif
+#define HX_LOAD_BG(set_, st_)                                                                                                      \
+    do { int s__ = (st_); s__ = s__ < nsteps ? s__ : nsteps - 1; const int c__ = s__ / 9;                                         \
+         const T* g_ = wqb + ((long)(s__ - 9 * c__) * nchunks + (ch0 + c__)) * wrow;                                               \
+         _Pragma("unroll") for (int j = 0; j < TNt; j++)                                                                          \
+             _Pragma("unroll") for (int pl = 0; pl < NPL; pl++) fbr[set_][j][pl] = *reinterpret_cast<const v8*>(g_ + (j * 2 * NPL + pl) * (64 * 8)); \
+    } while (0)
+    // A fragments of tap t_ (row blocks i0_ ... i0_ + HM - 1, both planes) into register set fs_
+#define HX_READ_FA(fs_, t_, i0_)                                                                                                   \
+    do { const int toff_ = ((t_) / 3) * AROW + ((t_) % 3) * PITCH;                                                               \
+         _Pragma("unroll") for (int i = 0; i < HM; i++)                                                                           \
+             _Pragma("unroll") for (int pl = 0; pl < NPL; pl++) fa[fs_][i][pl] = *reinterpret_cast<const v8*>(&Ac[abase[(i0_) + i] + toff_ + pl * KC]); \
+    } while (0)
+    if (ch0 < ch1) {
+        HX_LOAD_A(ch0);
+#pragma unroll
+        for (int d = 0; d < DB; d++) HX_LOAD_BG(d, d);
+        HX_STORE_A(ch0);                                      // (buffer 0)
+    }
+    __syncthreads();
+    int cur = 0, step = 0;
+    for (int chunk = ch0; chunk < ch1; chunk++) {
+        const T* Ac = As + cur * ASZ;
+        // A fragments ahead of their MFMAs (with one register set hipcc re-used eight registers for every fragment pair and each MFMA triple waited for its own LDS round trip):
+        // TMF = 2: the fragments of tap t + 1 are requested before the MFMAs of tap t (two sets); TMF = 4: half a tap ahead -- the upper row blocks of tap t are requested before
+        // the MFMAs of its lower row blocks, the lower row blocks of tap t + 1 before the MFMAs of the upper ones (two half sets: 32 registers instead of 64 keep the instance at
+        // two waves per SIMD beside the nine-deep weight ring)
+        constexpr int HM = TMF >= 4 ? TMF / 2 : TMF;          // row blocks per fragment set
+        v8 fa[2][HM][NPL];
+#define HX_MFMA_SET(fs_, i0_)                                                                                                     \
+        do {      /* small terms first; product-major: consecutive MFMAs go to different accumulators (the order per accumulator is what matters for the result) */ \
+            _Pragma("unroll") for (int i = 0; i < HM; i++)                                                                        \
+                _Pragma("unroll") for (int j = 0; j < TNt; j++) accf[(i0_) + i][j] = mfma16(fa[fs_][i][1], fbr[d][j][0], accf[(i0_) + i][j]); \
+            _Pragma("unroll") for (int i = 0; i < HM; i++)                                                                        \
+                _Pragma("unroll") for (int j = 0; j < TNt; j++) accf[(i0_) + i][j] = mfma16(fa[fs_][i][0], fbr[d][j][1], accf[(i0_) + i][j]); \
+            _Pragma("unroll") for (int i = 0; i < HM; i++)                                                                        \
+                _Pragma("unroll") for (int j = 0; j < TNt; j++) accf[(i0_) + i][j] = mfma16(fa[fs_][i][0], fbr[d][j][0], accf[(i0_) + i][j]); \
+        } while (0)
+        HX_READ_FA(0, 0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++, step++) {
+            const int d = tap % DB;
+            if (TMF >= 4) {
+                if (!(HX_EXP & 4)) HX_READ_FA(1, tap, HM);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_MFMA_SET(0, 0);
+                if (tap + 1 < 9 && !(HX_EXP & 4)) HX_READ_FA(0, tap + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_MFMA_SET(1, HM);
+            } else {
+                const int fs = tap & 1;
+                if (tap + 1 < 9 && !(HX_EXP & 4)) HX_READ_FA(fs ^ 1, tap + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                HX_MFMA_SET((HX_EXP & 4) ? 0 : fs, 0);
+            }
+            if (!(HX_EXP & 2)) HX_LOAD_BG(d, step + DB);      // refill the register set just used
+            if (tap == 3 && !(HX_EXP & 8)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile (last chunk: re-requested, unused)
+            // (without a barrier in the loop nothing stops hipcc's scheduler from sinking these loads down to their first use, a chunk later: load -> s_waitcnt vmcnt(0) -> MFMA,
+            //  the ring gone.  Nothing may cross this point.)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef HX_MFMA_SET
+        if (chunk + 1 < ch1 && !(HX_EXP & 1)) { asto = (cur ^ 1) * ASZ; HX_STORE_A(chunk + 1); }      // into the other buffer: every wave passed the previous barrier, i.e. is done reading it
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef HX_READ_FA
+#undef HX_LOAD_BG
+    // exchange: wave (wr, kh) keeps the M tiles kh TMt ... of its pair's rows and receives the partner's partial sums of them; sum = partial of kh 0 + partial of kh 1
+    {
+        float* xr = reinterpret_cast<float*>(As);             // (every wave is past the loop's last barrier: the halo buffers are dead)
+        const bool kh = (wm & 1) != 0;
+        const int pw = (wm ^ 1) * WN + wn;
+#pragma unroll
+        for (int i = 0; i < TMt; i++)
+#pragma unroll
+            for (int j = 0; j < TNt; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) xr[(((wave * TMt + i) * TNt + j) * 16 + r) * 64 + lane] = kh ? accf[i][j][r] : accf[TMt + i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TMt; i++)
+#pragma unroll
+            for (int j = 0; j < TNt; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float got = xr[(((pw * TMt + i) * TNt + j) * 16 + r) * 64 + lane];
+                    const float own = kh ? accf[TMt + i][j][r] : accf[i][j][r];
+                    acc[i][j][r] = kh ? got + own : own + got;
+                }
+        __syncthreads();                                      // (the BatchNorm partial sums below reuse the buffer)
+    }
     }
 
     if (!is_bf16<T>::value && a.sat_flag != nullptr && amax > 0x477fe000u /* bits of 65504.f */) atomicOr(a.sat_flag, amax > 0x7f800000u ? 3u : 1u);      // bit 1: a NaN among them      // (rare: one atomic per saturating thread)
@@ -493,9 +620,13 @@ __device__ __forceinline__ void pk_hx_elem(const PackDesc& d, T* wq, int Cout_pa
     }
     if (sizeof(T) == 2 && !is_bf16<T>::value) v *= HX_WSCALE;      // f16 forms only (see HX_WSCALE)
     const T hi = (T)v;
-    T* o = wq + (((long)tap * nch + ch) * Cout_pad + row) * (NPL * KC) + kk;
+    // FRAGMENT-MAJOR order inside every 32-row block of a (tap, chunk) tile (round 6; same bytes, permuted): [K half kh = kk >> 4][plane][lane = 32 (kk >> 3 & 1) + row & 31][8 halves]
+    // -- the 1-KB run of (row block, kh, plane) IS the B operand of one v_mfma_f32_32x32x16 (lane l: row l & 31, eight channels (l >> 5) of the K half), so the kernels that take
+    // their weight fragments straight from global memory (k_conv_hx<BG>) read it with one fully coalesced 16-byte load per lane; the LDS-staged kernels undo the permutation
+    // when they store their 16-byte pieces (HX_STORE_B), conv_direct.hip addresses its 16 x 16 x 32 fragments through hx_wq_piece
+    T* o = wq + ((long)tap * nch + ch) * Cout_pad * (NPL * KC) + hx_wq_piece<NPL>(row, kk >> 3) * 8 + (kk & 7);
     o[0] = hi;
-    if (NPL == 2) o[KC] = (T)(v - (float)hi);
+    if (NPL == 2) o[64 * 8] = (T)(v - (float)hi);            // (plane 1: the next 64 pieces)
 }
 __device__ __forceinline__ int pk_hx_nch(const PackDesc& d, int dgrad_seg) {
     int Kq = 0;
@@ -559,6 +690,7 @@ int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int total_blocks, hipSt
 }
 int hx_pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 int g_hx_big_override = -1;      // tests: force (1) / forbid (0) the 8-wave 16x16x128 tile variant regardless of the grid size
+int g_hx_bg = -1;                // tests / A-B runs: >= 0 overrides CADDY_HX_BG (which under-filled tile variants take their weight fragments straight from global memory)
 
 // does conv_hx_try run a launch of this geometry on one of the two tile variants that carry the fused max-pool epilogue (EP = 1)?
 // (the same decisions as below, incl. the test override)
@@ -669,15 +801,25 @@ int conv_hx_try(const ConvArgs& a0, hipStream_t st, bool dry) {
     // 4-wave variants: 3-deep register ring of weight tiles (with one step of prefetch the next tile has ~0.4 us to arrive from L2, less than its latency under load; measured,
     // E/R/A/D step: ring on launches of <= 256 / 512 / 1024 workgroups / always: 77.2 / 75.5 / 75.8 / 75.5 ms, batch-1 roll-out frame -3 %).  The single-product study
     // precisions (PREC_*X1, tools/bench_hx.py) keep one step of prefetch.
+    // round 6: the under-filled variants with the weight fragments straight into registers (template parameter BG of k_conv_hx) -- split operands, plain epilogue, fp32 output.
+    // g_hx_bg / CADDY_HX_BG: bit 0 the 4 x 16 x 64 tile, bit 1 8 x 16 x 64, bit 2 8 x 16 x 32 (tests and A/B runs; default all)
+    static const int bg_env = []() { const char* e = getenv("CADDY_HX_BG"); return e ? atoi(e) : 7; }();
+    // ... and only where a workgroup walks at least four 32-channel chunks: the nine-deep ring's prologue and the exchange of the partial tiles are pure overhead for the 1 - 2 chunks
+    // of a K-split 64-channel layer (measured alone: E res 64 -> 64 @32 15.0 -> 15.9 us, R same 272 -> 128 @16 (8 K slices) 22.5 -> 23.6 us; 4+ chunks: -10 ... -25 %)
+    const int bgm = (nchunks + a.splitk - 1) / a.splitk >= 4 || g_hx_bg >= 8 ? ((g_hx_bg >= 0 ? g_hx_bg : bg_env) & 7) : 0;
 #define HX_LAUNCH(T_, NPL_, EP_, IO_)                                                                                             \
     do {                                                                                                                          \
         constexpr int D_ = NPL_ == 2 ? 3 : 1;                                                                                     \
+        constexpr int BG_ = (NPL_ == 2 && EP_ == 0 && ((IO_) & 2) == 0) ? 1 : 0;                                                  \
         if (big) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 128, 4, 2, 3, EP_, IO_>), grid, dim3(512), 0, st, a, tx, ty);    \
         else if (bn == 128) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 128, 2, 2, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);   \
-        else if (th4) hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0, IO_>), grid, dim3(256), 0, st, a, tx, ty);       /* (plain epilogue only) */ \
-        else if (bn == 64 && small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);   \
+        else if (th4) { if (bgm & 1) hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0, IO_, 1>), grid, dim3(256), 0, st, a, tx, ty);       /* (plain epilogue only) */ \
+                        else hipLaunchKernelGGL((k_conv_hx<T_, 2, 4, 16, 64, 2, 2, 3, 0, IO_>), grid, dim3(256), 0, st, a, tx, ty); }   \
+        else if (bn == 64 && small_tiles) { if ((bgm & 2) && BG_) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_, IO_, BG_>), grid, dim3(256), 0, st, a, tx, ty);   \
+                                            else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 64, 2, 2, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty); }   \
         else if (bn == 64) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 64, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);    \
-        else if (small_tiles) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty); \
+        else if (small_tiles) { if ((bgm & 4) && BG_) hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_, IO_, BG_>), grid, dim3(256), 0, st, a, tx, ty); \
+                                else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 8, 16, 32, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty); } \
         else hipLaunchKernelGGL((k_conv_hx<T_, NPL_, 16, 16, 32, 4, 1, D_, EP_, IO_>), grid, dim3(256), 0, st, a, tx, ty);                  \
     } while (0)
     if (a.avgpool && !a.split_stride) return dry ? 0 : -1;      // (a whole-K tile launch has no pooled epilogue)

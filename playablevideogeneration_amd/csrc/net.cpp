@@ -777,13 +777,18 @@ T4 caddy_ctx::bn_act(const T4& x, BNL& bn, const T4* x2, BNL* bn2, bool actf, co
         tp->push_back([=]() {
             TV om = dv(out);
             const TV* omp = actf ? &om : nullptr;
+            // single-input BatchNorm + LeakyReLU: the slope decision of act(x * scale + shift) is recomputed from x, which both passes read anyway (the same fused multiply-add as
+            // the forward's FBnApply: bit-identical decisions) -- the materialised output is not read a second and third time (round 6)
+            const bool mask_x = actf && !has2 && !small && mask_from_x;
+            const TV* omr = mask_x ? nullptr : omp;
+            const float* lsx = mask_x ? s1.scale : nullptr;
             if (small) {
                 TV dres{}; if (has2) dres = gv(x2c);
                 RUN(pw_bn_small_bwd(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, gv_w(x, x.nz), bn_dgamma(b1), bn_dbeta(b1), has2 ? &dres : nullptr, x.nz ? 1 : 0, stream, (has2 && x2c.nz2) ? 1 : 0));
                 return;
             }
-            RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream));   // sums assigned; param grads fused
-            RUN(pw_bn_bwd_apply(gv(out), omp, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv_w(x, x.nz), nullptr, nullptr, x.nz ? 1 : 0, stream));
+            RUN(pw_bn_bwd_reduce(gv(out), omr, dv(x), s1.mean, s1.invstd, s1.sums, red_scratch, bn_dgamma(b1), bn_dbeta(b1), stream, lsx, s1.shift));   // sums assigned; param grads fused
+            RUN(pw_bn_bwd_apply(gv(out), omr, dv(x), s1.mean, s1.invstd, b1->gamma, s1.sums, gv_w(x, x.nz), nullptr, nullptr, x.nz ? 1 : 0, stream, lsx, s1.shift));
             if (has2 && b2) {
                 RUN(pw_bn_bwd_reduce(gv(out), omp, dv(x2c), s2.mean, s2.invstd, s2.sums, red_scratch, bn_dgamma(b2), bn_dbeta(b2), stream));
                 RUN(pw_bn_bwd_apply(gv(out), omp, dv(x2c), s2.mean, s2.invstd, b2->gamma, s2.sums, gv_w(x2c, x2c.nz), nullptr, nullptr, x2c.nz ? 1 : 0, stream));
@@ -1548,6 +1553,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (caddy_serial_streams()) c->use_dstream = false;
     hipMemset(c->sat_flag, 0, sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // (second half: sticky until polled, caddy_f16_saturated)
     if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
+    if (const char* e = getenv("CADDY_MASK_FROM_X")) c->mask_from_x = atoi(e) != 0;      // A/B aid: 0 = BatchNorm backward reads the materialised output for the LeakyReLU slope (round-5 form)
     if (const char* e = getenv("CADDY_S16_GRADS")) c->s16_grads = atoi(e) != 0;      // A/B aid: 0 = every model gradient as fp32 (round-5 form)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
     if (const char* e = getenv("CADDY_PRECISION")) {      // A/B + parity aid: "exact" = every convolution on the exact-fp32 MFMA path

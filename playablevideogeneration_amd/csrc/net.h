@@ -137,6 +137,7 @@ struct caddy_ctx {
     bool tape2_done = false;
     std::vector<T4> dbg;             // every alloc() of the current forward (debug introspection, caddy_debug_*)
     std::deque<GradFmt> gfmts;       // gradient formats of this forward's convolution outputs (T4::gs points here: a deque keeps the addresses stable)
+    bool mask_from_x = true;         // BatchNorm backward of a single-input BatchNorm + LeakyReLU takes the slope from x * scale + shift instead of reading the output (CADDY_MASK_FROM_X=0: round-5 form)
     bool s16_grads = true;           // conv-output gradients pre-split by their producers where every reader understands it (CADDY_S16_GRADS=0: fp32 everywhere, the round-5 exchange)
     std::vector<ConvL*> convs;
     std::vector<BNL*> bns;

@@ -102,6 +102,7 @@ inline void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t, hipStream_t, Arg
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu::mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* scheduling hint only */
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)      /* scheduling hint only */
 static inline void __threadfence() {}      /* workgroups run one after the other on the simulator */
 
 static inline void __syncthreads() { emu::syncthreads(); }

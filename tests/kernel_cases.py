@@ -1180,3 +1180,16 @@ def s16_grad_case(lib, dev, *, N, H, W, Cin, Cout, seed=0, force_big=-1, produce
             assert (outs[0] - 1.0).abs().max().item() > 0
     finally:
         lib.caddy_k_hx_force_big(-1)
+
+
+def hx_register_weights_case(lib, dev, cases):
+    """round 6 (conv_hx.hip, template parameter BG): the under-filled tile variants with the weight fragments straight from global memory -- every case runs with the variants
+    forced on (caddy_k_hx_set_bg(15): bit 3 lifts the chunks-per-workgroup threshold) and forced off (0: LDS-staged weight tiles); hx_conv_case / s16_grad_case check each
+    against the fp64 reference, so the two forms agree to the split-operand error although their summation orders differ (K halves per wave + one exchange vs whole K per wave)."""
+    for mask in (15, 0):
+        lib.caddy_k_hx_set_bg(mask)
+        try:
+            for kind, kw in cases:
+                (hx_conv_case if kind == "conv" else s16_grad_case)(lib, dev, **kw)
+        finally:
+            lib.caddy_k_hx_set_bg(-1)

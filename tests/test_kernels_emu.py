@@ -234,3 +234,15 @@ def test_s16_gradients_small():
     K.s16_grad_case(lib, "cpu", N=1, H=9, W=18, Cin=40, Cout=64, seed=1)                # ragged tiles, channel tail on the dgrad's output side
     K.s16_grad_case(lib, "cpu", N=2, H=6, W=16, Cin=32, Cout=32, seed=2)                # <= 32 output channels of the weight gradient: row-split waves
     K.s16_grad_case(lib, "cpu", N=1, H=16, W=16, Cin=128, Cout=64, seed=3, force_big=1, producers=False)      # 8-wave 16 x 16 x 128 tile
+
+
+def test_conv_hx_register_weight_variants_small():
+    """round 6: k_conv_hx<BG> -- 8 x 16 x 64 / 8 x 16 x 32 / 4 x 16 x 64-pixel tile variants with the weights straight into a register ring, K halves per wave pair, double-buffered
+    halo: ragged tiles, three segments incl. a broadcast vector, channel tails, accumulating dgrads (deterministic K split and whole K), pre-split dY, an odd number of chunks"""
+    K.hx_register_weights_case(load_emu(), "cpu", [
+        ("conv", dict(N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=48, bias=True)),                      # 8 x 16 x 64, 4 chunks, three segments
+        ("conv", dict(N=1, H=9, W=17, segs=[(96, False)], Cout=32, act=3, seed=1)),                                             # 8 x 16 x 32 (four row-pair waves), 3 chunks
+        ("conv", dict(N=1, H=8, W=16, segs=[(40, False)], Cout=64, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True, seed=2)),   # split-bf16 dgrad on 4 x 16 tiles
+        ("conv", dict(N=1, H=14, W=64, segs=[(256, False)], Cout=128, bias=True, act=3, direct="tile4", split=True, seed=3)),   # inference 4 x 16 tiles, K split into slabs
+        ("s16", dict(N=2, H=8, W=16, Cin=64, Cout=160, seed=4, producers=False)),                                                # pre-split dY, 5 chunks
+    ])

@@ -275,3 +275,17 @@ def test_pre_split_gradient_tensors(lib, kw):
 def test_streaming_weight_gradients(lib, kw):
     """round 5 (conv_stream.hip): k_wgrad_head7 (7x7 head, split bf16, taps on the M side) and k_wgrad_1x1 (identity paths, operands straight from global memory)"""
     K.conv_case(lib, "cuda", **kw)
+
+
+def test_conv_hx_register_weight_variants(lib):
+    """round 6: k_conv_hx<BG> at the shapes of R's gate convolutions and their dgrads (and the simulator's small cases), forced on and off"""
+    K.hx_register_weights_case(lib, "cuda", [
+        ("conv", dict(N=1, H=10, W=20, segs=[(40, False), (9, True), (33, False)], Cout=48, bias=True)),
+        ("conv", dict(N=1, H=9, W=17, segs=[(96, False)], Cout=32, act=3, seed=1)),
+        ("conv", dict(N=8, H=32, W=32, segs=[(128, False), (16, True), (128, False)], Cout=512, bias=True, seed=2)),              # lstm0 gates: 8 x 16 x 64, 512 workgroups
+        ("conv", dict(N=8, H=16, W=16, segs=[(256, False), (16, True), (256, False)], Cout=1024, bias=True, seed=3)),             # lstm1 gates
+        ("conv", dict(N=8, H=32, W=32, segs=[(512, False)], Cout=128, precision=K.PREC_BF16X3, dgrad_seg=0, accumulate=True, seed=4)),   # gate dgrad: 4 x 16 tiles, 16 chunks
+        ("conv", dict(N=1, H=14, W=64, segs=[(256, False)], Cout=128, bias=True, act=3, direct="tile4", split=True, seed=5)),
+        ("s16", dict(N=8, H=32, W=32, Cin=128, Cout=512, seed=6, producers=False)),
+        ("s16", dict(N=8, H=16, W=16, Cin=256, Cout=1024, seed=7, producers=False)),
+    ])
