@@ -35,7 +35,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 MFMA16_DENSE_PEAK_TFLOPS = 2500.0 # same guide: bf16 / f16 dense MFMA (v_mfma_f32_32x32x16_{f16,bf16})
 SPLIT_PRODUCTS = 3                # conv_hx: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the 16-bit pipe -> 3 MFMA FLOPs per algorithmic FLOP
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "profiles/r05_pmc_traffic_{workload}{suffix}.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh <workload>)
+PMC_FILE = "profiles/r06_pmc_traffic_{workload}{suffix}.json"      # HBM bytes per launch from THIS round's separate rocprofv3 --pmc passes (tools/gpu_pmc.sh <workload>)
 HX_FAMILIES = ("k_conv_hx<128>", "k_conv_hx<64>", "k_conv_hx<32>", "k_wgrad_hx", "k_conv_hx<128, 8 waves>")
 VGG_CONVS = [(3, 64, 0), (64, 64, 0), (64, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 2), (256, 256, 2), (256, 256, 2), (256, 512, 3),
              (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 4)]      # (Cin, Cout, number of 2x2 max-pools before): conv1_1 .. conv5_1

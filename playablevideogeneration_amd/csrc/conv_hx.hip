@@ -445,6 +445,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
     // gate convolution of a 16 x 16 map; see profiles/r06_experiments.md)
     constexpr int DB = 9;
     v8 fbr[DB][TNt][NPL];
+#ifndef HX_BG_LOADA_TAP
+#define HX_BG_LOADA_TAP 1      /* tap behind which the next chunk's halo tile is requested (alone: behind tap 3 76.7 us, tap 1 65.5, tap 0 67.2 for the 528 -> 1024 gate convolution; in situ no difference) */
+#endif
 #ifndef HX_EXP
 #define HX_EXP 0      /* timing studies (tools/build_exp.sh; results are wrong with any bit set): 1 no halo conversion / store in the loop, 2 no weight loads, 4 no fragment reads, 8 no halo loads */
 #endif
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
                 HX_MFMA_SET((HX_EXP & 4) ? 0 : fs, 0);
             }
             if (!(HX_EXP & 2)) HX_LOAD_BG(d, step + DB);      // refill the register set just used
-            if (tap == 3 && !(HX_EXP & 8)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile (last chunk: re-requested, unused)
+            if (tap == HX_BG_LOADA_TAP && !(HX_EXP & 8)) HX_LOAD_A(chunk + 1 < ch1 ? chunk + 1 : chunk);      // next halo tile (last chunk: re-requested, unused)
             // (without a barrier in the loop nothing stops hipcc's scheduler from sinking these loads down to their first use, a chunk later: load -> s_waitcnt vmcnt(0) -> MFMA,
             //  the ring gone.  Nothing may cross this point.)
             __builtin_amdgcn_sched_barrier(0);
