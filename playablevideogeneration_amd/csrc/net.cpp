@@ -423,6 +423,31 @@ void caddy_ctx::replay_tape2(bool concurrent) {
         leave_d();
     }
 }
+// chunk table of the time-chunked perceptual pass: nch chunks over the Trec reconstructed frames, LAST time steps first (perc_t0[0] = Trec > perc_t0[1] > ... > perc_t0[nch] = 0);
+// the late chunks are the larger ones (what is left behind the last chunk -- its steps' BPTT and the E / A tail -- has nothing to run beside)
+void caddy_ctx::perc_plan(int Trec, bool chunked) {
+    // chunking pays where the VGG19 launches of a chunk still fill the chip: BAIR 256 x 256 x 15 x 8 (7.9 M pixels) -3.5 ms with two chunks; Breakout 160 x 208 x 8 x 8 (2.1 M) +0.2 ms,
+    // Breakout 64 x 64 x 7 x 4 +3.5 ms (profiles/r06_experiments.md section 9).  caddy_debug_set_perc_chunks overrides the size test.
+    const bool big = (long)cfg.batch * Trec * cfg.height * cfg.width >= (4L << 20);
+    int n = !chunked ? 1 : (perc_chunks_force > 0 ? perc_chunks_force : (big ? perc_chunks_cfg : 1));
+    if (n > PERC_MAX_CHUNKS) n = PERC_MAX_CHUNKS;
+    if (n > Trec) n = Trec;
+    if (n < 1) n = 1;
+    perc_nch = n; perc_trec = Trec;
+    int t = Trec;
+    for (int k = 0; k < n; k++) { perc_t0[k] = t; const int left = n - k; t -= (t + left - 1) / left; }
+    perc_t0[n] = 0;
+}
+// tape replay, in front of the backward of time step t: the seeds d(rec_r) of that step's frames must be final -- wait for the event of the chunk that holds them (and, with
+// stacked observations, the frames the step's feedback encoder adds to: up to stacking - 1 steps earlier)
+void caddy_ctx::perc_wait(int t) {
+    if (!perc_pipelined || dry) return;
+    t -= cfg.stacking - 1;
+    if (t < 0) t = 0;
+    int k = 0;
+    while (k + 1 < perc_nch && t < perc_t0[k + 1]) k++;
+    for (int j = 0; j <= k; j++) if (!perc_waited[j]) { hipStreamWaitEvent(stream, perc_ev[j], 0); perc_waited[j] = true; }
+}
 void caddy_ctx::fold_d_bn_grads() {
     VecAddJobs j{};
     for (BNL* b : bns) {
@@ -1131,7 +1156,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
             c->leave_d();
             if (t + 2 >= gt_init || t + 2 >= T) c->tape.push_back([c]() {      // (reverse replay: runs right before R-bwd of the last teacher-forced step)
                 if (c->d_forked && !c->dry) { hipStreamWaitEvent(c->stream, c->d_done, 0); c->d_forked = false; c->fold_d_bn_grads(); }
-                else if (!c->tape2_done) c->replay_tape2(false);
+                else if (!c->tape2_done) { c->perc_wait(0); c->replay_tape2(false); }      // (pipelined perceptual pass: the teacher-forced decoder steps need every chunk's seeds)
             });
         } else c->render(hdn, t, T - 1);
         if (t + 1 >= gt_init) {   // feed the reconstruction back through E (model.py:249-258, compute_current_observation :499-543)
@@ -1152,6 +1177,7 @@ static int forward_full(caddy_ctx* c, const float* obs, int gt_init, float tau, 
             T4 dst = tslice(c->rec_x65, B, T, t + 1);
             c->encode(fb, true, &dst);
         }
+        if (c->recording && g.perceptual) c->tape.push_back([c, t]() { c->perc_wait(t); });      // (reverse replay: first thing of this time step's backward)
     }
     c->mark("fwd:closed-loop steps");
     if (c->recording) c->tape.push_back([c]() { c->mark("bwd:A2"); });
@@ -1290,6 +1316,9 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         if (!dry) c->ck(loss_l1(dv(c->obs), dv(f), gv(f), 1 << r, c->pretraining ? 0 : 1, T, Trec, (float)(w.rec / 3.0 / nr[r]), c->loss_acc + LOSS_L1_R0 + r, perc ? gt_img[r].d : nullptr, st), "loss_l1");
     }
     VggLevels lv{};
+    // round 6: with several chunks (perc_plan) the VGG19 work runs on the side stream, chunk by chunk from the last time steps, BESIDE the tape replay below
+    c->perc_pipelined = perc && lc->perceptual != 0.0 && c->perc_nch > 1 && !c->pretraining && !c->prof && !dry && !caddy_serial_streams() && c->use_side && c->side != nullptr;
+    if (c->perc_pipelined) for (int k = 0; k < c->perc_nch; k++) { if (!c->perc_ev[k]) hipEventCreateWithFlags(&c->perc_ev[k], hipEventDisableTiming); c->perc_waited[k] = false; }
     if (perc) vgg_perceptual(c, lc->perceptual, gt_img, &lv);      // VGG19 features of both branches + d(term)/d(rec_r) added to the L1 seeds
     T4 sa = chan(c->x65_gt, 0, 64), sb = chan(c->rec_x65, 0, 64);
     double nst = (double)sa.N * 64 * sa.H * sa.W;
@@ -1315,19 +1344,25 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
     a.Pbuf = c->q_prob + (size_t)B * (T - 1) * K;      // K*K floats allocated behind q_prob
     a.mi_grad_scale = (float)(c->hook ? c->world : 1);
     if (!dry) c->ck(loss_small(a, c->hook, c->hook_user, st), "loss_small");
-    if (!dry) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize");
+    // (pipelined perceptual pass: its level sums arrive on the side stream -- the totals are formed behind the join at the end)
+    auto join_perc = [&]() { if (c->perc_pipelined) { hipEvent_t e = c->sev(); hipEventRecord(e, c->side); hipStreamWaitEvent(st, e, 0); } };
+    if (!dry && !c->perc_pipelined) c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize");
     if (lc->diagnostics && !dry) {      // logging-only scalars (trainer.py:475-491): states = output 3, hidden states = output 4 (5 in pretraining): R's hidden states
         DiagArgs dg{c->head1.b.samples, c->head1.b.ddist, c->head2.b.ddist, c->head1.b.variations, c->centroids, B * (T - 1), K, Da, c->loss_acc};
         c->ck(loss_diagnostics(dg, dv(sa), dv(c->hidden), st), "loss_diagnostics");
     }
     if (c->seeds_only) {      // test aid (caddy_debug_set_seeds_only): stop after the loss kernels -- the gradient arena holds d(loss)/d(output) of the direct loss terms only
+        if (!dry && c->perc_pipelined) { join_perc(); c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize"); c->perc_pipelined = false; }
         if (!dry && losses_host) { hipMemcpyAsync(losses_host, c->loss_acc, sizeof(double) * LOSS_SLOTS, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); }
         return finish(c);
     }
     c->mark("bwd:losses (+ VGG19)");
     // the decoder backward of the teacher-forced steps only needs the loss seeds: start it on its own stream, beside the serial BPTT chain
     c->tape2_done = false;
-    if (!c->tape2.empty() && c->use_dstream && !dry) { c->replay_tape2(true); c->tape2_done = true; }
+    // (pipelined perceptual pass: those steps' seeds are in the LAST chunk -- a decoder stream waiting for it would hold up the auxiliary jobs the BPTT chain forks onto that
+    //  stream; the steps are replayed at their place in the main tape instead, behind perc_wait(0).  Starting them on the decoder stream once the last chunk has run was measured:
+    //  no gain, profiles/r06_experiments.md section 9)
+    if (!c->tape2.empty() && c->use_dstream && !dry && !c->perc_pipelined) { c->replay_tape2(true); c->tape2_done = true; }
     for (size_t i = c->tape.size(); i-- > 0;) c->tape[i]();
     c->flush_all_wgrad();
     c->join_aux(st);
@@ -1335,6 +1370,10 @@ static int loss_backward(caddy_ctx* c, const caddy_loss_cfg* lc, double* losses_
         hipEvent_t e = c->sev();
         hipEventRecord(e, c->side);
         hipStreamWaitEvent(st, e, 0);
+    }
+    if (!dry && c->perc_pipelined) {      // (the join above covered the side stream: every chunk has run)
+        c->ck(loss_finalize(c->loss_acc, w, nr[0], nr[1], nr[2], nst, nhid, perc ? &lv : nullptr, st), "loss_finalize");
+        c->perc_pipelined = false;
     }
     c->mark("bwd:A1 + E(gt)");
     c->unpack_all();
@@ -1553,6 +1592,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (caddy_serial_streams()) c->use_dstream = false;
     hipMemset(c->sat_flag, 0, sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // (second half: sticky until polled, caddy_f16_saturated)
     if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
+    if (const char* e = getenv("CADDY_PERC_CHUNKS")) c->perc_chunks_cfg = atoi(e);      // A/B aid: 1 = the one-pass perceptual loss of rounds 2 - 5
     if (const char* e = getenv("CADDY_MASK_FROM_X")) c->mask_from_x = atoi(e) != 0;      // A/B aid: 0 = BatchNorm backward reads the materialised output for the LeakyReLU slope (round-5 form)
     if (const char* e = getenv("CADDY_S16_GRADS")) c->s16_grads = atoi(e) != 0;      // A/B aid: 0 = every model gradient as fp32 (round-5 form)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
@@ -1566,6 +1606,7 @@ extern "C" int caddy_dp_shutdown(caddy_ctx* c);
 void caddy_ctx_destroy(caddy_ctx* c) {
     if (c && (c->comm || c->comm2)) caddy_dp_shutdown(c);
     if (c && c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c) for (int k = 0; k < caddy_ctx::PERC_MAX_CHUNKS; k++) if (c->perc_ev[k]) hipEventDestroy(c->perc_ev[k]);
     if (c && c->gstream) { if (c->graph_exec) hipStreamSynchronize(c->stream); hipStreamSynchronize(c->gstream); c->drop_graph(); hipStreamDestroy(c->gstream); }
     if (c) for (ConvL* L : c->convs) if (L->off_ev) hipEventDestroy(L->off_ev);
     if (c && c->dstream) { hipStreamSynchronize(c->dstream); hipStreamDestroy(c->dstream); if (c->d_done) hipEventDestroy(c->d_done); }
@@ -1576,6 +1617,7 @@ int caddy_debug_set_poison(caddy_ctx* c, int on) { c->poison_nz = on != 0; retur
 int caddy_debug_set_bn_paths(caddy_ctx* c, int small, int lazy, int epilogue_stats) { c->bn_small = small != 0; c->lazy_bn = lazy != 0; c->epi_stats = epilogue_stats != 0; return 0; }
 int caddy_debug_set_vgg_s16(caddy_ctx* c, int on) { c->vgg_s16 = on != 0; return 0; }
 int caddy_debug_set_s16_grads(caddy_ctx* c, int on) { c->s16_grads = on != 0; return 0; }
+int caddy_debug_set_perc_chunks(caddy_ctx* c, int n) { c->perc_chunks_force = n; return 0; }
 long caddy_debug_s16_grad_count(caddy_ctx* c) { long n = 0; for (const GradFmt& g : c->gfmts) n += g.fmt ? 1 : 0; return n; }
 int caddy_debug_set_pack_merged(caddy_ctx* c, int on) { c->merged_pack = on != 0; c->pack_jobs.key = -1; for (auto& j : c->unpack_jobs) j.key = -1; return 0; }
 int caddy_debug_set_seeds_only(caddy_ctx* c, int on) { c->seeds_only = on != 0; return 0; }

@@ -191,7 +191,22 @@ struct caddy_ctx {
     bool vgg_s16 = true;             // VGG19 feature maps / feature gradients of well-filled layers as S16 tensors (caddy_debug_set_vgg_s16; CADDY_VGG_S16=0)
     int prec_fwd = PREC_F16X3, prec_bwd = PREC_BF16X3;                 // ... of the model's wide 3x3 convolutions (caddy_set_precision; CADDY_PRECISION=exact)
     // ground-truth VGG19 branch overlapped with the forward pass on the side stream (perceptual.hip: vgg_gt_prefetch)
-    T4 gt_img[3]{}, gt_taps[3][5]{}; size_t gt_scratch_off = 0, gt_scratch_end = 0; bool gt_prefetched = false, perc_prefetch = true; hipEvent_t gt_done = nullptr;
+    T4 gt_img[3]{}; size_t gt_scratch_off = 0, gt_scratch_end = 0; bool gt_prefetched = false, perc_prefetch = true; hipEvent_t gt_done = nullptr;
+    // Time-chunked perceptual pass (round 6; perceptual.hip, net.cpp: loss_backward).  The reconstructed frames are handed to VGG19 in chunks of time steps, LAST steps first, on the
+    // side stream; chunk k covers t in [perc_t0[k + 1], perc_t0[k]) of the Trec reconstructed frames of every sample.  The BPTT replay on the main stream waits per time step for the
+    // event of the chunk that holds that step's frames (perc_wait): the latency-bound BPTT chain of the late steps runs beside the throughput-bound VGG19 work of the early ones
+    // instead of behind all of it.  perc_nch = 1: the one-pass form of rounds 2 - 5.  The ground-truth taps of a forward pass are laid out per chunk (gt_taps_c).
+    static constexpr int PERC_MAX_CHUNKS = 8;
+    int perc_chunks_cfg = 2;         // requested chunks (CADDY_PERC_CHUNKS, caddy_debug_set_perc_chunks; 1 = one pass).  Measured at BAIR 256 x 256 x 16 x 8: 2 chunks -3.5 ms, 3 - 4 -2 ms, 8 +8 ms
+    int perc_chunks_force = 0;       // > 0: caddy_debug_set_perc_chunks -- that many chunks whatever the size of the step
+    int perc_nch = 1, perc_trec = 0; // chunk table of the current forward pass
+    int perc_t0[PERC_MAX_CHUNKS + 1] = {};
+    hipEvent_t perc_ev[PERC_MAX_CHUNKS] = {};
+    bool perc_waited[PERC_MAX_CHUNKS] = {};
+    bool perc_pipelined = false;     // this loss_backward runs the chunks on the side stream beside the tape replay
+    T4 gt_taps_c[PERC_MAX_CHUNKS][3][5]{};
+    void perc_plan(int Trec, bool chunked);
+    void perc_wait(int t);
     size_t gt_lo = 0, gt_hi = 0;     // [gt_lo, gt_hi) of the activation arena: ground-truth VGG19 taps + scratch of vgg_gt_prefetch -- never back-propagated, so their gradient mirror is not zero-filled
     size_t fwd_off = 0;              // act.off at the end of the last forward: loss_backward allocates its VGG buffers past it and releases them
     int prof_kind_override = -1;     // profiling: record kind (3 = VGG forward, 4 = VGG dgrad) instead of 0 / 1

@@ -156,6 +156,17 @@ __global__ __launch_bounds__(256) void k_gt_resize(TV gt, float* out, int Ho, in
         reinterpret_cast<float4*>(out)[q] = o;
     }
 }
+// frames of the time steps [t0, t0 + len) of every sample, (B, Tfull) sample-major <-> (B, len) sample-major; F4 = float4 per frame.  add = 0: chunk[q] = full[...] (gather);
+// add = 1: full[...] += chunk[q] (the chunk's gradient back onto the seeds; each element has one writer per launch)
+__global__ __launch_bounds__(256) void k_time_chunk(float4* full, float4* chunk, long F4, int Tfull, int t0, int len, long total4, int add) {
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total4; q += (long)gridDim.x * 256) {
+        const long fr = q / F4, i = q - fr * F4;
+        const long b = fr / len, j = fr - b * len;
+        const long s = ((b * Tfull + t0 + j) * F4) + i;
+        if (add) { float4 a = full[s]; const float4 v = chunk[q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; full[s] = a; }
+        else chunk[q] = full[s];
+    }
+}
 __global__ void k_copy_f(const float* src, float* dst, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
@@ -362,23 +373,30 @@ void vgg_forward(caddy_ctx* c, const T4& img, Branch& B, const T4* taps, bool ke
 void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     bool dry = c->dry;
     const caddy_config& g = c->cfg;
-    const int N = g.batch * Trec;
     const int tc[5] = {64, 128, 256, 512, 512};
-    size_t scratch_bytes = 0;
+    // chunk table of this forward pass (caddy_ctx::perc_plan): the taps are laid out per chunk, whatever the loss call then does with them.  Pretraining (no BPTT chain to run
+    // beside) and evaluation passes keep one chunk.
+    c->perc_plan(Trec, c->training && !c->pretraining);
     c->gt_lo = (c->act.off + 255) & ~(size_t)255;
-    for (int r = 0; r < 3; r++) {
-        int h = g.height >> r, w = g.width >> r;
-        c->gt_img[r] = valloc(c, N, h, w, 3);                  // (ld 4)
-        for (int l = 0; l < 5; l++) { c->gt_taps[r][l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; }
+    T4 gimg[caddy_ctx::PERC_MAX_CHUNKS][3];
+    int kmax = 0;
+    for (int k = 0; k < c->perc_nch; k++) {
+        const int len = c->perc_t0[k] - c->perc_t0[k + 1], N = g.batch * len;
+        if (len > c->perc_t0[kmax] - c->perc_t0[kmax + 1]) kmax = k;
+        for (int r = 0; r < 3; r++) {
+            int h = g.height >> r, w = g.width >> r;
+            gimg[k][r] = valloc(c, N, h, w, 3);                 // (ld 4)
+            for (int l = 0; l < 5; l++) { c->gt_taps_c[k][r][l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; }
+        }
     }
-    {   // scratch for the non-tapped maps of the largest resolution (allocation pattern of vgg_forward at r = 0)
+    for (int r = 0; r < 3; r++) c->gt_img[r] = gimg[0][r];
+    {   // scratch for the non-tapped maps of the largest chunk at the largest resolution (allocation pattern of vgg_forward at r = 0)
         const size_t m0 = c->act.off;
         Branch G{};
         const bool was_dry = c->dry; c->dry = true;
-        vgg_forward(c, c->gt_img[0], G, c->gt_taps[0], false);
+        vgg_forward(c, gimg[kmax][0], G, c->gt_taps_c[kmax][0], false);
         c->dry = was_dry;
-        scratch_bytes = c->act.off - m0;
-        // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every resolution
+        // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every chunk and resolution
         c->gt_scratch_off = m0; c->gt_scratch_end = c->act.off;
     }
     c->gt_hi = c->act.off;
@@ -388,63 +406,88 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     if (!c->use_side || !c->side) return;
     hipStream_t main_st = c->stream, side = c->wgrad_stream();      // ordered after everything enqueued so far (the NHWC observations)
     c->stream = side;
-    for (int r = 0; r < 3; r++) {
-        const T4& gi = c->gt_img[r];
-        const long npix = (long)gi.N * gi.H * gi.W;
-        hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, side, dv(c->obs), gi.d, gi.H, gi.W, npix, 1 << r, t_off, g.seq_len, Trec);
-        const size_t keep = c->act.off;
-        c->act.off = c->gt_scratch_off;                        // (host-side bump pointer only: the region is private to the side stream)
-        Branch G{};
-        vgg_forward(c, gi, G, c->gt_taps[r], false);
-        for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) c->gt_taps[r][VGG[i].tap].fmt = G.a[i].fmt;      // (a tapped map may be an S16 tensor)
-        c->act.off = keep;
+    for (int k = 0; k < c->perc_nch; k++) {                  // (the order the loss call consumes them in: last time steps first)
+        const int t0 = c->perc_t0[k + 1], len = c->perc_t0[k] - t0;
+        for (int r = 0; r < 3; r++) {
+            const T4& gi = gimg[k][r];
+            const long npix = (long)gi.N * gi.H * gi.W;
+            hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, side, dv(c->obs), gi.d, gi.H, gi.W, npix, 1 << r, t_off + t0, g.seq_len, len);
+            const size_t keep = c->act.off;
+            c->act.off = c->gt_scratch_off;                    // (host-side bump pointer only: the region is private to the side stream)
+            Branch G{};
+            vgg_forward(c, gi, G, c->gt_taps_c[k][r], false);
+            for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) c->gt_taps_c[k][r][VGG[i].tap].fmt = G.a[i].fmt;      // (a tapped map may be an S16 tensor)
+            c->act.off = keep;
+        }
     }
     c->stream = main_st;
     hipEventRecord(c->gt_done, side);
     c->gt_prefetched = true;
-    (void)scratch_bytes;
 }
 
 // Called from loss_backward after the L1 terms (which also wrote the resized ground-truth images gt_img[r]) and before the tape is replayed:
 // accumulates d(perceptual term)/d(rec_r) into the gradients of c->frames[r] and the raw level sums into c->loss_acc.
+// Round 6: chunk by chunk of time steps (caddy_ctx::perc_t0, last steps first).  One chunk: the form of rounds 2 - 5 (the half- and quarter-resolution levels on the side stream
+// beside the full-resolution one, the dgrad of conv1_1 accumulating straight onto the L1 seeds).  Several chunks: a chunk's frames are gathered into a contiguous batch
+// (k_time_chunk), its gradient is assigned to the gathered copy and added onto the seeds of its time steps; with caddy_ctx::perc_pipelined ALL of it runs on the side stream and
+// an event per chunk tells the tape replay which time steps may start (perc_wait).
 void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv) {
     bool dry = c->dry;
     VggState& V = c->vgg;
     hipStream_t st = c->stream;
+    const caddy_config& g = c->cfg;
     const bool pre = c->gt_prefetched && !dry;      // the ground-truth branch already ran beside the forward pass (vgg_gt_prefetch)
-    if (pre) hipStreamWaitEvent(st, c->gt_done, 0);
+    const int nch = c->perc_nch, Trec = c->perc_trec, B = g.batch;
+    const bool pipe = c->perc_pipelined && nch > 1 && !dry;
     // The half- and quarter-resolution levels (24 % of the work, most of it in under-filled launches on 8x8 ... 64x64 maps) run on the driver's side
-    // stream BESIDE the full-resolution level: separate memory (they are allocated first and stay live until the join), their own thin-kernel
+    // stream BESIDE the full-resolution level (one-chunk form): separate memory (they are allocated first and stay live until the join), their own thin-kernel
     // scratch, the three levels only meet in the loss accumulators (atomics) and write disjoint gradient tensors (d rec_r).
     const bool no_par = caddy_serial_streams();
-    const bool par = !no_par && !dry && c->use_side && c->side != nullptr && !c->prof;
-    hipStream_t side = par ? c->wgrad_stream() : st;      // (ordered after the L1 kernels that wrote the seeds / resized ground truth)
+    const bool par = nch == 1 && !no_par && !dry && c->use_side && c->side != nullptr && !c->prof;
+    hipStream_t side = (par || pipe) ? c->wgrad_stream() : st;      // (ordered after the L1 kernels that wrote the seeds / resized ground truth)
+    if (pre) hipStreamWaitEvent(pipe ? side : st, c->gt_done, 0);
     const size_t mark_all = c->act.off;
     size_t side_end = mark_all;                             // memory layout is the parallel one whether or not the levels really overlap (dry-run sizing)
     const int order[3] = {1, 2, 0};
+    for (int k = 0; k < nch; k++) {
+    const int t0 = c->perc_t0[k + 1], len = c->perc_t0[k] - t0;
     for (int oi = 0; oi < 3; oi++) {
         const int r = order[oi];
-        const bool on_side = par && r != 0;
+        const bool on_side = pipe || (par && r != 0);
         c->stream = on_side ? side : st;
         hipStream_t st = c->stream;                         // (shadows the outer one for the point-wise launches below)
         float* const aux = on_side ? c->conv_aux2 : c->conv_aux;
-        if (r == 0 && !no_par) c->act.off = side_end;      // above everything levels 1 / 2 may still be using
-        const T4& rec = c->frames[r];
+        if (nch > 1) c->act.off = mark_all;                 // chunks and levels follow each other on one stream: they share the region
+        else if (r == 0 && !no_par) c->act.off = side_end;      // above everything levels 1 / 2 may still be using
+        const T4& full = c->frames[r];
         const size_t mark = c->act.off;
+        const long F4 = (long)full.H * full.W * (full.ld / 4);
+        // this chunk's reconstructed frames: the tensor itself (one chunk) or a gathered copy
+        T4 rec = full;
+        if (nch > 1) {
+            rec = valloc(c, B * len, full.H, full.W, 3);
+            if (full.ld != 4 || full.sn != F4 * 4) { c->fail = true; set_error("internal: frame tensor layout of the chunked perceptual pass"); }
+            if (!dry) hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)full.d, (float4*)rec.d, F4, Trec, t0, len, (long)rec.N * F4, 0);
+        }
         // ground-truth branch: keeps only the five tapped maps
         T4 taps[5];
         Branch G{}, R{};
-        if (pre) { for (int l = 0; l < 5; l++) taps[l] = c->gt_taps[r][l]; }
+        if (pre) { for (int l = 0; l < 5; l++) taps[l] = c->gt_taps_c[k][r][l]; }
         else {
             int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
             for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; }      // MaxPool2d floors odd sizes
+            T4 gi = gt_img[r];
+            if (nch > 1) {
+                gi = valloc(c, rec.N, rec.H, rec.W, 3);
+                if (!dry) hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)gt_img[r].d, (float4*)gi.d, F4, Trec, t0, len, (long)rec.N * F4, 0);
+            }
             const size_t mark2 = c->act.off;
-            vgg_forward(c, gt_img[r], G, taps, false);
+            vgg_forward(c, gi, G, taps, false);
             for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) taps[VGG[i].tap].fmt = G.a[i].fmt;
             c->act.off = mark2;                  // stream order: the temporaries of the ground-truth branch are dead before anything below overwrites them
         }
         vgg_forward(c, rec, R, nullptr, true);
-        // per-level sums and weights.  w_l = lambda * (l == 0 ? 1 : 2) / 3 / numel_l   (aliasing of level 0 with the total, see the header)
+        // per-level sums and weights.  w_l = lambda * (l == 0 ? 1 : 2) / 3 / numel_l   (aliasing of level 0 with the total, see the header); numel_l counts ALL B x Trec frames
         float wl[5];
         int li[5];
         for (int i = 0; i < VGG_NCONV; i++) if (VGG[i].tap >= 0) li[VGG[i].tap] = i;
@@ -459,7 +502,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
         for (int i = 0; i < VGG_NCONV; i++) gzs[i] = io_d[i] && (i + 1 == VGG_NCONV || VGG[i + 1].pool_before || io_d[i + 1]);
         for (int l = 0; l < 5; l++) {
             const T4& f = R.a[li[l]];
-            const double numel = (double)f.N * f.H * f.W * f.C;
+            const double numel = (double)B * Trec * f.H * f.W * f.C;
             lv->numel[r][l] = numel;
             wl[l] = (float)(lambda * (l == 0 ? 1.0 : 2.0) / 3.0 / numel);
             if (!dry) launch_feat_l1(st, f, taps[l], wl[l], l == 4 ? f.g : (float*)nullptr, gzs[li[4]], c->loss_acc + LOSS_PERC_R0 + 6 * r + 1 + l);
@@ -478,7 +521,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 if (d.precision != PREC_FP32 && L.wqd[0]) d.wq = L.wqd[d.precision == PREC_BF16X1 ? 1 : 0];
                 d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
                 d.in_s16 = gzs[i] ? 1 : 0;
-                if (i == 0) d.accumulate = 1;                                 // += into d(rec_r), next to the L1 seed
+                if (i == 0) d.accumulate = nch == 1 ? 1 : 0;                  // one chunk: += into d(rec_r), next to the L1 seed; chunks: assigned to the gathered copy, added below
                 else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue; the output IS gz_{i-1}
                     d.mask = in.d; d.mask_s16 = in.fmt;
                     if (VGG[i - 1].tap >= 0) { const T4& tp = taps[VGG[i - 1].tap]; d.seed_ref = tp.d; d.seed_w = wl[VGG[i - 1].tap]; d.seed_s16 = tp.fmt; }
@@ -489,9 +532,13 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                     if (!dry) launch_maxpool_bwd(st, R.a[i - 1], (const float*)in.g, gzs[i - 1]);
                 }
             }
+            if (nch > 1 && !dry)      // the chunk's d(rec_r) onto the seeds of its time steps
+                hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)full.g, (float4*)rec.g, F4, Trec, t0, len, (long)rec.N * F4, 1);
         }
         if (r != 0 && c->act.off > side_end) side_end = c->act.off;
-        c->act.off = mark;                                  // levels 1 and 2 share memory (same stream, in order)
+        if (nch == 1) c->act.off = mark;                    // levels 1 and 2 share memory (same stream, in order)
+    }
+    if (pipe) hipEventRecord(c->perc_ev[k], side);          // the seeds of the time steps [t0, t0 + len) are final
     }
     c->stream = st;
     if (par) {                                               // join: the tape replay reads d(rec_1), d(rec_2)

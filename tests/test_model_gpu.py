@@ -77,6 +77,17 @@ def test_perceptual_loss_parity(lib, name):
     print(info)
 
 
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+def test_perceptual_loss_parity_time_chunks(lib, chunks):
+    """round 6: the perceptual pass in chunks of time steps on the side stream beside the BPTT replay (library default: 2 chunks; net.cpp: perc_plan / perc_wait) -- the golden of the
+    reference's ParallelPerceptualLoss with one chunk (the one-pass form), three, and one chunk per time step (caddy_debug_set_perc_chunks clamps to the number of reconstructed
+    frames): level sums, totals, d(total)/d(rec_r) and the parameter gradients behind the per-step waits"""
+    import ctypes as C
+    lib.caddy_debug_set_perc_chunks.argtypes = [C.c_void_p, C.c_int]
+    eng, info = M.perceptual_case("perc_main_s1", lib, "cuda", prep=lambda e: lib.caddy_debug_set_perc_chunks(C.c_void_p(e.ctx), chunks))
+    print(chunks, info)
+
+
 def test_perceptual_loss_parity_s16_every_layer(lib):
     """round 5: the same golden with every VGG19 launch forced onto the well-filled tile variants, i.e. every feature map / feature gradient exchanged as an S16 tensor"""
     lib.caddy_k_hx_force_big(1)
