@@ -99,7 +99,7 @@ def test_checkpoint_loaded_before_cuda_then_step(tmp_path):
     m2 = m2.cuda(); m2.train()                                                               # train.py:67-68
     got = step(m2, tr2, 101)
     assert tr2.mi_ema.is_cuda and tr2.adam_m.is_cuda
-    assert got == want, (got, want)
+    assert abs(got - want) <= 1e-14 * abs(want), (got, want)      # (the loss scalars are fp64 atomic sums over blocks: the last bit depends on the arrival order -- seen once in ~10 suite runs; the parameters below are what must be bit-identical)
     assert torch.equal(m2._flat, m._flat), ("parameters after the resumed step", (m2._flat - m._flat).abs().max().item())      # (the default, atomic backward: +-2 lr on ~0 gradients)
 
 
