@@ -445,19 +445,23 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
     const bool no_par = caddy_serial_streams();
     const bool par = nch == 1 && !no_par && !dry && c->use_side && c->side != nullptr && !c->prof;
     hipStream_t side = (par || pipe) ? c->wgrad_stream() : st;      // (ordered after the L1 kernels that wrote the seeds / resized ground truth)
-    if (pre) hipStreamWaitEvent(pipe ? side : st, c->gt_done, 0);
+    if (pre) { hipStreamWaitEvent(st, c->gt_done, 0); if (pipe) hipStreamWaitEvent(side, c->gt_done, 0); }
     const size_t mark_all = c->act.off;
     size_t side_end = mark_all;                             // memory layout is the parallel one whether or not the levels really overlap (dry-run sizing)
-    const int order[3] = {1, 2, 0};
+    // Pipelined form: nothing runs beside the FIRST chunk (the tape replay waits for it), so that chunk keeps the level parallelism of the one-pass form -- its full-resolution
+    // level on the main stream (in front of the replay's launches), its half- and quarter-resolution levels on the side stream; the later chunks run on the side stream alone,
+    // beside the replay.  Memory: [mark_all, main_end) the first chunk's full-resolution level, everything the side stream touches above it.
+    size_t side_base = mark_all;
     for (int k = 0; k < nch; k++) {
     const int t0 = c->perc_t0[k + 1], len = c->perc_t0[k] - t0;
+    const bool first_par = nch > 1 && k == 0 && (pipe || dry);      // (dry run: the same layout)
     for (int oi = 0; oi < 3; oi++) {
-        const int r = order[oi];
-        const bool on_side = pipe || (par && r != 0);
+        const int r = first_par ? oi : (oi == 2 ? 0 : oi + 1);      // levels 1, 2, 0 -- the first chunk of the pipelined form 0 (main stream), 1, 2
+        const bool on_side = (pipe && !(first_par && r == 0)) || (par && r != 0);
         c->stream = on_side ? side : st;
         hipStream_t st = c->stream;                         // (shadows the outer one for the point-wise launches below)
         float* const aux = on_side ? c->conv_aux2 : c->conv_aux;
-        if (nch > 1) c->act.off = mark_all;                 // chunks and levels follow each other on one stream: they share the region
+        if (nch > 1) c->act.off = (first_par && r == 0) ? mark_all : side_base;      // chunks and levels that follow each other on one stream share their region
         else if (r == 0 && !no_par) c->act.off = side_end;      // above everything levels 1 / 2 may still be using
         const T4& full = c->frames[r];
         const size_t mark = c->act.off;
@@ -537,8 +541,9 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
         }
         if (r != 0 && c->act.off > side_end) side_end = c->act.off;
         if (nch == 1) c->act.off = mark;                    // levels 1 and 2 share memory (same stream, in order)
+        if (first_par && r == 0) side_base = c->act.off;
     }
-    if (pipe) hipEventRecord(c->perc_ev[k], side);          // the seeds of the time steps [t0, t0 + len) are final
+    if (pipe) hipEventRecord(c->perc_ev[k], side);          // the seeds of the time steps [t0, t0 + len) are final (first chunk: its full-resolution level is ordered by the main stream itself)
     }
     c->stream = st;
     if (par) {                                               // join: the tape replay reads d(rec_1), d(rec_2)
