@@ -426,10 +426,13 @@ void caddy_ctx::replay_tape2(bool concurrent) {
 // chunk table of the time-chunked perceptual pass: nch chunks over the Trec reconstructed frames, LAST time steps first (perc_t0[0] = Trec > perc_t0[1] > ... > perc_t0[nch] = 0);
 // the late chunks are the larger ones (what is left behind the last chunk -- its steps' BPTT and the E / A tail -- has nothing to run beside)
 void caddy_ctx::perc_plan(int Trec, bool chunked) {
-    // chunking pays where the VGG19 launches of a chunk still fill the chip: BAIR 256 x 256 x 15 x 8 (7.9 M pixels) -3.5 ms with two chunks; Breakout 160 x 208 x 8 x 8 (2.1 M) +0.2 ms,
-    // Breakout 64 x 64 x 7 x 4 +3.5 ms (profiles/r06_experiments.md section 9).  caddy_debug_set_perc_chunks overrides the size test.
-    const bool big = (long)cfg.batch * Trec * cfg.height * cfg.width >= (4L << 20);
-    int n = !chunked ? 1 : (perc_chunks_force > 0 ? perc_chunks_force : (big ? perc_chunks_cfg : 1));
+    // chunking pays where the VGG19 launches of a chunk still fill the chip (profiles/r06_experiments.md section 9): three chunks for steps of >= 4 M reconstructed pixels, two from
+    // 1 M, one pass below.  caddy_debug_set_perc_chunks / a negative CADDY_PERC_CHUNKS override the size test.
+    // (measured with the first chunk level-parallel: BAIR 7.9 M pixels one pass / 2 / 3 / 4 chunks 124.3 / 120.7 / 120.2 / 121.7 ms; Breakout-160 2.1 M pixels 39.4 / 37.2 / 40.0 ms;
+    //  Breakout-64 0.1 M pixels 12.3 / 14.9 / 18.5 ms)
+    const long px = (long)cfg.batch * Trec * cfg.height * cfg.width;
+    const int by_size = px >= (4L << 20) ? perc_chunks_cfg : (px >= (1L << 20) ? (perc_chunks_cfg < 2 ? perc_chunks_cfg : 2) : 1);
+    int n = !chunked ? 1 : (perc_chunks_force > 0 ? perc_chunks_force : by_size);
     if (n > PERC_MAX_CHUNKS) n = PERC_MAX_CHUNKS;
     if (n > Trec) n = Trec;
     if (n < 1) n = 1;
@@ -1592,7 +1595,7 @@ caddy_ctx* caddy_ctx_create(const caddy_config* cfg, float* params, float* grads
     if (caddy_serial_streams()) c->use_dstream = false;
     hipMemset(c->sat_flag, 0, sizeof(unsigned) * 2 * CADDY_N_FLAGS);      // (second half: sticky until polled, caddy_f16_saturated)
     if (const char* e = getenv("CADDY_DETERMINISTIC")) c->deterministic = atoi(e) != 0;      // profiling aid: the bit-reproducible backward without touching the caller (tools/gpu_serial_breakdown.sh)
-    if (const char* e = getenv("CADDY_PERC_CHUNKS")) c->perc_chunks_cfg = atoi(e);      // A/B aid: 1 = the one-pass perceptual loss of rounds 2 - 5
+    if (const char* e = getenv("CADDY_PERC_CHUNKS")) { const int n = atoi(e); if (n < 0) c->perc_chunks_force = -n; else c->perc_chunks_cfg = n; }      // (negative: that many chunks whatever the size of the step)      // A/B aid: 1 = the one-pass perceptual loss of rounds 2 - 5
     if (const char* e = getenv("CADDY_MASK_FROM_X")) c->mask_from_x = atoi(e) != 0;      // A/B aid: 0 = BatchNorm backward reads the materialised output for the LeakyReLU slope (round-5 form)
     if (const char* e = getenv("CADDY_S16_GRADS")) c->s16_grads = atoi(e) != 0;      // A/B aid: 0 = every model gradient as fp32 (round-5 form)
     if (const char* e = getenv("CADDY_VGG_S16")) c->vgg_s16 = atoi(e) != 0;      // A/B aid: 0 = every VGG19 feature map as fp32 (round-4 form)
