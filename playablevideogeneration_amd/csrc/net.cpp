@@ -440,6 +440,13 @@ void caddy_ctx::perc_plan(int Trec, bool chunked) {
     int t = Trec;
     for (int k = 0; k < n; k++) { perc_t0[k] = t; const int left = n - k; t -= (t + left - 1) / left; }
     perc_t0[n] = 0;
+    if (chunked && n > 1) if (const char* e = getenv("CADDY_PERC_BOUNDS")) {      // A/B aid: explicit inner boundaries, descending ("10,5" = [10, Trec) [5, 10) [0, 5))
+        int m = 0, b[PERC_MAX_CHUNKS];
+        for (const char* q = e; *q && m < PERC_MAX_CHUNKS - 1;) { b[m++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        bool ok = m >= 1; int prev = Trec;
+        for (int i = 0; i < m && ok; i++) { ok = b[i] > 0 && b[i] < prev; prev = b[i]; }
+        if (ok) { perc_nch = m + 1; perc_t0[0] = Trec; for (int i = 0; i < m; i++) perc_t0[i + 1] = b[i]; perc_t0[m + 1] = 0; }
+    }
 }
 // tape replay, in front of the backward of time step t: the seeds d(rec_r) of that step's frames must be final -- wait for the event of the chunk that holds them (and, with
 // stacked observations, the frames the step's feedback encoder adds to: up to stacking - 1 steps earlier)
