@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_hx(ConvArgs a, int tiles_
         }
     }
     } else {
-    // ---- BG: weight fragments straight into a D-deep register ring, halo image double-buffered, one barrier per chunk ----
+    // ---- BG: weight fragments straight into a nine-deep register ring, halo image double-buffered, one barrier per chunk ----
     f32x16 accf[TMF][TNt];
 #pragma unroll
     for (int i = 0; i < TMF; i++)
