@@ -197,7 +197,7 @@ struct caddy_ctx {
     // event of the chunk that holds that step's frames (perc_wait): the latency-bound BPTT chain of the late steps runs beside the throughput-bound VGG19 work of the early ones
     // instead of behind all of it.  perc_nch = 1: the one-pass form of rounds 2 - 5.  The ground-truth taps of a forward pass are laid out per chunk (gt_taps_c).
     static constexpr int PERC_MAX_CHUNKS = 8;
-    int perc_chunks_cfg = 3;         // requested chunks (CADDY_PERC_CHUNKS, caddy_debug_set_perc_chunks; 1 = one pass).  Measured at BAIR 256 x 256 x 16 x 8: 2 chunks -3.6 ms, 3 -4.2 ms, 4 -2.7 ms, 8 +8 ms
+    int perc_chunks_cfg = 4;         // requested chunks of the full-resolution level (CADDY_PERC_CHUNKS, caddy_debug_set_perc_chunks; 1 = one pass) for steps of >= 1 M reconstructed pixels
     int perc_chunks_force = 0;       // > 0: caddy_debug_set_perc_chunks -- that many chunks whatever the size of the step
     int perc_nch = 1, perc_trec = 0; // chunk table of the current forward pass
     int perc_t0[PERC_MAX_CHUNKS + 1] = {};

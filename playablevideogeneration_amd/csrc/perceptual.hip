@@ -380,10 +380,13 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     c->gt_lo = (c->act.off + 255) & ~(size_t)255;
     T4 gimg[caddy_ctx::PERC_MAX_CHUNKS][3];
     int kmax = 0;
+    // (only the full-resolution level is chunked: the half- and quarter-resolution levels -- a quarter of the work, in launches that under-fill the chip already at 120 frames --
+    //  keep all Trec frames of every sample in one batch, chunk 0)
     for (int k = 0; k < c->perc_nch; k++) {
-        const int len = c->perc_t0[k] - c->perc_t0[k + 1], N = g.batch * len;
+        const int len = c->perc_t0[k] - c->perc_t0[k + 1];
         if (len > c->perc_t0[kmax] - c->perc_t0[kmax + 1]) kmax = k;
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < (k == 0 ? 3 : 1); r++) {
+            const int N = g.batch * (r == 0 ? len : Trec);
             int h = g.height >> r, w = g.width >> r;
             gimg[k][r] = valloc(c, N, h, w, 3);                 // (ld 4)
             for (int l = 0; l < 5; l++) { c->gt_taps_c[k][r][l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; }
@@ -392,9 +395,15 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     for (int r = 0; r < 3; r++) c->gt_img[r] = gimg[0][r];
     {   // scratch for the non-tapped maps of the largest chunk at the largest resolution (allocation pattern of vgg_forward at r = 0)
         const size_t m0 = c->act.off;
-        Branch G{};
         const bool was_dry = c->dry; c->dry = true;
-        vgg_forward(c, gimg[kmax][0], G, c->gt_taps_c[kmax][0], false);
+        size_t end = m0;
+        for (int r = 0; r < 2; r++) {      // (the un-chunked half-resolution level can need more than a short full-resolution chunk)
+            Branch G{};
+            c->act.off = m0;
+            vgg_forward(c, gimg[r == 0 ? kmax : 0][r], G, c->gt_taps_c[r == 0 ? kmax : 0][r], false);
+            if (c->act.off > end) end = c->act.off;
+        }
+        c->act.off = end;
         c->dry = was_dry;
         // keep the region allocated (the main stream goes on allocating past it); the side stream re-walks it for every chunk and resolution
         c->gt_scratch_off = m0; c->gt_scratch_end = c->act.off;
@@ -407,8 +416,8 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     hipStream_t main_st = c->stream, side = c->wgrad_stream();      // ordered after everything enqueued so far (the NHWC observations)
     c->stream = side;
     for (int k = 0; k < c->perc_nch; k++) {                  // (the order the loss call consumes them in: last time steps first)
-        const int t0 = c->perc_t0[k + 1], len = c->perc_t0[k] - t0;
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < (k == 0 ? 3 : 1); r++) {
+            const int t0 = r == 0 ? c->perc_t0[k + 1] : 0, len = r == 0 ? c->perc_t0[k] - t0 : Trec;
             const T4& gi = gimg[k][r];
             const long npix = (long)gi.N * gi.H * gi.W;
             hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, side, dv(c->obs), gi.d, gi.H, gi.W, npix, 1 << r, t_off + t0, g.seq_len, len);
@@ -453,10 +462,12 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
     // beside the replay.  Memory: [mark_all, main_end) the first chunk's full-resolution level, everything the side stream touches above it.
     size_t side_base = mark_all;
     for (int k = 0; k < nch; k++) {
-    const int t0 = c->perc_t0[k + 1], len = c->perc_t0[k] - t0;
     const bool first_par = nch > 1 && k == 0 && (pipe || dry);      // (dry run: the same layout)
     for (int oi = 0; oi < 3; oi++) {
         const int r = first_par ? oi : (oi == 2 ? 0 : oi + 1);      // levels 1, 2, 0 -- the first chunk of the pipelined form 0 (main stream), 1, 2
+        if (r != 0 && k != 0) continue;                     // the half- and quarter-resolution levels are not chunked: all Trec frames with chunk 0 (vgg_gt_prefetch)
+        const bool whole = nch == 1 || r != 0;              // this level's batch is the frame tensor itself
+        const int t0 = whole ? 0 : c->perc_t0[k + 1], len = whole ? Trec : c->perc_t0[k] - t0;
         const bool on_side = (pipe && !(first_par && r == 0)) || (par && r != 0);
         c->stream = on_side ? side : st;
         hipStream_t st = c->stream;                         // (shadows the outer one for the point-wise launches below)
@@ -468,7 +479,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
         const long F4 = (long)full.H * full.W * (full.ld / 4);
         // this chunk's reconstructed frames: the tensor itself (one chunk) or a gathered copy
         T4 rec = full;
-        if (nch > 1) {
+        if (!whole) {
             rec = valloc(c, B * len, full.H, full.W, 3);
             if (full.ld != 4 || full.sn != F4 * 4) { c->fail = true; set_error("internal: frame tensor layout of the chunked perceptual pass"); }
             if (!dry) hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)full.d, (float4*)rec.d, F4, Trec, t0, len, (long)rec.N * F4, 0);
@@ -481,7 +492,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
             int h = rec.H, w = rec.W; const int tc[5] = {64, 128, 256, 512, 512};
             for (int l = 0; l < 5; l++) { taps[l] = valloc(c, rec.N, h, w, tc[l]); h /= 2; w /= 2; }      // MaxPool2d floors odd sizes
             T4 gi = gt_img[r];
-            if (nch > 1) {
+            if (!whole) {
                 gi = valloc(c, rec.N, rec.H, rec.W, 3);
                 if (!dry) hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)gt_img[r].d, (float4*)gi.d, F4, Trec, t0, len, (long)rec.N * F4, 0);
             }
@@ -525,7 +536,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                 if (d.precision != PREC_FP32 && L.wqd[0]) d.wq = L.wqd[d.precision == PREC_BF16X1 ? 1 : 0];
                 d.out = in.g; d.out_sn = in.sn; d.out_ld = in.ld;
                 d.in_s16 = gzs[i] ? 1 : 0;
-                if (i == 0) d.accumulate = nch == 1 ? 1 : 0;                  // one chunk: += into d(rec_r), next to the L1 seed; chunks: assigned to the gathered copy, added below
+                if (i == 0) d.accumulate = whole ? 1 : 0;                     // whole batch: += into d(rec_r), next to the L1 seed; a chunk: assigned to the gathered copy, added below
                 else if (!VGG[i].pool_before) {                               // direct input a[i-1]: ReLU mask (+ L1 seed when a[i-1] is tapped) in the epilogue; the output IS gz_{i-1}
                     d.mask = in.d; d.mask_s16 = in.fmt;
                     if (VGG[i - 1].tap >= 0) { const T4& tp = taps[VGG[i - 1].tap]; d.seed_ref = tp.d; d.seed_w = wl[VGG[i - 1].tap]; d.seed_s16 = tp.fmt; }
@@ -536,7 +547,7 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
                     if (!dry) launch_maxpool_bwd(st, R.a[i - 1], (const float*)in.g, gzs[i - 1]);
                 }
             }
-            if (nch > 1 && !dry)      // the chunk's d(rec_r) onto the seeds of its time steps
+            if (!whole && !dry)      // the chunk's d(rec_r) onto the seeds of its time steps
                 hipLaunchKernelGGL(k_time_chunk, dim3(grid_for((long)rec.N * F4)), dim3(256), 0, st, (float4*)full.g, (float4*)rec.g, F4, Trec, t0, len, (long)rec.N * F4, 1);
         }
         if (r != 0 && c->act.off > side_end) side_end = c->act.off;
