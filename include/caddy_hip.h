@@ -270,7 +270,7 @@ int caddy_debug_set_vgg_s16(caddy_ctx* ctx, int on);
 int caddy_debug_set_s16_grads(caddy_ctx* ctx, int on);
 /* tests / A-B runs (round 6): the VGG19 perceptual loss (training/losses.py:379-491) of a training step is evaluated in `n` chunks of time steps, last steps first, on the side stream
  * beside the BPTT replay, which waits per time step for its chunk; 1 = one pass over all frames before the replay (rounds 2 - 5); 0 = the library's choice
- * (four chunks of the full-resolution level for steps of >= 1 M reconstructed pixels, else one pass; CADDY_PERC_CHUNKS changes the four, a negative value forces its magnitude).  Takes effect at the next
+ * (three chunks of the full-resolution level for steps of >= 4 M reconstructed pixels, four from 1 M, else one pass; CADDY_PERC_CHUNKS changes the three, a negative value forces its magnitude).  Takes effect at the next
  * caddy_forward_full.  Same loss; gradients equal up to the summation order of the per-chunk launches. */
 int caddy_debug_set_perc_chunks(caddy_ctx* ctx, int n);
 long caddy_debug_s16_grad_count(caddy_ctx* ctx);

@@ -426,13 +426,14 @@ void caddy_ctx::replay_tape2(bool concurrent) {
 // chunk table of the time-chunked perceptual pass: nch chunks over the Trec reconstructed frames, LAST time steps first (perc_t0[0] = Trec > perc_t0[1] > ... > perc_t0[nch] = 0);
 // the late chunks are the larger ones (what is left behind the last chunk -- its steps' BPTT and the E / A tail -- has nothing to run beside)
 void caddy_ctx::perc_plan(int Trec, bool chunked) {
-    // chunking pays where the VGG19 launches of a chunk still fill the chip (profiles/r06_experiments.md section 9): four chunks for steps of >= 1 M reconstructed pixels, one
-    // pass below.  caddy_debug_set_perc_chunks / a negative CADDY_PERC_CHUNKS override the size test.
+    // chunking pays where the VGG19 launches of a chunk still fill the chip (profiles/r06_experiments.md section 9): three chunks for steps of >= 4 M reconstructed pixels, four
+    // from 1 M, one pass below.  caddy_debug_set_perc_chunks / a negative CADDY_PERC_CHUNKS override the size test.
     // (measured with the first chunk level-parallel: BAIR 7.9 M pixels one pass / 2 / 3 / 4 chunks 124.3 / 120.7 / 120.2 / 121.7 ms; Breakout-160 2.1 M pixels 39.4 / 37.2 / 40.0 ms;
     //  Breakout-64 0.1 M pixels 12.3 / 14.9 / 18.5 ms)
     const long px = (long)cfg.batch * Trec * cfg.height * cfg.width;
     // (only the full-resolution level chunked, the final form: BAIR 2 / 3 / 4 / 5 / 6 chunks 121.6 / 120.5 / 119.7 / 120.7 / 121.0 ms; Breakout-160 39.2 / 38.3 / 37.2 / 36.6 ms for 1 / 2 / 3 / 4)
-    const int by_size = px >= (1L << 20) ? perc_chunks_cfg : 1;
+    // (the smaller levels cut once, the final form: BAIR one pass / 2 / 3 / 4 chunks 127.0 / 123.2 / 121.4 / 123.0 ms; Breakout-160 39.9 / 37.0 / 37.6 / 36.9 ms)
+    const int by_size = px >= (4L << 20) ? perc_chunks_cfg : (px >= (1L << 20) ? (perc_chunks_cfg > 1 ? 4 : perc_chunks_cfg) : 1);
     int n = !chunked ? 1 : (perc_chunks_force > 0 ? perc_chunks_force : by_size);
     if (n > PERC_MAX_CHUNKS) n = PERC_MAX_CHUNKS;
     if (n > Trec) n = Trec;

@@ -197,7 +197,7 @@ struct caddy_ctx {
     // event of the chunk that holds that step's frames (perc_wait): the latency-bound BPTT chain of the late steps runs beside the throughput-bound VGG19 work of the early ones
     // instead of behind all of it.  perc_nch = 1: the one-pass form of rounds 2 - 5.  The ground-truth taps of a forward pass are laid out per chunk (gt_taps_c).
     static constexpr int PERC_MAX_CHUNKS = 8;
-    int perc_chunks_cfg = 4;         // requested chunks of the full-resolution level (CADDY_PERC_CHUNKS, caddy_debug_set_perc_chunks; 1 = one pass) for steps of >= 1 M reconstructed pixels
+    int perc_chunks_cfg = 3;         // requested chunks of the full-resolution level (CADDY_PERC_CHUNKS, caddy_debug_set_perc_chunks; 1 = one pass) for steps of >= 4 M reconstructed pixels (four from 1 M)
     int perc_chunks_force = 0;       // > 0: caddy_debug_set_perc_chunks -- that many chunks whatever the size of the step
     int perc_nch = 1, perc_trec = 0; // chunk table of the current forward pass
     int perc_t0[PERC_MAX_CHUNKS + 1] = {};
@@ -205,6 +205,16 @@ struct caddy_ctx {
     bool perc_waited[PERC_MAX_CHUNKS] = {};
     bool perc_pipelined = false;     // this loss_backward runs the chunks on the side stream beside the tape replay
     T4 gt_taps_c[PERC_MAX_CHUNKS][3][5]{};
+    // time range [t0, t0 + len) of resolution level r handled with chunk k (false: nothing).  The full-resolution level follows the chunk table; the half- and quarter-resolution
+    // levels (a quarter of the work, launches that under-fill the chip at 120 frames) are cut ONCE, at the boundary in front of chunk nch / 2: the late half runs with the first
+    // chunk (beside its full-resolution level), the early half in front of the full-resolution level of chunk nch / 2 -- whose event then covers it
+    bool perc_range(int r, int k, int* t0, int* len) const {
+        if (r == 0 || perc_nch == 1) { if (r != 0 && k != 0) return false; *t0 = r == 0 ? perc_t0[k + 1] : 0; *len = r == 0 ? perc_t0[k] - perc_t0[k + 1] : perc_trec; return true; }
+        const int kb = perc_nch / 2;
+        if (k == 0) { *t0 = perc_t0[kb]; *len = perc_trec - perc_t0[kb]; return true; }
+        if (k == kb) { *t0 = 0; *len = perc_t0[kb]; return true; }
+        return false;
+    }
     void perc_plan(int Trec, bool chunked);
     void perc_wait(int t);
     size_t gt_lo = 0, gt_hi = 0;     // [gt_lo, gt_hi) of the activation arena: ground-truth VGG19 taps + scratch of vgg_gt_prefetch -- never back-propagated, so their gradient mirror is not zero-filled

@@ -380,13 +380,13 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     c->gt_lo = (c->act.off + 255) & ~(size_t)255;
     T4 gimg[caddy_ctx::PERC_MAX_CHUNKS][3];
     int kmax = 0;
-    // (only the full-resolution level is chunked: the half- and quarter-resolution levels -- a quarter of the work, in launches that under-fill the chip already at 120 frames --
-    //  keep all Trec frames of every sample in one batch, chunk 0)
+    // (caddy_ctx::perc_range: the full-resolution level follows the chunk table, the half- and quarter-resolution levels are cut once)
     for (int k = 0; k < c->perc_nch; k++) {
-        const int len = c->perc_t0[k] - c->perc_t0[k + 1];
-        if (len > c->perc_t0[kmax] - c->perc_t0[kmax + 1]) kmax = k;
-        for (int r = 0; r < (k == 0 ? 3 : 1); r++) {
-            const int N = g.batch * (r == 0 ? len : Trec);
+        if (c->perc_t0[k] - c->perc_t0[k + 1] > c->perc_t0[kmax] - c->perc_t0[kmax + 1]) kmax = k;
+        for (int r = 0; r < 3; r++) {
+            int t0, len;
+            if (!c->perc_range(r, k, &t0, &len)) continue;
+            const int N = g.batch * len;
             int h = g.height >> r, w = g.width >> r;
             gimg[k][r] = valloc(c, N, h, w, 3);                 // (ld 4)
             for (int l = 0; l < 5; l++) { c->gt_taps_c[k][r][l] = valloc(c, N, h, w, tc[l]); h /= 2; w /= 2; }
@@ -416,8 +416,9 @@ void vgg_gt_prefetch(caddy_ctx* c, int Trec, int t_off) {
     hipStream_t main_st = c->stream, side = c->wgrad_stream();      // ordered after everything enqueued so far (the NHWC observations)
     c->stream = side;
     for (int k = 0; k < c->perc_nch; k++) {                  // (the order the loss call consumes them in: last time steps first)
-        for (int r = 0; r < (k == 0 ? 3 : 1); r++) {
-            const int t0 = r == 0 ? c->perc_t0[k + 1] : 0, len = r == 0 ? c->perc_t0[k] - t0 : Trec;
+        for (int r = 0; r < 3; r++) {
+            int t0, len;
+            if (!c->perc_range(r, k, &t0, &len)) continue;
             const T4& gi = gimg[k][r];
             const long npix = (long)gi.N * gi.H * gi.W;
             hipLaunchKernelGGL(k_gt_resize, dim3(grid_for(npix)), dim3(256), 0, side, dv(c->obs), gi.d, gi.H, gi.W, npix, 1 << r, t_off + t0, g.seq_len, len);
@@ -465,9 +466,9 @@ void vgg_perceptual(caddy_ctx* c, double lambda, const T4* gt_img, VggLevels* lv
     const bool first_par = nch > 1 && k == 0 && (pipe || dry);      // (dry run: the same layout)
     for (int oi = 0; oi < 3; oi++) {
         const int r = first_par ? oi : (oi == 2 ? 0 : oi + 1);      // levels 1, 2, 0 -- the first chunk of the pipelined form 0 (main stream), 1, 2
-        if (r != 0 && k != 0) continue;                     // the half- and quarter-resolution levels are not chunked: all Trec frames with chunk 0 (vgg_gt_prefetch)
-        const bool whole = nch == 1 || r != 0;              // this level's batch is the frame tensor itself
-        const int t0 = whole ? 0 : c->perc_t0[k + 1], len = whole ? Trec : c->perc_t0[k] - t0;
+        int t0, len;
+        if (!c->perc_range(r, k, &t0, &len)) continue;      // (the half- and quarter-resolution levels are cut once: caddy_ctx::perc_range)
+        const bool whole = len == Trec;                     // this level's batch is the frame tensor itself
         const bool on_side = (pipe && !(first_par && r == 0)) || (par && r != 0);
         c->stream = on_side ? side : st;
         hipStream_t st = c->stream;                         // (shadows the outer one for the point-wise launches below)
